@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- depth frames/sec through the per-frame KinectFusion path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A step = one depth frame through  u16-mm -> f32 -> gate -> bilateral -> vertices/normals -> 3-level ICP (10/5/4,
+device-resident Gauss-Newton) -> TSDF integrate -> raycast.  Frames are synthetic (Scene S, hybkinectfu_amd/scene.py) and
+already resident in HBM when the timed region starts.  N=1 runs BASELINE.json configs[1] ("C2": 512^3 @ 4 m, VGA);
+N>1 runs configs[3] ("C4": 1024^3 @ 6 m, z-slab per GPU, strong scaling) under torch.distributed/RCCL.
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (the TSDF fusion kernel, HBM-bound,
+timed with HIP events on the context's own stream) and `cpu_baseline` (the CPU oracle on a bounded sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from hybkinectfu_amd import lib as K  # noqa: E402
+from hybkinectfu_amd import scene as S  # noqa: E402
+
+P = S.STOCK
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def workload(n_gpus):
+    if n_gpus == 1:
+        return dict(name="C2", res=512, size=4.0, cam=S.vga_camera(), trunc_max=P["depth_trunc_max"], integ_dist=P["integrate_depth_trunc"],
+                    desc="C2: synthetic 640x480 depth stream (Scene S), 512^3 @ 4 m TSDF, 3-level ICP 10/5/4, 1xMI355X")
+    # C4: depth gates raised to the volume size so the whole 6 m volume is exercised
+    return dict(name="C4", res=1024, size=6.0, cam=S.vga_camera(), trunc_max=6.0, integ_dist=6.0,
+                desc="C4: synthetic 640x480 depth (Scene S), 1024^3 @ 6 m TSDF, z-slab per GPU, %d GPUs" % n_gpus)
+
+
+def cpu_baseline(wl, frames_mm, n_sample=3):
+    """The CPU oracle (oracle/, 'port') on the first n_sample frames of the same stream, all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    cores = O.set_threads(os.cpu_count() or 1)
+    cam = wl["cam"]
+    ocam = O.Cam.make(*cam)
+    vol = O.OVolume(wl["res"], wl["size"], P["volume_max_weight"])
+    pose = S.pose0(wl["size"])
+    mv = mn = None
+    t0 = time.perf_counter()
+    for k in range(n_sample):
+        tr = O.trunc_depth(O.depth_mm_to_m(frames_mm[k]), P["depth_trunc_min"], wl["trunc_max"])
+        fl = O.bilateral(tr, P["filter_sigma_pixel"], P["filter_sigma_depth"])
+        v = O.depth_to_vertices(fl, ocam)
+        n = O.vertices_to_normals(v)
+        if k > 0:
+            ok, pose = O.icp_estimate(O.pyramid(v, 3), O.pyramid(n, 3, True), O.pyramid(mv, 3), O.pyramid(mn, 3, True), ocam,
+                                      P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"], pose)
+        O.integrate(vol, tr, n, None, False, False, pose, P["integrate_sdf_trunc"], wl["integ_dist"], ocam, ocam)
+        mv, mn, _ = O.raycast(vol, False, pose, P["raycast_increment_factor"] * P["integrate_sdf_trunc"], ocam, P["depth_trunc_min"], wl["trunc_max"])
+    dt = time.perf_counter() - t0
+    return dict(value=round(n_sample / dt, 4), unit="frames/s", cores=int(cores), kind="port",
+                sample="%d frames of the same stream through oracle/libkforacle.so (preprocess+ICP+integrate+raycast), %.1f s" % (n_sample, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", action="store_true", help="extra instrumented pass: per-stage milliseconds to stderr")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    wl = workload(world)
+    cam, res, size = wl["cam"], wl["res"], wl["size"]
+    kcam = K.camera(*cam)
+    period = 100
+    n_unique = min(period, args.warmup + args.steps)
+    frames, _ = S.make_stream(n_unique, cam, size)
+    dev_frames = torch.from_numpy(frames.astype(np.int16)).cuda()        # u16 bits, resident in HBM
+    frame_bytes = cam[0] * cam[1] * 2
+
+    if world == 1:
+        from hybkinectfu_amd.pipeline import SingleGpuPipeline as Pipe
+        pipe = Pipe(kcam, res, size, wl, device=local_rank)
+    else:
+        from hybkinectfu_amd.pipeline import SlabPipeline as Pipe
+        pipe = Pipe(kcam, res, size, wl, rank=rank, world=world, device=local_rank)
+
+    def run(first, count):
+        for k in range(first, first + count):
+            pipe.process_frame_device(dev_frames.data_ptr() + (k % n_unique) * frame_bytes, k)
+
+    def barrier():
+        pipe.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    run(0, args.warmup)
+    barrier()
+    s0 = pipe.stats()
+    pipe.stage_timers(1 << 5)                 # time only the fusion kernel inside the timed region (two event records per frame)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.warmup, args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms, cnt = pipe.read_stage_ms()
+    s1 = pipe.stats()
+    lost = s1["frames_lost"] - s0["frames_lost"]
+    n_upd = (s1["updated_total"] - s0["updated_total"])
+    if dist is not None:
+        t = torch.tensor([float(n_upd), float(lost)], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        n_upd_all, lost = int(t[0].item()), int(t[1].item()) // world
+    else:
+        n_upd_all = n_upd
+    fps = args.steps / dt
+
+    # roofline of the dominant HBM kernel (k_integrate_bricks): algorithmic bytes per launch / measured duration
+    launches = max(int(cnt[5]), 1)
+    kern_ms = float(ms[5]) / launches
+    alg_bytes = (n_upd / max(args.steps, 1)) * 16.0 + cam[0] * cam[1] * 4.0       # N_upd x 2 x 8 B + depth map
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "integrate_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(wl["name"])
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                    traffic=traffic, kernel="k_integrate_bricks", kernel_ms=round(kern_ms, 5),
+                    algorithmic_bytes_per_launch=int(alg_bytes), n_upd_per_frame=int(n_upd / max(args.steps, 1)))
+
+    if args.stages and rank == 0:
+        pipe.stage_timers(0xFF)
+        run(args.warmup + args.steps, min(args.steps, 50))
+        pipe.sync()
+        sm, sc = pipe.read_stage_ms()
+        names = ["upload", "preprocess", "track", "integrate", "raycast", "integrate_kernel", "mcubes", "raycast_kernel"]
+        print("stage ms/frame: " + ", ".join("%s=%.4f" % (n, sm[i] / max(int(sc[i]), 1)) for i, n in enumerate(names)), file=sys.stderr)
+
+    out = dict(metric="depth frames/sec into TSDF (integrate+ICP+raycast)", value=round(fps, 2), unit="frames/s", n_gpus=world,
+               steps=args.steps, warmup=args.warmup, ms_per_step=round(1000.0 * dt / args.steps, 4), higher_is_better=True,
+               scaling="weak" if world == 1 else "strong", vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload=wl["desc"], volume="%d^3 @ %g m" % (res, size), image="%dx%d" % (cam[0], cam[1]),
+                           tracker="ICP 10/5/4 (device-resident Gauss-Newton)", frames_lost=int(lost),
+                           partition="none" if world == 1 else "z-slab x%d" % world),
+               roofline=roofline)
+    if world == 1 and not args.no_cpu_baseline:
+        pipe.close()
+        out["cpu_baseline"] = cpu_baseline(wl, frames)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,383 @@
+// ctx.hip -- context lifetime, uploads/downloads, volume import/export.
+// Replaces CudaDeviceDataMan (src/cuda/CudaDeviceDataMan.h:24-67), CudaMap1D/2D (src/cuda/DataMap.h) and the
+// blocking clone(CPU)/copyDataFrom calls the reference's host classes make on the singleton.
+#include "kf_internal.h"
+#include <string.h>
+#include <stdlib.h>
+#include <new>
+
+extern "C" const char* kf_version(void) { return "hybkf-gfx950 0.1"; }
+
+extern "C" const char* kf_error_string(int s) {
+  switch (s) {
+    case 0: return "ok";
+    case KF_ERR_ARG: return "invalid argument";
+    case KF_ERR_STATE: return "invalid state";
+    case KF_ERR_ALLOC: return "allocation failed";
+    default: return hipGetErrorString((hipError_t)s);
+  }
+}
+
+template <typename T>
+static int dev_alloc(T** p, size_t n) {
+  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  if (e != hipSuccess) { *p = nullptr; return (int)e; }
+  return 0;
+}
+
+extern "C" int kf_destroy(kf_ctx* c) {
+  if (!c) return KF_ERR_ARG;
+  hipSetDevice(c->cfg.device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  void* ptrs[] = {c->depth_mm, c->raw_depth, c->trunced_depth, c->filtered_depth, c->raw_rgb, c->raycast_rgb, c->icp_partials,
+                  c->track, c->counters, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->active_bricks,
+                  c->tile_max_depth, c->triangles, c->mc_block_counts};
+  for (void* p : ptrs) if (p) hipFree(p);
+  for (int l = 0; l < KF_MAX_LEVELS; ++l) {
+    if (c->new_v[l]) hipFree(c->new_v[l]);
+    if (c->new_n[l]) hipFree(c->new_n[l]);
+    if (c->model_v[l]) hipFree(c->model_v[l]);
+    if (c->model_n[l]) hipFree(c->model_n[l]);
+  }
+  for (int s = 0; s < 8; ++s) for (int k = 0; k < 2; ++k) for (int i = 0; i < 64; ++i) if (c->ev[s][k][i]) hipEventDestroy(c->ev[s][k][i]);
+  if (c->host_pinned) hipHostFree(c->host_pinned);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
+  if (!cfg || !out) return KF_ERR_ARG;
+  *out = nullptr;
+  const uint32_t R = cfg->volume.resolution;
+  if (R == 0 || (R % KF_BRICK) != 0) return KF_ERR_ARG;
+  if (cfg->pyramid_levels < 1 || cfg->pyramid_levels > KF_MAX_LEVELS) return KF_ERR_ARG;
+  if (cfg->depth_camera.cols == 0 || cfg->depth_camera.rows == 0) return KF_ERR_ARG;
+  uint32_t z0 = cfg->slab_z_begin, z1 = cfg->slab_z_end ? cfg->slab_z_end : R;
+  if (z0 >= z1 || z1 > R || (z0 % KF_BRICK) || (z1 % KF_BRICK)) return KF_ERR_ARG;
+  KF_CHECK(hipSetDevice(cfg->device));
+  kf_ctx* c = new (std::nothrow) kf_ctx();
+  if (!c) return KF_ERR_ALLOC;
+  memset((void*)c, 0, sizeof(*c));
+  c->cfg = *cfg;
+  c->cfg.slab_z_end = z1;
+  c->cols = cfg->depth_camera.cols; c->rows = cfg->depth_camera.rows; c->levels = cfg->pyramid_levels;
+  int st = 0;
+#define TRY(x) do { st = (x); if (st) { kf_destroy(c); return st; } } while (0)
+  TRY((int)hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  const size_t npx = (size_t)c->cols * c->rows;
+  TRY(dev_alloc(&c->depth_mm, npx));
+  TRY(dev_alloc(&c->raw_depth, npx)); TRY(dev_alloc(&c->trunced_depth, npx)); TRY(dev_alloc(&c->filtered_depth, npx));
+  const size_t nrgb = (size_t)cfg->rgb_camera.cols * cfg->rgb_camera.rows;
+  if (cfg->has_color) { TRY(dev_alloc(&c->raw_rgb, nrgb ? nrgb : npx)); TRY(dev_alloc(&c->raycast_rgb, npx)); }
+  int lc = c->cols, lr = c->rows;
+  for (int l = 0; l < c->levels; ++l) {               // CudaDeviceDataMan.h:36-47
+    c->lvl_cols[l] = lc; c->lvl_rows[l] = lr;
+    size_t n = (size_t)lc * lr;
+    TRY(dev_alloc(&c->new_v[l], n)); TRY(dev_alloc(&c->new_n[l], n));
+    TRY(dev_alloc(&c->model_v[l], n)); TRY(dev_alloc(&c->model_n[l], n));
+    TRY((int)hipMemsetAsync(c->model_v[l], 0, n * sizeof(float4), c->stream));
+    TRY((int)hipMemsetAsync(c->model_n[l], 0, n * sizeof(float4), c->stream));
+    TRY((int)hipMemsetAsync(c->new_v[l], 0, n * sizeof(float4), c->stream));
+    TRY((int)hipMemsetAsync(c->new_n[l], 0, n * sizeof(float4), c->stream));
+    lc >>= 1; lr >>= 1;
+  }
+  TRY(dev_alloc(&c->icp_partials, (size_t)KF_ICP_MAX_WG * 32));
+  TRY(dev_alloc(&c->track, 1)); TRY(dev_alloc(&c->counters, 1)); TRY(dev_alloc(&c->scratch_mats, 8 * 16));
+  TRY((int)hipMemsetAsync(c->track, 0, sizeof(KfTrackState), c->stream));
+  TRY((int)hipMemsetAsync(c->counters, 0, sizeof(KfCounters), c->stream));
+  // volume: tsdfvolume::init (tsdfVolume.h:29-37), bricked, slab + halo
+  KfVolume& v = c->vol;
+  v.res = (int)R; v.nb = (int)(R / KF_BRICK);
+  uint32_t halo_b = (cfg->slab_halo + KF_BRICK - 1) / KF_BRICK;
+  int b0 = (int)(z0 / KF_BRICK) - (int)halo_b, b1 = (int)(z1 / KF_BRICK) + (int)halo_b;
+  v.bz0 = b0 < 0 ? 0 : b0; v.bz1 = b1 > v.nb ? v.nb : b1;
+  v.own_z0 = (int)z0; v.own_z1 = (int)z1;
+  v.size = cfg->volume.size_m; v.max_weight = cfg->volume.max_weight;
+  v.cell = v.size / (float)v.res;
+  c->n_stored_bricks = (size_t)(v.bz1 - v.bz0) * v.nb * v.nb;
+  c->n_stored_vox = c->n_stored_bricks * KF_BRICK_VOX;
+  TRY(dev_alloc(&v.tw, c->n_stored_vox));
+  if (cfg->has_color) TRY(dev_alloc(&v.color, c->n_stored_vox));
+  TRY(dev_alloc(&v.flags, c->n_stored_bricks));
+  TRY(dev_alloc(&c->active_bricks, c->n_stored_bricks));
+  TRY(dev_alloc(&c->tile_max_depth, (size_t)kf_div_up(c->cols, 16) * kf_div_up(c->rows, 16)));
+  c->max_triangles = cfg->max_triangles;
+  if (c->max_triangles) TRY(dev_alloc(&c->triangles, (size_t)c->max_triangles));
+  c->mc_blocks_cap = (c->n_stored_vox + 255) / 256;
+  TRY(dev_alloc(&c->mc_block_counts, c->mc_blocks_cap + 1));
+  TRY((int)hipHostMalloc(&c->host_pinned, 4096, hipHostMallocDefault));
+  TRY(kf_reset_volume(c));
+  TRY((int)hipStreamSynchronize(c->stream));
+#undef TRY
+  *out = c;
+  return 0;
+}
+
+extern "C" int kf_reset_volume(kf_ctx* c) {
+  if (!c) return KF_ERR_ARG;
+  KF_CHECK(hipSetDevice(c->cfg.device));
+  KF_CHECK(hipMemsetAsync(c->vol.tw, 0, c->n_stored_vox * sizeof(float2), c->stream));
+  if (c->vol.color) KF_CHECK(hipMemsetAsync(c->vol.color, 0, c->n_stored_vox * sizeof(uchar4), c->stream));
+  KF_CHECK(hipMemsetAsync(c->vol.flags, 0, c->n_stored_bricks, c->stream));
+  KF_CHECK(hipMemsetAsync(c->counters, 0, sizeof(KfCounters), c->stream));
+  return 0;
+}
+
+extern "C" int kf_synchronize(kf_ctx* c) {
+  if (!c) return KF_ERR_ARG;
+  KF_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" void* kf_stream(kf_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+extern "C" int kf_stored_z_range(kf_ctx* c, uint32_t* z_begin, uint32_t* z_end) {
+  if (!c || !z_begin || !z_end) return KF_ERR_ARG;
+  *z_begin = c->vol.bz0 * KF_BRICK; *z_end = c->vol.bz1 * KF_BRICK;
+  return 0;
+}
+
+// ---- frame upload: HybKinectfu::copyFrameToGPU (src/HybKinectfu.cpp:63-96) ----------------------------------------
+// `float v = mat.at<unsigned short>(row,col)*0.001;` is an int * double product narrowed to float.
+__global__ void __launch_bounds__(256) k_depth_mm_to_m(const uint16_t* __restrict__ mm, float* __restrict__ out, int n) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (float)((double)mm[i] * 0.001);
+}
+
+extern "C" int kf_set_depth_mm_device(kf_ctx* c, const uint16_t* dev_mm, uint32_t cols, uint32_t rows) {
+  if (!c || !dev_mm || (int)cols != c->cols || (int)rows != c->rows) return KF_ERR_ARG;
+  int n = c->cols * c->rows;
+  hipLaunchKernelGGL(k_depth_mm_to_m, dim3(kf_div_up(n, 256)), dim3(256), 0, c->stream, dev_mm, c->raw_depth, n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int kf_upload_depth_mm(kf_ctx* c, const uint16_t* host_mm, uint32_t cols, uint32_t rows) {
+  if (!c || !host_mm || (int)cols != c->cols || (int)rows != c->rows) return KF_ERR_ARG;
+  KF_CHECK(hipMemcpyAsync(c->depth_mm, host_mm, (size_t)cols * rows * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+  return kf_set_depth_mm_device(c, c->depth_mm, cols, rows);
+}
+
+__global__ void __launch_bounds__(256) k_rgb3_to_rgb4(const unsigned char* __restrict__ in, uchar4* __restrict__ out, int n) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = make_uchar4(in[3 * i], in[3 * i + 1], in[3 * i + 2], 0);
+}
+__global__ void __launch_bounds__(256) k_rgb4_to_rgb3(const uchar4* __restrict__ in, unsigned char* __restrict__ out, int n) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { uchar4 p = in[i]; out[3 * i] = p.x; out[3 * i + 1] = p.y; out[3 * i + 2] = p.z; }
+}
+
+extern "C" int kf_upload_rgb(kf_ctx* c, const uint8_t* host_bgr, uint32_t cols, uint32_t rows) {
+  if (!c || !host_bgr || !c->raw_rgb || cols != c->cfg.rgb_camera.cols || rows != c->cfg.rgb_camera.rows) return KF_ERR_ARG;
+  size_t n = (size_t)cols * rows;
+  unsigned char* tmp = nullptr;
+  KF_CHECK(hipMalloc((void**)&tmp, n * 3));
+  hipError_t e = hipMemcpyAsync(tmp, host_bgr, n * 3, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_rgb3_to_rgb4, dim3(kf_div_up((int)n, 256)), dim3(256), 0, c->stream, tmp, c->raw_rgb, (int)n);
+    e = hipStreamSynchronize(c->stream);
+  }
+  hipFree(tmp);
+  return (int)e;
+}
+
+// ---- map download / upload (CudaMap2D::clone(CPU), DataMap.h) -----------------------------------------------------
+static int map_ptr(kf_ctx* c, int id, uint32_t level, void** p, size_t* bytes, bool* is_rgb) {
+  *is_rgb = false;
+  size_t npx = (size_t)c->cols * c->rows;
+  switch (id) {
+    case KF_MAP_RAW_DEPTH: *p = c->raw_depth; *bytes = npx * 4; return 0;
+    case KF_MAP_TRUNCED_DEPTH: *p = c->trunced_depth; *bytes = npx * 4; return 0;
+    case KF_MAP_FILTERED_DEPTH: *p = c->filtered_depth; *bytes = npx * 4; return 0;
+    case KF_MAP_RAW_RGB: *p = c->raw_rgb; *bytes = (size_t)c->cfg.rgb_camera.cols * c->cfg.rgb_camera.rows * 3; *is_rgb = true; return c->raw_rgb ? 0 : KF_ERR_STATE;
+    case KF_MAP_RAYCAST_RGB: *p = c->raycast_rgb; *bytes = npx * 3; *is_rgb = true; return c->raycast_rgb ? 0 : KF_ERR_STATE;
+    default: break;
+  }
+  if (level >= (uint32_t)c->levels) return KF_ERR_ARG;
+  size_t n = (size_t)c->lvl_cols[level] * c->lvl_rows[level] * sizeof(float4);
+  switch (id) {
+    case KF_MAP_NEW_VERTICES: *p = c->new_v[level]; break;
+    case KF_MAP_NEW_NORMALS: *p = c->new_n[level]; break;
+    case KF_MAP_MODEL_VERTICES: *p = c->model_v[level]; break;
+    case KF_MAP_MODEL_NORMALS: *p = c->model_n[level]; break;
+    default: return KF_ERR_ARG;
+  }
+  *bytes = n;
+  return 0;
+}
+
+extern "C" int kf_download_map(kf_ctx* c, int id, uint32_t level, void* dst, size_t dst_bytes) {
+  if (!c || !dst) return KF_ERR_ARG;
+  void* p; size_t bytes; bool rgb;
+  int st = map_ptr(c, id, level, &p, &bytes, &rgb);
+  if (st) return st;
+  if (dst_bytes < bytes) return KF_ERR_ARG;
+  if (rgb) {
+    int n = (int)(bytes / 3);
+    unsigned char* tmp = nullptr;
+    KF_CHECK(hipMalloc((void**)&tmp, bytes));
+    hipLaunchKernelGGL(k_rgb4_to_rgb3, dim3(kf_div_up(n, 256)), dim3(256), 0, c->stream, (const uchar4*)p, tmp, n);
+    hipError_t e = hipMemcpyAsync(dst, tmp, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(tmp);
+    return (int)e;
+  }
+  KF_CHECK(hipMemcpyAsync(dst, p, bytes, hipMemcpyDeviceToHost, c->stream));
+  KF_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int kf_upload_map(kf_ctx* c, int id, uint32_t level, const void* src, size_t src_bytes) {
+  if (!c || !src) return KF_ERR_ARG;
+  void* p; size_t bytes; bool rgb;
+  int st = map_ptr(c, id, level, &p, &bytes, &rgb);
+  if (st) return st;
+  if (src_bytes != bytes) return KF_ERR_ARG;
+  if (rgb) {
+    if (id != KF_MAP_RAW_RGB) return KF_ERR_ARG;
+    return kf_upload_rgb(c, (const uint8_t*)src, c->cfg.rgb_camera.cols, c->cfg.rgb_camera.rows);
+  }
+  KF_CHECK(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, c->stream));
+  KF_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---- volume import / export in the reference's linear order (tsdfVolume.h:57-60) -----------------------------------
+__global__ void __launch_bounds__(256) k_volume_export(KfVolume v, int z_begin, int z_end, float* __restrict__ tsdf,
+                                                       float* __restrict__ weight, unsigned char* __restrict__ color) {
+  size_t n = (size_t)(z_end - z_begin) * v.res * v.res;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    int x = (int)(i % v.res), y = (int)((i / v.res) % v.res), z = z_begin + (int)(i / ((size_t)v.res * v.res));
+    size_t idx = kf_vox_index(v, x, y, z);
+    float2 q = v.tw[idx];
+    tsdf[i] = q.x; weight[i] = q.y;
+    if (color && v.color) { uchar4 cc = v.color[idx]; color[3 * i] = cc.x; color[3 * i + 1] = cc.y; color[3 * i + 2] = cc.z; }
+  }
+}
+__global__ void __launch_bounds__(256) k_volume_import(KfVolume v, int z_begin, int z_end, const float* __restrict__ tsdf,
+                                                       const float* __restrict__ weight, const unsigned char* __restrict__ color) {
+  size_t n = (size_t)(z_end - z_begin) * v.res * v.res;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    int x = (int)(i % v.res), y = (int)((i / v.res) % v.res), z = z_begin + (int)(i / ((size_t)v.res * v.res));
+    size_t idx = kf_vox_index(v, x, y, z);
+    v.tw[idx] = make_float2(tsdf[i], weight[i]);
+    if (color && v.color) v.color[idx] = make_uchar4(color[3 * i], color[3 * i + 1], color[3 * i + 2], 0);
+  }
+}
+// rebuild the per-brick flags from the voxel data (after an import)
+__global__ void __launch_bounds__(256) k_rebuild_flags(KfVolume v, size_t n_bricks) {
+  __shared__ unsigned s_flag;
+  for (size_t b = blockIdx.x; b < n_bricks; b += gridDim.x) {
+    if (threadIdx.x == 0) s_flag = 0;
+    __syncthreads();
+    unsigned f = 0;
+    for (int k = threadIdx.x; k < KF_BRICK_VOX; k += 256) {
+      float2 q = v.tw[b * KF_BRICK_VOX + k];
+      if (q.y > 0.f) f |= KF_FLAG_OBSERVED;
+      if (q.x < 0.f) f |= KF_FLAG_HASNEG;
+    }
+    if (f) atomicOr(&s_flag, f);
+    __syncthreads();
+    if (threadIdx.x == 0) v.flags[b] = (uint8_t)s_flag;
+    __syncthreads();
+  }
+}
+
+static int volume_xfer(kf_ctx* c, uint32_t z0, uint32_t z1, float* tsdf, float* weight, uint8_t* color, bool to_host) {
+  if (!c || !tsdf || !weight) return KF_ERR_ARG;
+  if (z0 >= z1 || (int)z0 < c->vol.bz0 * KF_BRICK || (int)z1 > c->vol.bz1 * KF_BRICK) return KF_ERR_ARG;
+  size_t n = (size_t)(z1 - z0) * c->vol.res * c->vol.res;
+  float *dt = nullptr, *dw = nullptr; unsigned char* dc = nullptr;
+  hipError_t e = hipMalloc((void**)&dt, n * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&dw, n * 4);
+  if (e == hipSuccess && color && c->vol.color) e = hipMalloc((void**)&dc, n * 3);
+  int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  if (e == hipSuccess) {
+    if (to_host) {
+      hipLaunchKernelGGL(k_volume_export, dim3(grid), dim3(256), 0, c->stream, c->vol, (int)z0, (int)z1, dt, dw, dc);
+      e = hipMemcpyAsync(tsdf, dt, n * 4, hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(weight, dw, n * 4, hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess && dc) e = hipMemcpyAsync(color, dc, n * 3, hipMemcpyDeviceToHost, c->stream);
+    } else {
+      e = hipMemcpyAsync(dt, tsdf, n * 4, hipMemcpyHostToDevice, c->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(dw, weight, n * 4, hipMemcpyHostToDevice, c->stream);
+      if (e == hipSuccess && dc) e = hipMemcpyAsync(dc, color, n * 3, hipMemcpyHostToDevice, c->stream);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_volume_import, dim3(grid), dim3(256), 0, c->stream, c->vol, (int)z0, (int)z1, dt, dw, dc);
+        int fg = (int)(c->n_stored_bricks > 4096 ? 4096 : c->n_stored_bricks);
+        hipLaunchKernelGGL(k_rebuild_flags, dim3(fg), dim3(256), 0, c->stream, c->vol, c->n_stored_bricks);
+      }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  }
+  if (dt) hipFree(dt);
+  if (dw) hipFree(dw);
+  if (dc) hipFree(dc);
+  return (int)e;
+}
+
+extern "C" int kf_download_volume(kf_ctx* c, uint32_t z0, uint32_t z1, float* tsdf, float* weight, uint8_t* color) {
+  return volume_xfer(c, z0, z1, tsdf, weight, color, true);
+}
+extern "C" int kf_upload_volume(kf_ctx* c, uint32_t z0, uint32_t z1, const float* tsdf, const float* weight, const uint8_t* color) {
+  return volume_xfer(c, z0, z1, (float*)tsdf, (float*)weight, (uint8_t*)color, false);
+}
+
+// ---- statistics ----------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_count_weight(KfVolume v, KfCounters* cnt) {
+  // owned layers only; bricks are 8 layers thick and the owned range is brick aligned
+  size_t b0 = (size_t)(v.own_z0 / KF_BRICK - v.bz0) * v.nb * v.nb, b1 = (size_t)(v.own_z1 / KF_BRICK - v.bz0) * v.nb * v.nb;
+  size_t n0 = b0 * KF_BRICK_VOX, n1 = b1 * KF_BRICK_VOX;
+  unsigned local = 0;
+  for (size_t i = n0 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n1; i += (size_t)gridDim.x * 256) local += v.tw[i].y > 0.f ? 1u : 0u;
+  float s = kf_wave_sum((float)local);      // local <= n/(grid*256) stays far below 2^24: exact in fp32
+  if ((threadIdx.x & 63) == 0 && s > 0.f) atomicAdd(&cnt->weight_gt0, (unsigned long long)s);
+}
+
+extern "C" int kf_get_volume_stats(kf_ctx* c, kf_volume_stats* out) {
+  if (!c || !out) return KF_ERR_ARG;
+  KF_CHECK(hipMemsetAsync(&c->counters->weight_gt0, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_count_weight, dim3(2048), dim3(256), 0, c->stream, c->vol, c->counters);
+  KfCounters h;
+  KF_CHECK(hipMemcpyAsync(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  KF_CHECK(hipStreamSynchronize(c->stream));
+  out->updated_last = h.n_upd; out->weight_gt0 = h.weight_gt0;
+  out->bricks_active = h.n_active_bricks; out->bricks_total = c->n_stored_bricks;
+  out->updated_total = h.n_upd_total; out->frames_fused = h.frames_fused; out->frames_lost = h.frames_lost;
+  return 0;
+}
+
+// ---- per-stage device timers ----------------------------------------------------------------------------------------
+static void evt_fold(kf_ctx* c, int s) {
+  if (c->ev_n[s] == 0) return;
+  (void)hipEventSynchronize(c->ev[s][1][c->ev_n[s] - 1]);
+  for (int i = 0; i < c->ev_n[s]; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[s][0][i], c->ev[s][1][i]) == hipSuccess) { c->ev_ms[s] += ms; c->ev_count[s] += 1; }
+  }
+  c->ev_n[s] = 0;
+}
+void kf_evt_begin(kf_ctx* c, int s) {
+  if (!(c->timers_enabled & (1 << s))) return;
+  if (c->ev_n[s] == 64) evt_fold(c, s);
+  if (!c->ev[s][0][c->ev_n[s]]) { (void)hipEventCreate(&c->ev[s][0][c->ev_n[s]]); (void)hipEventCreate(&c->ev[s][1][c->ev_n[s]]); }
+  (void)hipEventRecord(c->ev[s][0][c->ev_n[s]], c->stream);
+}
+void kf_evt_end(kf_ctx* c, int s) {
+  if (!(c->timers_enabled & (1 << s))) return;
+  (void)hipEventRecord(c->ev[s][1][c->ev_n[s]], c->stream);
+  c->ev_n[s] += 1;
+}
+
+// enable: bit mask of KF_STAGE_* to time (0 = off).  Resets the accumulators.
+extern "C" int kf_stage_timers(kf_ctx* c, int enable) {
+  if (!c) return KF_ERR_ARG;
+  for (int s = 0; s < 8; ++s) { evt_fold(c, s); c->ev_ms[s] = 0.0; c->ev_count[s] = 0; }
+  c->timers_enabled = enable;
+  return 0;
+}
+// out_ms[s] = accumulated milliseconds of stage s; counts[s] (may be null) = number of timed intervals.  Blocking.
+extern "C" int kf_read_stage_ms(kf_ctx* c, float out_ms[8], uint32_t* counts) {
+  if (!c || !out_ms) return KF_ERR_ARG;
+  for (int s = 0; s < 8; ++s) { evt_fold(c, s); out_ms[s] = (float)c->ev_ms[s]; if (counts) counts[s] = c->ev_count[s]; }
+  return 0;
+}

@@ -1,0 +1,213 @@
+// integrate.hip -- projective TSDF fusion (reference: integrateKernel src/cuda/integrateVolume.cu:15-77,
+// tsdfvolume::updateVoxel src/cuda/tsdfVolume.h:57-75, wrapper :78-96).
+//
+// gfx950 design (HBM-bound kernel, see DESIGN.md "integrate"):
+//   * the volume is bricked: an 8x8x8 brick is 4 KiB of contiguous (tsdf, weight) pairs, so one 256-thread workgroup
+//     owns one brick and each lane moves one 16-byte pair-of-voxels -> every wave instruction is a full 1 KiB burst;
+//   * only voxels that pass the reference's update predicate may touch memory.  A cull pass classifies bricks against
+//     the camera frustum, the [0, max_dist + trunc) depth range and a 16x16-pixel tile max of the gated depth image, and
+//     queues the survivors; the fusion pass walks that queue.  The tests are conservative (a brick is dropped only
+//     when no voxel of it can pass the predicate), so the result is identical to visiting every voxel;
+//   * the per-voxel arithmetic is the reference's, one rounded fp32 op per source op (-ffp-contract=off), hence the
+//     updated-voxel count and the tsdf/weight bits match the CPU oracle exactly;
+//   * per-brick flags (observed / has-negative) are maintained here; raycast and marching cubes use them to skip space.
+#include "kf_internal.h"
+
+struct IntegrateArgs {
+  KfVolume vol;
+  KfCam dcam, rcam;
+  const float* depth;            // trunced_depth
+  const float4* normals;         // new_normals_pyramid[0]
+  const uchar4* rgb;             // raw_rgb
+  const float* pose;             // device: camera -> world (null: use pose_val)
+  KfMat pose_val;                // host-supplied transform, passed by value
+  float* tinv;                   // device scratch: world -> camera (Mat44::getInverse)
+  float* tile_max;               // device: per 16x16 tile max of depth gated by max_dist
+  unsigned* queue;               // active brick slots
+  KfCounters* cnt;
+  const KfTrackState* track;     // non-null: integrate only when track->tracked
+  float sdf_trunc, max_dist;
+  int has_color, color_angled;
+  int tiles_x, tiles_y;
+};
+
+
+// pass 0: one workgroup per 16x16 pixel tile -> max of the depth values that can integrate (0 < d < max_dist);
+// workgroup 0 also inverts the pose and clears the counters.
+__global__ void __launch_bounds__(256) k_integrate_prepare(IntegrateArgs a) {
+  __shared__ float s_max[4];
+  const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+  const int x = tx * 16 + (threadIdx.x & 15), y = ty * 16 + (threadIdx.x >> 4);
+  float d = 0.f;
+  if (x < a.dcam.cols && y < a.dcam.rows) { float v = a.depth[y * a.dcam.cols + x]; d = (v < a.max_dist) ? v : 0.f; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) d = fmaxf(d, __shfl_down(d, off, 64));
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.tile_max[blockIdx.x] = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    if (blockIdx.x == 0) {
+      kf_mat44_inverse(a.pose ? a.pose : a.pose_val.m, a.tinv);   // integrateVolume.cu:84
+      a.cnt->n_upd = 0ull; a.cnt->n_active_bricks = 0u;
+    }
+  }
+}
+
+// pass 1: one lane per stored brick; conservative rejection, survivors appended to the queue.
+__global__ void __launch_bounds__(256) k_integrate_cull(IntegrateArgs a) {
+  if (a.track && !a.track->tracked) {                        // HybKinectfu.cpp:123: integrate only when tracking succeeded
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.cnt->frames_lost += 1;
+    return;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.cnt->frames_fused += 1;
+  const KfVolume& v = a.vol;
+  const size_t nbricks = (size_t)(v.bz1 - v.bz0) * v.nb * v.nb;
+  const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (slot >= nbricks) return;
+  const int bx = (int)(slot % v.nb), by = (int)((slot / v.nb) % v.nb), bz = (int)(slot / ((size_t)v.nb * v.nb)) + v.bz0;
+  const float* m = a.tinv;
+  const float cell = v.cell;
+  // voxel centres of the brick span [(8b+0.5), (8b+7.5)] * cell per axis -> centre (8b+4)*cell, half-diagonal 3.5*sqrt(3)*cell
+  const float cx = (float)(bx * 8 + 4) * cell, cy = (float)(by * 8 + 4) * cell, cz = (float)(bz * 8 + 4) * cell;
+  const float r = 6.1f * cell + 1e-4f * v.size;
+  const float px = m[0] * cx + m[1] * cy + m[2] * cz + m[3];
+  const float py = m[4] * cx + m[5] * cy + m[6] * cz + m[7];
+  const float pz = m[8] * cx + m[9] * cy + m[10] * cz + m[11];
+  if (pz + r <= 0.f) return;                                           // every voxel has pf.z <= 0
+  if (pz - r >= a.max_dist + a.sdf_trunc) return;                      // needs pf.z < depth + trunc < max_dist + trunc
+  // frustum side planes through the eye, widened by one pixel
+  const float tl = (-1.f - a.dcam.cx) / a.dcam.fx, tr = ((float)a.dcam.cols - a.dcam.cx) / a.dcam.fx;
+  const float tt = (-1.f - a.dcam.cy) / a.dcam.fy, tb = ((float)a.dcam.rows - a.dcam.cy) / a.dcam.fy;
+  if ((px - tl * pz) < -r * sqrtf(1.f + tl * tl)) return;
+  if ((tr * pz - px) < -r * sqrtf(1.f + tr * tr)) return;
+  if ((py - tt * pz) < -r * sqrtf(1.f + tt * tt)) return;
+  if ((tb * pz - py) < -r * sqrtf(1.f + tb * tb)) return;
+  // depth test against the tile max over the brick's pixel footprint (only when the brick is clear of the eye plane)
+  const float zn = pz - r, zf = pz + r;
+  if (zn > 4.f * cell) {
+    const float xl = px - r, xr = px + r, yl = py - r, yr = py + r;
+    float u0 = (xl < 0.f ? xl / zn : xl / zf) * a.dcam.fx + a.dcam.cx, u1 = (xr > 0.f ? xr / zn : xr / zf) * a.dcam.fx + a.dcam.cx;
+    float w0 = (yl < 0.f ? yl / zn : yl / zf) * a.dcam.fy + a.dcam.cy, w1 = (yr > 0.f ? yr / zn : yr / zf) * a.dcam.fy + a.dcam.cy;
+    int ix0 = (int)floorf(u0) - 1, ix1 = (int)ceilf(u1) + 2, iy0 = (int)floorf(w0) - 1, iy1 = (int)ceilf(w1) + 2;
+    ix0 = max(ix0, 0); iy0 = max(iy0, 0); ix1 = min(ix1, a.dcam.cols - 1); iy1 = min(iy1, a.dcam.rows - 1);
+    if (ix0 > ix1 || iy0 > iy1) return;
+    float dmax = 0.f;
+    for (int ty = iy0 >> 4; ty <= (iy1 >> 4); ++ty)
+      for (int tx = ix0 >> 4; tx <= (ix1 >> 4); ++tx) dmax = fmaxf(dmax, a.tile_max[ty * a.tiles_x + tx]);
+    if (dmax == 0.f) return;                                           // no pixel under the brick can integrate
+    if (zn >= dmax + a.sdf_trunc) return;                              // every voxel lies behind every surface it can see
+  }
+  unsigned pos = atomicAdd(&a.cnt->n_active_bricks, 1u);               // wave-aggregated by the compiler
+  a.queue[pos] = (unsigned)slot;
+}
+
+// pass 2: one workgroup per queued brick, one lane per x-adjacent voxel pair (16 contiguous bytes).
+template <bool HAS_COLOR>
+__global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
+  const KfVolume& v = a.vol;
+  const unsigned n_active = a.cnt->n_active_bricks;
+  const float* m = a.tinv;
+  const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8], m9 = m[9], m10 = m[10], m11 = m[11];
+  const float cell = v.cell;
+  const int lx = (threadIdx.x & 3) * 2, ly = (threadIdx.x >> 2) & 7, lz = threadIdx.x >> 5;
+  __shared__ unsigned s_flags;
+  unsigned long long upd_total = 0;
+  for (unsigned qi = blockIdx.x; qi < n_active; qi += gridDim.x) {
+    const unsigned slot = a.queue[qi];
+    const int bx = (int)(slot % v.nb), by = (int)((slot / v.nb) % v.nb), bz = (int)(slot / ((unsigned)v.nb * v.nb)) + v.bz0;
+    const int y = by * 8 + ly, z = bz * 8 + lz;
+    // tsdfVolume.h:38-49 voxel centre; Mat.h:230-238 row*vector summed left to right; the (x,y) part is shared by the pair
+    const float wy = ((float)y + 0.5f) * cell, wz = ((float)z + 0.5f) * cell;
+    float4* p = reinterpret_cast<float4*>(v.tw + (size_t)slot * KF_BRICK_VOX) + threadIdx.x;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool loaded = false;
+    unsigned flags = 0, n_upd = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int x = bx * 8 + lx + k;
+      const float wx = ((float)x + 0.5f) * cell;
+      const float pfx = m0 * wx + m1 * wy + m2 * wz + m3 * 1.0f;
+      const float pfy = m4 * wx + m5 * wy + m6 * wz + m7 * 1.0f;
+      const float pfz = m8 * wx + m9 * wy + m10 * wz + m11 * 1.0f;
+      if (pfz <= 0.f) continue;                                                             // :39
+      int2 sp = kf_project(kf3(pfx, pfy, pfz), a.dcam);
+      if (sp.x >= a.dcam.cols - 1 || sp.y >= a.dcam.rows - 1 || sp.x < 1 || sp.y < 1) continue;   // :43
+      const float d = a.depth[sp.y * a.dcam.cols + sp.x];
+      if (d == 0.f) continue;                                                               // :50
+      uchar4 col = make_uchar4(0, 0, 0, 0);
+      float normalz = 0.f;
+      if (HAS_COLOR) {
+        normalz = a.normals[sp.y * a.dcam.cols + sp.x].z;
+        int cxp = kf_to_int((double)(pfx * 525 / pfz + 320)), cyp = kf_to_int((double)(pfy * 525 / pfz + 240));   // :56-57
+        if (cxp >= a.rcam.cols - 1 || cyp >= a.rcam.rows - 1 || cxp < 1 || cyp < 1) continue;
+        col = a.rgb[(size_t)cyp * a.rcam.cols + cxp];
+      }
+      if (!(d < a.max_dist)) continue;                                                      // :64
+      const float sdf = d - pfz;
+      if (!(sdf > -a.sdf_trunc)) continue;                                                  // :67
+      const float tsdf = fminf(1.0f, sdf / a.sdf_trunc);
+      if (!loaded) { q = *p; loaded = true; }
+      float ot = k ? q.z : q.x, ow = k ? q.w : q.y;
+      const float nw = fminf(ow + 1.f, v.max_weight);                                       // tsdfVolume.h:65
+      const float nt = (ot * ow + tsdf * 1.f) / (ow + 1.f);                                 // tsdfVolume.h:66
+      if (k) { q.z = nt; q.w = nw; } else { q.x = nt; q.y = nw; }
+      if (HAS_COLOR) {
+        // :72 `(color_angled?fminf(1.0,abs(normalz)/0.75):1.0)*2.0` -- the division and the doubling run in double
+        const float wc = a.color_angled ? (float)((double)fminf(1.0f, (float)((double)fabsf(normalz) / 0.75)) * 2.0) : 2.0f;
+        uchar4* cp = v.color + (size_t)slot * KF_BRICK_VOX + threadIdx.x * 2 + k;
+        uchar4 oc = *cp;
+        float c0 = fminf(255.0f, ((float)oc.x * ow + (float)col.x * wc) / (ow + wc));       // tsdfVolume.h:68-70
+        float c1 = fminf(255.0f, ((float)oc.y * ow + (float)col.y * wc) / (ow + wc));
+        float c2 = fminf(255.0f, ((float)oc.z * ow + (float)col.z * wc) / (ow + wc));
+        *cp = make_uchar4((unsigned char)c0, (unsigned char)c1, (unsigned char)c2, 0);
+      }
+      ++n_upd;
+      flags |= KF_FLAG_OBSERVED | (nt < 0.f ? KF_FLAG_HASNEG : 0u);
+    }
+    if (loaded) *p = q;
+    // brick flags + update count: one LDS word per brick, one global byte per brick
+    if (threadIdx.x == 0) s_flags = 0;
+    __syncthreads();
+    if (flags) atomicOr(&s_flags, flags);
+    upd_total += n_upd;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_flags) v.flags[slot] = (uint8_t)(v.flags[slot] | s_flags);
+  }
+  // N_upd: wave sum then one atomic per wave
+  float s = kf_wave_sum((float)upd_total);          // < 2^24 per wave: exact
+  if ((threadIdx.x & 63) == 0 && s > 0.f) { atomicAdd(&a.cnt->n_upd, (unsigned long long)s); atomicAdd(&a.cnt->n_upd_total, (unsigned long long)s); }
+}
+
+static inline KfCam to_cam(const kf_camera_params* p) {
+  KfCam c; c.cols = (int)p->cols; c.rows = (int)p->rows; c.cx = p->cx; c.cy = p->cy; c.fx = p->fx; c.fy = p->fy; return c;
+}
+
+extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weight_color, const kf_mat44* transform,
+                                   const kf_integrate_params* ip, const kf_camera_params* dcam, const kf_camera_params* rcam) {
+  if (!c || !ip || !dcam) return KF_ERR_ARG;
+  if ((int)dcam->cols != c->cols || (int)dcam->rows != c->rows) return KF_ERR_ARG;
+  if (has_color && (!c->vol.color || !c->raw_rgb || !rcam)) return KF_ERR_STATE;
+  IntegrateArgs a;
+  a.vol = c->vol; a.dcam = to_cam(dcam); a.rcam = rcam ? to_cam(rcam) : a.dcam;
+  a.depth = c->trunced_depth; a.normals = c->new_n[0]; a.rgb = c->raw_rgb;
+  a.tinv = c->scratch_mats + 16; a.tile_max = c->tile_max_depth; a.queue = c->active_bricks; a.cnt = c->counters;
+  a.sdf_trunc = ip->sdf_truncation; a.max_dist = ip->max_integrate_dist;
+  a.has_color = has_color; a.color_angled = use_angle_weight_color;
+  a.tiles_x = kf_div_up(c->cols, 16); a.tiles_y = kf_div_up(c->rows, 16);
+  if (transform) {
+    for (int i = 0; i < 16; ++i) a.pose_val.m[i] = transform->m[i];
+    a.pose = nullptr; a.track = nullptr;
+  } else {
+    a.pose = c->track->pose; a.track = c->track;
+  }
+  kf_evt_begin(c, KF_STAGE_INTEGRATE);
+  hipLaunchKernelGGL(k_integrate_prepare, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_integrate_cull, dim3((unsigned)((c->n_stored_bricks + 255) / 256)), dim3(256), 0, c->stream, a);
+  unsigned grid = (unsigned)(c->n_stored_bricks < 4096 ? c->n_stored_bricks : 4096);
+  kf_evt_begin(c, KF_STAGE_INTEGRATE_KERNEL);
+  if (has_color) hipLaunchKernelGGL(k_integrate_bricks<true>, dim3(grid), dim3(256), 0, c->stream, a);
+  else hipLaunchKernelGGL(k_integrate_bricks<false>, dim3(grid), dim3(256), 0, c->stream, a);
+  kf_evt_end(c, KF_STAGE_INTEGRATE_KERNEL);
+  kf_evt_end(c, KF_STAGE_INTEGRATE);
+  return (int)hipGetLastError();
+}

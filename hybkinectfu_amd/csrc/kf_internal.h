@@ -1,0 +1,260 @@
+// kf_internal.h -- context layout and device-side arithmetic shared by the gfx950 kernels.
+//
+// All device arithmetic that feeds a discrete decision (pixel rounding, update predicate, cube index) is written one
+// fp32 operation per reference source operation and the library is built with -ffp-contract=off, so the result bits
+// equal the reference's C++ semantics (see DESIGN.md "Parity").  Citations are relative to /root/reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/hybkf.h"
+
+#define KF_BRICK 8                 // voxels per brick edge
+#define KF_BRICK_VOX 512           // voxels per brick: 4 KiB of (tsdf, weight) pairs, contiguous in HBM
+#define KF_FLAG_OBSERVED 1u        // some voxel of the brick has weight > 0
+#define KF_FLAG_HASNEG 2u          // some voxel of the brick has (or once had) tsdf < 0
+#define KF_MAX_LEVELS 3
+#define KF_ICP_MAX_WG 512
+
+enum { KF_ERR_ARG = 1001, KF_ERR_STATE = 1002, KF_ERR_ALLOC = 1003 };
+
+// Dense TSDF volume, bricked: voxel (x,y,z) lives in brick (x>>3, y>>3, z>>3) at offset ((z&7)<<6 | (y&7)<<3 | (x&7)).
+// Only brick layers [bz0, bz1) are stored (z-slab + halo).  Reference: tsdfVolume.h:14-19,57-60 (12-byte AoS, linear).
+struct KfVolume {
+  float2* tw;            // (tsdf, weight) per voxel
+  uchar4* color;         // (c0, c1, c2, unused) per voxel; null when the context has no colour
+  uint8_t* flags;        // per brick KF_FLAG_*
+  int res;               // voxels per axis
+  int nb;                // bricks per axis
+  int bz0, bz1;          // stored brick layers
+  int own_z0, own_z1;    // owned voxel layers (subset of the stored ones)
+  float size;            // metres
+  float cell;            // size / (float)res, the reference's fp32 quotient (tsdfVolume.h:44-46)
+  float max_weight;
+};
+
+// Device-resident tracker state (what CameraPoseFinder keeps in _pose plus the Gauss-Newton scratch).
+struct KfTrackState {
+  float pose[16];        // CameraPoseFinder::_pose
+  float cur[16];         // cur_transform of the running estimate
+  float last_inv[16];    // _pose.getInverse() at the start of the frame
+  float reduced[27];     // rigid_align_buf_reduced
+  int   status;          // KF_TRACK_*
+  int   tracked;         // result of the last findCameraPose
+  int   iterations;
+  int   converged;       // SDF tracker: |x| < 1e-3 reached
+  unsigned ticket;       // arrival counter of the single-pass reduction
+  unsigned pad_[3];
+};
+
+struct KfCounters {
+  unsigned long long n_upd;       // voxels updated by the last integrate
+  unsigned n_active_bricks;       // bricks queued by the last cull
+  unsigned n_triangles;           // MarchingcubeData::_ptr_num_triangles
+  unsigned long long weight_gt0;
+  unsigned scan_total;
+  unsigned frames_lost;           // integrate calls skipped because tracking failed (device-resident pose path)
+  unsigned long long n_upd_total; // running sum of n_upd over integrate calls (reset with kf_reset_volume)
+  unsigned frames_fused;
+  unsigned pad_;
+};
+
+struct kf_ctx {
+  kf_config cfg;
+  hipStream_t stream;
+  int cols, rows;
+  int levels;
+  int lvl_cols[KF_MAX_LEVELS], lvl_rows[KF_MAX_LEVELS];
+  // frame maps (CudaDeviceDataMan.h:56-67)
+  uint16_t* depth_mm;                 // staging for host uploads
+  float* raw_depth; float* trunced_depth; float* filtered_depth;
+  uchar4* raw_rgb; uchar4* raycast_rgb;   // stored 4 bytes/pixel on the device
+  float4* new_v[KF_MAX_LEVELS]; float4* new_n[KF_MAX_LEVELS];
+  float4* model_v[KF_MAX_LEVELS]; float4* model_n[KF_MAX_LEVELS];
+  float* icp_partials;                // KF_ICP_MAX_WG x 32 floats
+  KfTrackState* track;                // device
+  KfCounters* counters;               // device
+  float* scratch_mats;                // device: 8 x 16 floats for host-supplied transforms
+  KfVolume vol;
+  size_t n_stored_vox, n_stored_bricks;
+  unsigned* active_bricks;            // device: brick ids queued by the cull kernel
+  float* tile_max_depth;              // device: per 16x16-pixel tile max of gated depth
+  kf_triangle* triangles; uint32_t max_triangles;
+  unsigned* mc_block_counts; size_t mc_blocks_cap;
+  void* host_pinned;                  // small pinned staging buffer
+  // per-stage hipEvent timers (KF_STAGE_*): bit s of timers_enabled turns stage s on
+  int timers_enabled;
+  hipEvent_t ev[8][2][64];            // [stage][begin/end][ring]
+  int ev_n[8];                        // pairs recorded and not yet folded
+  double ev_ms[8]; unsigned ev_count[8];
+};
+
+enum { KF_STAGE_UPLOAD = 0, KF_STAGE_PREPROCESS = 1, KF_STAGE_TRACK = 2, KF_STAGE_INTEGRATE = 3, KF_STAGE_RAYCAST = 4,
+       KF_STAGE_INTEGRATE_KERNEL = 5, KF_STAGE_MCUBES = 6, KF_STAGE_RAYCAST_KERNEL = 7 };
+void kf_evt_begin(kf_ctx* c, int stage);
+void kf_evt_end(kf_ctx* c, int stage);
+
+#define KF_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+static inline int kf_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// device arithmetic
+// ------------------------------------------------------------------------------------------------------------------
+struct KfMat { float m[16]; };
+struct KfCam { int cols, rows; float cx, cy, fx, fy; };
+
+__device__ __forceinline__ float3 kf3(float x, float y, float z) { return make_float3(x, y, z); }
+__device__ __forceinline__ float3 kf_sub(float3 a, float3 b) { return kf3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float3 kf_add(float3 a, float3 b) { return kf3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ float3 kf_scale(float3 a, float s) { return kf3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float kf_dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float3 kf_cross(float3 a, float3 b) {
+  return kf3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float kf_norm(float3 v) { return sqrtf(kf_dot(v, v)); }
+// cuda_declar.h:89-94 -- reciprocal taken in double, narrowed, then an fp32 multiply
+__device__ __forceinline__ float3 kf_normalize(float3 v) {
+  float len = kf_norm(v);
+  if ((double)len < 1e-8) return kf3(0.f, 0.f, 0.f);
+  float r = (float)(1.0 / (double)len);
+  return kf_scale(v, r);
+}
+__device__ __forceinline__ bool kf_is_zero4(float4 v) { return v.x == 0.f && v.y == 0.f && v.z == 0.f && v.w == 0.f; }
+
+// Mat.h:230-238: row * vector, summed left to right
+__device__ __forceinline__ float4 kf_mat_vec(const float* m, float4 v) {
+  return make_float4(m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3] * v.w,
+                     m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7] * v.w,
+                     m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11] * v.w,
+                     m[12] * v.x + m[13] * v.y + m[14] * v.z + m[15] * v.w);
+}
+__device__ __forceinline__ float3 kf_mat_point3(const float* m, float x, float y, float z, float w) {
+  return kf3(m[0] * x + m[1] * y + m[2] * z + m[3] * w,
+             m[4] * x + m[5] * y + m[6] * z + m[7] * w,
+             m[8] * x + m[9] * y + m[10] * z + m[11] * w);
+}
+
+// (int) of a double the way the host reference rounds it: truncation; NaN and out-of-range give INT_MIN
+__device__ __forceinline__ int kf_to_int(double v) {
+  if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
+  return (int)v;
+}
+// DepthCamera.h:19-29
+__device__ __forceinline__ float3 kf_depth_to_skeleton(unsigned ux, unsigned uy, float depth, const KfCam& c) {
+  float vx = depth * ((float)ux - c.cx) / c.fx;
+  float vy = depth * ((float)uy - c.cy) / c.fy;
+  return kf3(vx, vy, depth);
+}
+// DepthCamera.h:30-43: `(int)(p + 0.5)` with a double literal
+__device__ __forceinline__ int2 kf_project(float3 v, const KfCam& c) {
+  float px = v.x * c.fx / v.z + c.cx;
+  float py = v.y * c.fy / v.z + c.cy;
+  return make_int2(kf_to_int((double)px + 0.5), kf_to_int((double)py + 0.5));
+}
+
+// ---- volume addressing -------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t kf_brick_slot(const KfVolume& v, int bx, int by, int bz) {
+  return ((size_t)(bz - v.bz0) * v.nb + by) * v.nb + bx;
+}
+__device__ __forceinline__ size_t kf_vox_index(const KfVolume& v, int x, int y, int z) {
+  return kf_brick_slot(v, x >> 3, y >> 3, z >> 3) * KF_BRICK_VOX + (size_t)(((z & 7) << 6) | ((y & 7) << 3) | (x & 7));
+}
+__device__ __forceinline__ bool kf_z_stored(const KfVolume& v, int z) { return z >= v.bz0 * KF_BRICK && z < v.bz1 * KF_BRICK; }
+
+// tsdfVolume.h:50-56
+__device__ __forceinline__ int3 kf_world_to_voxel(const KfVolume& v, float3 p) {
+  float r = (float)v.res;
+  return make_int3(kf_to_int((double)(p.x * r / v.size)), kf_to_int((double)(p.y * r / v.size)), kf_to_int((double)(p.z * r / v.size)));
+}
+// tsdfVolume.h:151-172
+__device__ __forceinline__ bool kf_interp_params(const KfVolume& v, float3 pos, int3& base, float& a, float& b, float& c) {
+  int3 g = kf_world_to_voxel(v, pos);
+  const int R = v.res;
+  if (g.x <= 0 || g.x >= R - 1) return false;
+  if (g.y <= 0 || g.y >= R - 1) return false;
+  if (g.z <= 0 || g.z >= R - 1) return false;
+  const float cell = v.cell;
+  float vx = ((float)g.x + 0.5f) * cell;
+  float vy = ((float)g.y + 0.5f) * cell;
+  float vz = ((float)g.z + 0.5f) * cell;
+  g.x = (pos.x < vx) ? (g.x - 1) : g.x;
+  g.y = (pos.y < vy) ? (g.y - 1) : g.y;
+  g.z = (pos.z < vz) ? (g.z - 1) : g.z;
+  base = g;
+  a = (pos.x - ((float)g.x + 0.5f) * cell) / cell;
+  b = (pos.y - ((float)g.y + 0.5f) * cell) / cell;
+  c = (pos.z - ((float)g.z + 0.5f) * cell) / cell;
+  return true;
+}
+// tsdfVolume.h:98-122.  Returns false as the reference does when any of the 8 voxels has weight 0.
+// Layers outside the stored slab read as unobserved (only reachable in multi-GPU runs, where the halo covers them).
+__device__ __forceinline__ bool kf_interpolate_sdf(const KfVolume& v, float3 pos, float& dist) {
+  int3 g; float a, b, c;
+  if (!kf_interp_params(v, pos, g, a, b, c)) return false;
+  if (!kf_z_stored(v, g.z) || !kf_z_stored(v, g.z + 1)) return false;
+  float2 q[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) q[k] = v.tw[kf_vox_index(v, g.x + (k >> 2), g.y + ((k >> 1) & 1), g.z + (k & 1))];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) if (q[k].y == 0.f) return false;
+  float ia = 1 - a, ib = 1 - b, ic = 1 - c;
+  dist = q[0].x * ia * ib * ic + q[1].x * ia * ib * c + q[2].x * ia * b * ic + q[3].x * ia * b * c +
+         q[4].x * a * ib * ic + q[5].x * a * ib * c + q[6].x * a * b * ic + q[7].x * a * b * c;
+  return true;
+}
+// tsdfVolume.h:123-148 (float -> uchar truncation)
+__device__ __forceinline__ bool kf_interpolate_color(const KfVolume& v, float3 pos, uchar4& out) {
+  int3 g; float a, b, c;
+  if (!kf_interp_params(v, pos, g, a, b, c)) return false;
+  if (!kf_z_stored(v, g.z) || !kf_z_stored(v, g.z + 1)) return false;
+  float ia = 1 - a, ib = 1 - b, ic = 1 - c;
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    size_t idx = kf_vox_index(v, g.x + (k >> 2), g.y + ((k >> 1) & 1), g.z + (k & 1));
+    if (v.tw[idx].y == 0.f) return false;
+    uchar4 col = v.color[idx];
+    float wa = (k >> 2) ? a : ia, wb = ((k >> 1) & 1) ? b : ib, wc = (k & 1) ? c : ic;
+    float t0 = (float)col.x * wa * wb * wc, t1 = (float)col.y * wa * wb * wc, t2 = (float)col.z * wa * wb * wc;
+    acc[0] = (k == 0) ? t0 : acc[0] + t0; acc[1] = (k == 0) ? t1 : acc[1] + t1; acc[2] = (k == 0) ? t2 : acc[2] + t2;
+  }
+  out = make_uchar4((unsigned char)acc[0], (unsigned char)acc[1], (unsigned char)acc[2], 0);
+  return true;
+}
+
+// wave64 sum by DPP-free shuffles (deterministic order)
+__device__ __forceinline__ float kf_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Mat44::getInverse (src/cuda/Mat.h:319-440): cofactor expansion; products and sums in the reference's order.
+#define T3(a, b, c) (e[a] * e[b] * e[c])
+__host__ __device__ static inline void kf_mat44_inverse(const float* e, float* out) {
+  float inv[16];
+  inv[0] = T3(5, 10, 15) - T3(5, 11, 14) - T3(9, 6, 15) + T3(9, 7, 14) + T3(13, 6, 11) - T3(13, 7, 10);
+  inv[4] = -T3(4, 10, 15) + T3(4, 11, 14) + T3(8, 6, 15) - T3(8, 7, 14) - T3(12, 6, 11) + T3(12, 7, 10);
+  inv[8] = T3(4, 9, 15) - T3(4, 11, 13) - T3(8, 5, 15) + T3(8, 7, 13) + T3(12, 5, 11) - T3(12, 7, 9);
+  inv[12] = -T3(4, 9, 14) + T3(4, 10, 13) + T3(8, 5, 14) - T3(8, 6, 13) - T3(12, 5, 10) + T3(12, 6, 9);
+  inv[1] = -T3(1, 10, 15) + T3(1, 11, 14) + T3(9, 2, 15) - T3(9, 3, 14) - T3(13, 2, 11) + T3(13, 3, 10);
+  inv[5] = T3(0, 10, 15) - T3(0, 11, 14) - T3(8, 2, 15) + T3(8, 3, 14) + T3(12, 2, 11) - T3(12, 3, 10);
+  inv[9] = -T3(0, 9, 15) + T3(0, 11, 13) + T3(8, 1, 15) - T3(8, 3, 13) - T3(12, 1, 11) + T3(12, 3, 9);
+  inv[13] = T3(0, 9, 14) - T3(0, 10, 13) - T3(8, 1, 14) + T3(8, 2, 13) + T3(12, 1, 10) - T3(12, 2, 9);
+  inv[2] = T3(1, 6, 15) - T3(1, 7, 14) - T3(5, 2, 15) + T3(5, 3, 14) + T3(13, 2, 7) - T3(13, 3, 6);
+  inv[6] = -T3(0, 6, 15) + T3(0, 7, 14) + T3(4, 2, 15) - T3(4, 3, 14) - T3(12, 2, 7) + T3(12, 3, 6);
+  inv[10] = T3(0, 5, 15) - T3(0, 7, 13) - T3(4, 1, 15) + T3(4, 3, 13) + T3(12, 1, 7) - T3(12, 3, 5);
+  inv[14] = -T3(0, 5, 14) + T3(0, 6, 13) + T3(4, 1, 14) - T3(4, 2, 13) - T3(12, 1, 6) + T3(12, 2, 5);
+  inv[3] = -T3(1, 6, 11) + T3(1, 7, 10) + T3(5, 2, 11) - T3(5, 3, 10) - T3(9, 2, 7) + T3(9, 3, 6);
+  inv[7] = T3(0, 6, 11) - T3(0, 7, 10) - T3(4, 2, 11) + T3(4, 3, 10) + T3(8, 2, 7) - T3(8, 3, 6);
+  inv[11] = -T3(0, 5, 11) + T3(0, 7, 9) + T3(4, 1, 11) - T3(4, 3, 9) - T3(8, 1, 7) + T3(8, 3, 5);
+  inv[15] = T3(0, 5, 10) - T3(0, 6, 9) - T3(4, 1, 10) + T3(4, 2, 9) + T3(8, 1, 6) - T3(8, 2, 5);
+  float det = e[0] * inv[0] + e[1] * inv[4] + e[2] * inv[8] + e[3] * inv[12];
+  float detr = 1.0f / det;
+  for (int i = 0; i < 16; ++i) out[i] = inv[i] * detr;
+}
+#undef T3
+
+// entry points implemented across the .hip files (internal linkage between translation units)
+int kf_launch_pyramids(kf_ctx* ctx, bool model, bool vertices, bool normals);

@@ -1,0 +1,273 @@
+// mcubes.hip -- marching-cubes iso-surface extraction (reference: extractIsoSurfaceKernel & helpers,
+// src/cuda/marchingcube.cu:5-164; tables src/cuda/marchingcube_table.h; MarchingcubeData src/cuda/MarchingcubeData.h).
+//
+// The reference appends triangles with one global atomicAdd, so its output ORDER is nondeterministic (and its
+// check-then-add can overshoot the buffer, marchingcube.cu:29-32).  Here extraction is two deterministic passes:
+//   count  : one lane per cell, 256 consecutive cells (z, y, x order) per workgroup -> per-workgroup triangle count;
+//   scan   : exclusive prefix over workgroups;
+//   emit   : the same cell logic again, intra-workgroup prefix, triangle k of cell (x,y,z) lands at a fixed index.
+// The canonical order is (z, y, x, k) -- identical for 1 GPU and for concatenated z-slabs.
+// Space skipping: a cell can only produce triangles if a corner SDF is negative, which needs a negative voxel in the
+// cell's +-2 neighbourhood (trilinear weights are convex), so workgroups and cells whose neighbourhood bricks carry no
+// KF_FLAG_HASNEG are dropped before any voxel is read.  The triangle table is packed into 256 x 64-bit words (16
+// nibbles per case) instead of the reference's 16 KiB int table; the 12-bit edge mask is derived from it.
+#include "kf_internal.h"
+
+__constant__ unsigned long long c_tri_words[256] = {
+#include "mc_tables.inc"
+};
+
+struct McArgs {
+  KfVolume vol;
+  int z0, z1;                    // cell layers processed (owned slab)
+  int has_color;
+  float thr;
+  unsigned* block_counts;        // [n_blocks + 1]
+  unsigned n_blocks;
+  kf_triangle* tris; unsigned max_tris;
+  KfCounters* cnt;
+};
+
+__device__ __forceinline__ float sel8(const float d[8], int k) {
+  float r = d[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) r = (k == i) ? d[i] : r;
+  return r;
+}
+__device__ __forceinline__ uchar4 sel8c(const uchar4 d[8], int k) {
+  uchar4 r = d[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) r = (k == i) ? d[i] : r;
+  return r;
+}
+
+// corner k (reference evaluation order 000,100,010,001,110,011,101,111 as x,y,z bits)
+__device__ __forceinline__ int corner_bits(int k) {
+  const int cb[8] = {0, 1, 2, 4, 3, 6, 5, 7};     // bit0 = x, bit1 = y, bit2 = z
+  return cb[k];
+}
+
+struct CellEval { float d[8]; uchar4 c[8]; unsigned ci; unsigned long long word; int ntri; float3 wp; };
+
+// does any brick in the +-2 voxel neighbourhood of (x,y,z) carry `mask`?
+__device__ __forceinline__ bool neighbourhood_has(const KfVolume& v, int x, int y, int z, unsigned mask) {
+  const int R = v.res;
+  const int bx0 = max(x - 2, 0) >> 3, bx1 = min(x + 2, R - 1) >> 3;
+  const int by0 = max(y - 2, 0) >> 3, by1 = min(y + 2, R - 1) >> 3;
+  const int bz0 = max(max(z - 2, 0) >> 3, v.bz0), bz1 = min(min(z + 2, R - 1) >> 3, v.bz1 - 1);
+  for (int bz = bz0; bz <= bz1; ++bz)
+    for (int by = by0; by <= by1; ++by)
+      for (int bx = bx0; bx <= bx1; ++bx)
+        if (v.flags[kf_brick_slot(v, bx, by, bz)] & mask) return true;
+  return false;
+}
+
+// extractIsoSurfaceAtPosition marchingcube.cu:41-113 up to the table lookup; returns the triangle count of the cell
+__device__ __forceinline__ int eval_cell(const McArgs& a, int x, int y, int z, CellEval& e) {
+  const KfVolume& v = a.vol;
+  e.ntri = 0;
+  if (!neighbourhood_has(v, x, y, z, KF_FLAG_HASNEG)) return 0;
+  const float cell = v.cell;
+  e.wp = kf3(((float)x + 0.5f) * cell, ((float)y + 0.5f) * cell, ((float)z + 0.5f) * cell);     // tsdfVolume.h:38-49
+  const float P = cell * 0.5f, M = cell * (-0.5f);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int b = corner_bits(k);
+    const float3 p = kf_add(e.wp, kf3((b & 1) ? P : M, (b & 2) ? P : M, (b & 4) ? P : M));
+    if (!kf_interpolate_sdf(v, p, e.d[k])) return 0;
+    e.c[k] = make_uchar4(0, 0, 0, 0);
+    if (a.has_color) kf_interpolate_color(v, p, e.c[k]);
+  }
+  // :77-85  cube index bit order 010,110,100,000,011,111,101,001  (k: 0=000 1=100 2=010 3=001 4=110 5=011 6=101 7=111)
+  unsigned ci = 0;
+  if (e.d[2] < 0.f) ci += 1;
+  if (e.d[4] < 0.f) ci += 2;
+  if (e.d[1] < 0.f) ci += 4;
+  if (e.d[0] < 0.f) ci += 8;
+  if (e.d[5] < 0.f) ci += 16;
+  if (e.d[7] < 0.f) ci += 32;
+  if (e.d[6] < 0.f) ci += 64;
+  if (e.d[3] < 0.f) ci += 128;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) if (fabsf(e.d[k]) > a.thr) return 0;                               // :101-108
+  const unsigned long long w = c_tri_words[ci];
+  unsigned emask = 0; int n = 0;
+#pragma unroll
+  for (int i = 0; i < 15; ++i) { unsigned ed = (unsigned)((w >> (4 * i)) & 0xF); if (ed != 0xF) { emask |= 1u << ed; ++n; } }
+  if (emask == 0 || emask == 255) return 0;                                                      // :110
+  e.ci = ci; e.word = w; e.ntri = n / 3;
+  return e.ntri;
+}
+
+// vertexInterp marchingcube.cu:5-26 for edge `ed` of the evaluated cell (edge -> corner pairs :116-127)
+__device__ __forceinline__ kf_vertex edge_vertex(const McArgs& a, const CellEval& e, unsigned ed) {
+  const int ea[12] = {2, 4, 1, 0, 5, 7, 6, 3, 2, 4, 1, 0};
+  const int eb[12] = {4, 1, 0, 2, 7, 6, 3, 5, 5, 7, 6, 3};
+  int ka = 0, kb = 0;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { ka = (ed == (unsigned)i) ? ea[i] : ka; kb = (ed == (unsigned)i) ? eb[i] : kb; }
+  const float cell = a.vol.cell;
+  const float P = cell * 0.5f, M = cell * (-0.5f);
+  const int ba = corner_bits(ka), bb = corner_bits(kb);
+  const float3 p1 = kf_add(e.wp, kf3((ba & 1) ? P : M, (ba & 2) ? P : M, (ba & 4) ? P : M));
+  const float3 p2 = kf_add(e.wp, kf3((bb & 1) ? P : M, (bb & 2) ? P : M, (bb & 4) ? P : M));
+  const float d1 = sel8(e.d, ka), d2 = sel8(e.d, kb);
+  const uchar4 c1 = sel8c(e.c, ka), c2 = sel8c(e.c, kb);
+  const float inv255 = (float)(1.0 / (double)255.f);          // `*(1.0/ 255.f)` : double quotient narrowed
+  kf_vertex r;
+  const float iso = 0.0f;
+  const bool pick1 = fabsf(iso - d1) < 0.00001f;
+  const bool pick2 = !pick1 && fabsf(iso - d2) < 0.00001f;
+  const bool pick1b = !pick1 && !pick2 && fabsf(d1 - d2) < 0.00001f;
+  if (pick1 || pick1b) {
+    r.pos[0] = p1.x; r.pos[1] = p1.y; r.pos[2] = p1.z;
+    r.color[0] = (float)c1.x * inv255; r.color[1] = (float)c1.y * inv255; r.color[2] = (float)c1.z * inv255;
+  } else if (pick2) {
+    r.pos[0] = p2.x; r.pos[1] = p2.y; r.pos[2] = p2.z;
+    r.color[0] = (float)c2.x * inv255; r.color[1] = (float)c2.y * inv255; r.color[2] = (float)c2.z * inv255;
+  } else {
+    const float mu = (iso - d1) / (d2 - d1);
+    r.pos[0] = p1.x + mu * (p2.x - p1.x); r.pos[1] = p1.y + mu * (p2.y - p1.y); r.pos[2] = p1.z + mu * (p2.z - p1.z);
+    r.color[0] = ((float)c1.x + mu * (float)((int)c2.x - (int)c1.x)) / 255.f;
+    r.color[1] = ((float)c1.y + mu * (float)((int)c2.y - (int)c1.y)) / 255.f;
+    r.color[2] = ((float)c1.z + mu * (float)((int)c2.z - (int)c1.z)) / 255.f;
+  }
+  return r;
+}
+
+// workgroup-level early out: 256 consecutive cells along x (then y) share at most (256/8 + 2) x 2 x 2 bricks
+__device__ __forceinline__ bool block_may_have_surface(const McArgs& a, size_t first_cell, int* s_any) {
+  const KfVolume& v = a.vol;
+  const int R = v.res;
+  if (threadIdx.x == 0) *s_any = 0;
+  __syncthreads();
+  // probe the cells at an 4-cell stride (+ the last one): every neighbourhood brick of every cell is covered
+  const size_t cell_i = first_cell + threadIdx.x;
+  const size_t n_cells = (size_t)(a.z1 - a.z0) * R * R;
+  if (cell_i < n_cells && ((threadIdx.x & 3) == 0 || threadIdx.x == 255)) {
+    const int x = (int)(cell_i % R), y = (int)((cell_i / R) % R), z = a.z0 + (int)(cell_i / ((size_t)R * R));
+    if (neighbourhood_has(v, x, y, z, KF_FLAG_HASNEG)) *s_any = 1;
+  }
+  __syncthreads();
+  return *s_any != 0;
+}
+
+__global__ void __launch_bounds__(256) k_mc_count(McArgs a) {
+  __shared__ int s_any; __shared__ unsigned s_sum[4];
+  const int R = a.vol.res;
+  const size_t first = (size_t)blockIdx.x * 256;
+  if (!block_may_have_surface(a, first, &s_any)) { if (threadIdx.x == 0) a.block_counts[blockIdx.x] = 0; return; }
+  const size_t i = first + threadIdx.x;
+  const size_t n_cells = (size_t)(a.z1 - a.z0) * R * R;
+  int n = 0;
+  if (i < n_cells) { CellEval e; n = eval_cell(a, (int)(i % R), (int)((i / R) % R), a.z0 + (int)(i / ((size_t)R * R)), e); }
+  float s = kf_wave_sum((float)n);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = (unsigned)s;
+  __syncthreads();
+  if (threadIdx.x == 0) a.block_counts[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+}
+
+// exclusive scan of block_counts[0..n) in place by ONE workgroup (chunks of 1024), total -> block_counts[n]
+__global__ void __launch_bounds__(256) k_mc_scan(unsigned* counts, unsigned n, KfCounters* cnt) {
+  __shared__ unsigned s_wave[4]; __shared__ unsigned s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (unsigned base = 0; base < n; base += 1024) {
+    const unsigned i0 = base + threadIdx.x * 4;
+    unsigned v[4]; unsigned local = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = (i0 + k < n) ? counts[i0 + k] : 0u; local += v[k]; }
+    // wave inclusive scan of `local`
+    unsigned inc = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { unsigned t = __shfl_up(inc, off, 64); if ((threadIdx.x & 63) >= off) inc += t; }
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    unsigned wave_off = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += s_wave[w];
+    unsigned excl = s_carry + wave_off + inc - local;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (i0 + k < n) counts[i0 + k] = excl; excl += v[k]; }
+    __syncthreads();
+    if (threadIdx.x == 255) s_carry = excl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { counts[n] = s_carry; cnt->scan_total = s_carry; }
+}
+
+__global__ void __launch_bounds__(256) k_mc_emit(McArgs a) {
+  __shared__ unsigned s_wave[4];
+  const unsigned my_base = a.block_counts[blockIdx.x], my_count = a.block_counts[blockIdx.x + 1] - my_base;
+  if (my_count == 0) return;
+  const int R = a.vol.res;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t n_cells = (size_t)(a.z1 - a.z0) * R * R;
+  CellEval e; e.ntri = 0;
+  int n = 0;
+  if (i < n_cells) n = eval_cell(a, (int)(i % R), (int)((i / R) % R), a.z0 + (int)(i / ((size_t)R * R)), e);
+  unsigned inc = (unsigned)n;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { unsigned t = __shfl_up(inc, off, 64); if ((threadIdx.x & 63) >= off) inc += t; }
+  if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  unsigned off0 = inc - (unsigned)n;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off0 += s_wave[w];
+  // append after what the buffer already holds (the reference never clears its counter: MarchingcubeData.h:56,99)
+  const unsigned start = a.cnt->n_triangles + my_base + off0;
+  for (int t = 0; t < n; ++t) {
+    const unsigned dst = start + (unsigned)t;
+    if (dst >= a.max_tris) break;                                                // marchingcube.cu:29-31
+    kf_triangle tri;
+    tri.v0 = edge_vertex(a, e, (unsigned)((e.word >> (12 * t)) & 0xF));
+    tri.v1 = edge_vertex(a, e, (unsigned)((e.word >> (12 * t + 4)) & 0xF));
+    tri.v2 = edge_vertex(a, e, (unsigned)((e.word >> (12 * t + 8)) & 0xF));
+    a.tris[dst] = tri;
+  }
+}
+
+__global__ void k_mc_finish(KfCounters* cnt, unsigned max_tris) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    unsigned long long t = (unsigned long long)cnt->n_triangles + cnt->scan_total;
+    cnt->n_triangles = (unsigned)(t > max_tris ? max_tris : t);
+  }
+}
+
+extern "C" int kf_marching_cubes(kf_ctx* c, int has_color, float thr) {
+  if (!c) return KF_ERR_ARG;
+  if (!c->triangles || c->max_triangles == 0) return KF_ERR_STATE;
+  if (has_color && !c->vol.color) return KF_ERR_STATE;
+  McArgs a;
+  a.vol = c->vol; a.z0 = c->vol.own_z0; a.z1 = c->vol.own_z1; a.has_color = has_color; a.thr = thr;
+  const size_t n_cells = (size_t)(a.z1 - a.z0) * c->vol.res * c->vol.res;
+  a.n_blocks = (unsigned)((n_cells + 255) / 256);
+  if (a.n_blocks > c->mc_blocks_cap) return KF_ERR_STATE;
+  a.block_counts = c->mc_block_counts; a.tris = c->triangles; a.max_tris = c->max_triangles; a.cnt = c->counters;
+  hipLaunchKernelGGL(k_mc_count, dim3(a.n_blocks), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_mc_scan, dim3(1), dim3(256), 0, c->stream, a.block_counts, a.n_blocks, c->counters);
+  hipLaunchKernelGGL(k_mc_emit, dim3(a.n_blocks), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_mc_finish, dim3(1), dim3(64), 0, c->stream, c->counters, c->max_triangles);
+  return (int)hipGetLastError();
+}
+
+extern "C" int kf_clear_triangles(kf_ctx* c) {
+  if (!c) return KF_ERR_ARG;
+  KF_CHECK(hipMemsetAsync(&c->counters->n_triangles, 0, sizeof(unsigned), c->stream));
+  return 0;
+}
+
+extern "C" int kf_triangle_count(kf_ctx* c, uint32_t* count) {
+  if (!c || !count) return KF_ERR_ARG;
+  KF_CHECK(hipMemcpyAsync(c->host_pinned, &c->counters->n_triangles, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  KF_CHECK(hipStreamSynchronize(c->stream));
+  *count = *(unsigned*)c->host_pinned;
+  return 0;
+}
+
+extern "C" int kf_read_triangles(kf_ctx* c, kf_triangle* dst, uint32_t first, uint32_t count) {
+  if (!c || !dst) return KF_ERR_ARG;
+  if ((uint64_t)first + count > c->max_triangles) return KF_ERR_ARG;
+  if (count == 0) return 0;
+  KF_CHECK(hipMemcpyAsync(dst, c->triangles + first, (size_t)count * sizeof(kf_triangle), hipMemcpyDeviceToHost, c->stream));
+  KF_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}

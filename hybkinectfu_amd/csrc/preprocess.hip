@@ -1,0 +1,193 @@
+// preprocess.hip -- depth gate, bilateral filter, back-projection, normals and the 2x2 box pyramids.
+// Reference: src/cuda/DataPreprocesser.cu, src/cuda/VerticesNormalsCalculater.cu, src/cuda/sample.cu.
+//
+// gfx950 notes: every map here (<= 4.9 MB) lives in the XCD L2 / Infinity Cache for the whole frame, so these kernels are
+// launch- and latency-bound, not HBM-bound.  Lanes run along x (64 consecutive pixels = 256 B / 1 KiB per wave row),
+// and the pyramid kernel writes level 1 and level 2 of vertices AND normals in one launch (the reference uses 8).
+#include "kf_internal.h"
+
+static inline KfCam to_cam(const kf_camera_params* p) {
+  KfCam c; c.cols = (int)p->cols; c.rows = (int)p->rows; c.cx = p->cx; c.cy = p->cy; c.fx = p->fx; c.fy = p->fy; return c;
+}
+
+// DataPreprocesser.cu:17-36: keep d iff trunc_min < d < trunc_max (strict both sides)
+__global__ void __launch_bounds__(256) k_trunc_depth(const float* __restrict__ in, float* __restrict__ out, int n, float tmin, float tmax) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float d = in[i];
+  out[i] = (d < tmax && d > tmin) ? d : 0.f;
+}
+
+// DataPreprocesser.cu:37-79.  64x4 pixel tile per workgroup, (64+2r)x(4+2r) depth halo staged through LDS.
+#define BIL_TX 64
+#define BIL_TY 4
+#define BIL_MAXR 8
+__global__ void __launch_bounds__(256) k_bilateral(const float* __restrict__ in, float* __restrict__ out, int cols, int rows,
+                                                   float ss_inv, float sd_inv, float sigma_depth, int radius) {
+  __shared__ float tile[(BIL_TY + 2 * BIL_MAXR) * (BIL_TX + 2 * BIL_MAXR)];
+  const int tw = BIL_TX + 2 * radius, th = BIL_TY + 2 * radius;
+  const int x0 = blockIdx.x * BIL_TX - radius, y0 = blockIdx.y * BIL_TY - radius;
+  for (int i = threadIdx.x; i < tw * th; i += 256) {
+    int lx = i % tw, ly = i / tw, gx = x0 + lx, gy = y0 + ly;
+    tile[i] = (gx >= 0 && gx < cols && gy >= 0 && gy < rows) ? in[gy * cols + gx] : 0.f;   // outside = skipped like a zero tap
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const int x = blockIdx.x * BIL_TX + lx, y = blockIdx.y * BIL_TY + ly;
+  if (x >= cols || y >= rows) return;
+  const float value = tile[(ly + radius) * tw + lx + radius];
+  float result = value;
+  if (value != 0.f) {
+    // the reference clamps the window to the image; out-of-image taps are zeros in the tile and zeros are skipped (:61-64)
+    float sum1 = 0.f, sum2 = 0.f;
+    bool aborted = false;
+    const float thr = 5 * sigma_depth;
+    for (int dy = -radius; dy <= radius && !aborted; ++dy) {
+      const float* rowp = &tile[(ly + radius + dy) * tw + lx + radius];
+      for (int dx = -radius; dx <= radius; ++dx) {
+        float tmp = rowp[dx];
+        if (tmp == 0.f) continue;
+        if (fabsf(tmp - value) > thr) { aborted = true; break; }                      // :66-69 keeps the unfiltered value
+        float space2 = (float)(dx * dx + dy * dy);
+        float data2 = (value - tmp) * (value - tmp);
+        float w = __expf(-(space2 * ss_inv + data2 * sd_inv));
+        sum1 += tmp * w; sum2 += w;
+      }
+    }
+    if (!aborted && sum2 > 0.f) result = sum1 / sum2;
+  }
+  out[y * cols + x] = result;
+}
+
+// VerticesNormalsCalculater.cu:15-33
+__global__ void __launch_bounds__(256) k_depth_to_vertices(const float* __restrict__ depth, float4* __restrict__ out, KfCam cam) {
+  int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= cam.cols || y >= cam.rows) return;
+  float d = depth[y * cam.cols + x];
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (d != 0.f) { float3 v = kf_depth_to_skeleton((unsigned)x, (unsigned)y, d, cam); r = make_float4(v.x, v.y, v.z, 1.0f); }
+  out[y * cam.cols + x] = r;
+}
+
+// VerticesNormalsCalculater.cu:35-66
+__global__ void __launch_bounds__(256) k_vertices_to_normals(const float4* __restrict__ in, float4* __restrict__ out, int cols, int rows) {
+  int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= cols || y >= rows) return;
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!(x == cols - 1 || y == rows - 1 || x == 0 || y == 0)) {
+    int i = y * cols + x;
+    float4 v0 = in[i], vr = in[i + 1], vu = in[i + cols], vl = in[i - 1], vd = in[i - cols];
+    if (v0.z != 0.f && vr.z != 0.f && vu.z != 0.f && vl.z != 0.f && vd.z != 0.f) {
+      float3 c = kf_normalize(kf_cross(kf_sub(kf3(vu.x, vu.y, vu.z), kf3(vd.x, vd.y, vd.z)), kf_sub(kf3(vr.x, vr.y, vr.z), kf3(vl.x, vl.y, vl.z))));
+      r = make_float4(c.x, c.y, c.z, 0.f);
+    }
+  }
+  out[y * cols + x] = r;
+}
+
+// sample.cu:37-61 (vertices) and :16-36 (normals), intended semantics: each output pixel exactly once.
+__device__ __forceinline__ float4 pyr_vertex(float4 p00, float4 p01, float4 p10, float4 p11) {
+  if (p00.z == 0.f || p01.z == 0.f || p10.z == 0.f || p11.z == 0.f) return make_float4(0.f, 0.f, 0.f, 0.f);
+  const float q = 0.25f;                                  // `*0.25`: double literal narrowed by operator*(float4, const float&)
+  return make_float4((p00.x + p01.x + p10.x + p11.x) * q, (p00.y + p01.y + p10.y + p11.y) * q,
+                     (p00.z + p01.z + p10.z + p11.z) * q, (p00.w + p01.w + p10.w + p11.w) * q);
+}
+__device__ __forceinline__ float4 pyr_normal(float4 p00, float4 p01, float4 p10, float4 p11) {
+  if (kf_is_zero4(p01) || kf_is_zero4(p10) || kf_is_zero4(p00) || kf_is_zero4(p11)) return make_float4(0.f, 0.f, 0.f, 0.f);
+  const float q = 0.25f;
+  float3 n = kf_normalize(kf3((p00.x + p01.x + p10.x + p11.x) * q, (p00.y + p01.y + p10.y + p11.y) * q, (p00.z + p01.z + p10.z + p11.z) * q));
+  return make_float4(n.x, n.y, n.z, 0.f);
+}
+
+// One thread per 2x2 block of level-1 pixels (= one level-2 pixel): reads 16 level-0 texels, writes 4 level-1 and 1 level-2.
+// blockIdx.z: 0 = vertices, 1 = normals.
+struct PyrMaps { const float4* in[2]; float4* l1[2]; float4* l2[2]; };
+__global__ void __launch_bounds__(256) k_pyramid(PyrMaps m, int cols0, int rows0, int levels, int kind_base) {
+  const int kind = kind_base + blockIdx.z;
+  const float4* __restrict__ in = m.in[kind];
+  float4* __restrict__ o1 = m.l1[kind];
+  float4* __restrict__ o2 = m.l2[kind];
+  const int c1 = cols0 >> 1, r1 = rows0 >> 1, c2 = c1 >> 1, r2 = r1 >> 1;
+  const int bx = blockIdx.x * 32 + (threadIdx.x & 31), by = blockIdx.y * 8 + (threadIdx.x >> 5);
+  float4 q[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int x1 = bx * 2 + i, y1 = by * 2 + j;
+      q[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x1 < c1 && y1 < r1) {
+        const float4* p = in + (size_t)(2 * y1) * cols0 + 2 * x1;
+        float4 p00 = p[0], p01 = p[1], p10 = p[cols0], p11 = p[cols0 + 1];
+        q[j][i] = kind ? pyr_normal(p00, p01, p10, p11) : pyr_vertex(p00, p01, p10, p11);
+        o1[(size_t)y1 * c1 + x1] = q[j][i];
+      }
+    }
+  if (levels > 2 && bx < c2 && by < r2)
+    o2[(size_t)by * c2 + bx] = kind ? pyr_normal(q[0][0], q[0][1], q[1][0], q[1][1]) : pyr_vertex(q[0][0], q[0][1], q[1][0], q[1][1]);
+}
+
+int kf_launch_pyramids(kf_ctx* c, bool model, bool vertices, bool normals) {
+  if (c->levels < 2 || (!vertices && !normals)) return 0;
+  PyrMaps m;
+  float4** v = model ? c->model_v : c->new_v;
+  float4** n = model ? c->model_n : c->new_n;
+  m.in[0] = v[0]; m.l1[0] = v[1]; m.l2[0] = c->levels > 2 ? v[2] : nullptr;
+  m.in[1] = n[0]; m.l1[1] = n[1]; m.l2[1] = c->levels > 2 ? n[2] : nullptr;
+  int c1 = c->cols >> 1, r1 = c->rows >> 1;
+  dim3 grid(kf_div_up(kf_div_up(c1, 2), 32), kf_div_up(kf_div_up(r1, 2), 8), (vertices && normals) ? 2 : 1);
+  hipLaunchKernelGGL(k_pyramid, grid, dim3(256), 0, c->stream, m, c->cols, c->rows, c->levels, vertices ? 0 : 1);
+  return (int)hipGetLastError();
+}
+
+// ---- C ABI ---------------------------------------------------------------------------------------------------------
+extern "C" int kf_trunc_depth(kf_ctx* c, float tmin, float tmax) {
+  if (!c) return KF_ERR_ARG;
+  int n = c->cols * c->rows;
+  hipLaunchKernelGGL(k_trunc_depth, dim3(kf_div_up(n, 256)), dim3(256), 0, c->stream, c->raw_depth, c->trunced_depth, n, tmin, tmax);
+  return (int)hipGetLastError();
+}
+
+extern "C" int kf_bilateral_filter_depth(kf_ctx* c, float sigma_pixel, float sigma_depth) {
+  if (!c) return KF_ERR_ARG;
+  // DataPreprocesser.cu:95-96: 0.5 is a double literal; the quotient is narrowed to float
+  float sd_inv = (float)(0.5 / (double)(sigma_depth * sigma_depth));
+  float ss_inv = (float)(0.5 / (double)(sigma_pixel * sigma_pixel));
+  int radius = (int)ceil(2.0 * (double)sigma_pixel);                                  // :45
+  if (radius < 0 || radius > BIL_MAXR) return KF_ERR_ARG;
+  dim3 grid(kf_div_up(c->cols, BIL_TX), kf_div_up(c->rows, BIL_TY));
+  hipLaunchKernelGGL(k_bilateral, grid, dim3(256), 0, c->stream, c->trunced_depth, c->filtered_depth, c->cols, c->rows,
+                     ss_inv, sd_inv, sigma_depth, radius);
+  return (int)hipGetLastError();
+}
+
+extern "C" int kf_calculate_new_vertices(kf_ctx* c, const kf_camera_params* cam) {
+  if (!c || !cam || (int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
+  dim3 grid(kf_div_up(c->cols, 64), kf_div_up(c->rows, 4));
+  hipLaunchKernelGGL(k_depth_to_vertices, grid, dim3(256), 0, c->stream, c->filtered_depth, c->new_v[0], to_cam(cam));
+  return (int)hipGetLastError();
+}
+
+extern "C" int kf_calculate_new_normals(kf_ctx* c) {
+  if (!c) return KF_ERR_ARG;
+  dim3 grid(kf_div_up(c->cols, 64), kf_div_up(c->rows, 4));
+  hipLaunchKernelGGL(k_vertices_to_normals, grid, dim3(256), 0, c->stream, c->new_v[0], c->new_n[0], c->cols, c->rows);
+  return (int)hipGetLastError();
+}
+
+extern "C" int kf_preprocess(kf_ctx* c, float tmin, float tmax, float sigma_pixel, float sigma_depth, const kf_camera_params* cam) {
+  if (!c) return KF_ERR_ARG;
+  int st;
+  kf_evt_begin(c, KF_STAGE_PREPROCESS);
+  if ((st = kf_trunc_depth(c, tmin, tmax))) return st;
+  if ((st = kf_bilateral_filter_depth(c, sigma_pixel, sigma_depth))) return st;
+  if ((st = kf_calculate_new_vertices(c, cam))) return st;
+  st = kf_calculate_new_normals(c);
+  kf_evt_end(c, KF_STAGE_PREPROCESS);
+  return st;
+}
+
+extern "C" int kf_downsample_new_vertices(kf_ctx* c) { return c ? kf_launch_pyramids(c, false, true, false) : KF_ERR_ARG; }
+extern "C" int kf_downsample_new_normals(kf_ctx* c) { return c ? kf_launch_pyramids(c, false, false, true) : KF_ERR_ARG; }
+extern "C" int kf_downsample_model_vertices(kf_ctx* c) { return c ? kf_launch_pyramids(c, true, true, false) : KF_ERR_ARG; }
+extern "C" int kf_downsample_model_normals(kf_ctx* c) { return c ? kf_launch_pyramids(c, true, false, true) : KF_ERR_ARG; }

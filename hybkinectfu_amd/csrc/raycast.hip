@@ -1,0 +1,138 @@
+// raycast.hip -- surface prediction for the next frame's ICP (reference: raycastKernel / raySample / gradientForPoint /
+// getMinTime / getMaxTime, src/cuda/raycastingVolume.cu:16-176; tsdfvolume::getVoxel(world), interpolateSDF,
+// interpolateColor, src/cuda/tsdfVolume.h:81-172).
+//
+// gfx950 design (gather / latency bound):
+//   * one lane per pixel, a wave covers an 8x8 pixel patch so its 64 rays stay spatially coherent through the volume;
+//   * the reference gathers one 12-byte voxel per step (~106 dependent gathers per ray).  Here a step first reads the
+//     1-byte flag of the 8^3 brick it lands in (a 256 KiB table at 512^3: L2 resident).  A brick that never held a
+//     negative tsdf cannot contain the `sdf < 0` sample of a +/- crossing, so the voxel gather is skipped; the tsdf of
+//     the previous sample is fetched lazily only when a negative sample is actually met.  The parameter t is still
+//     advanced by the same repeated fp32 addition, so every sample position, the first crossing and all the
+//     interpolation inputs are bit-identical to the reference march;
+//   * bricks are 4 KiB contiguous, so the trilinear taps at the hit (2 + 6 lookups x 8 voxels) touch 1-2 bricks.
+#include "kf_internal.h"
+
+struct RaycastArgs {
+  KfVolume vol;
+  KfCam cam;
+  const float* pose;             // device pointer or null -> pose_val
+  KfMat pose_val;
+  float4* out_v; float4* out_n; uchar4* out_rgb;
+  float inc, near_plane, far_plane;
+  int has_color;
+};
+
+// gradientForPoint raycastingVolume.cu:16-42: bounds tested on the LAST sample's voxel, taps taken around the vertex
+__device__ __forceinline__ bool gradient_for_point(const KfVolume& v, float3 samplepos, float3 vtx, float3& grad) {
+  int3 g = kf_world_to_voxel(v, samplepos);
+  const int R = v.res;
+  if (g.x <= 1 || g.x >= R - 2) return false;
+  if (g.y <= 1 || g.y >= R - 2) return false;
+  if (g.z <= 1 || g.z >= R - 2) return false;
+  const float cell = v.cell;
+  float f1, f2; float3 n;
+  if (!kf_interpolate_sdf(v, kf3(vtx.x + cell, vtx.y, vtx.z), f1)) return false;
+  if (!kf_interpolate_sdf(v, kf3(vtx.x - cell, vtx.y, vtx.z), f2)) return false;
+  n.x = f1 - f2;
+  if (!kf_interpolate_sdf(v, kf3(vtx.x, vtx.y + cell, vtx.z), f1)) return false;
+  if (!kf_interpolate_sdf(v, kf3(vtx.x, vtx.y - cell, vtx.z), f2)) return false;
+  n.y = f1 - f2;
+  if (!kf_interpolate_sdf(v, kf3(vtx.x, vtx.y, vtx.z + cell), f1)) return false;
+  if (!kf_interpolate_sdf(v, kf3(vtx.x, vtx.y, vtx.z - cell), f2)) return false;
+  n.z = f1 - f2;
+  float len = kf_norm(n);
+  if ((double)len < 1e-8) return false;
+  grad = kf_scale(n, 1 / len);                               // fp32 reciprocal (:40), unlike normalize()
+  return true;
+}
+
+__global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
+  const KfVolume& v = a.vol;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7), y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  if (x >= a.cam.cols || y >= a.cam.rows) return;
+  const int pix = y * a.cam.cols + x;
+  float4 out_v = make_float4(0.f, 0.f, 0.f, 0.f), out_n = make_float4(0.f, 0.f, 0.f, 0.f);
+  uchar4 out_c = make_uchar4(0, 0, 0, 0);
+  const float* T = a.pose ? a.pose : a.pose_val.m;
+  // raycastKernel :136-150
+  const float3 cam_dir = kf_normalize(kf_depth_to_skeleton((unsigned)x, (unsigned)y, 1.0f, a.cam));
+  const float3 org = kf3(T[3], T[7], T[11]);
+  const float4 wd = kf_mat_vec(T, make_float4(cam_dir.x, cam_dir.y, cam_dir.z, 0.0f));
+  float3 dir = kf3(wd.x, wd.y, wd.z);
+  dir.x = (dir.x == 0.f) ? (float)1e-15 : dir.x;
+  dir.y = (dir.y == 0.f) ? (float)1e-15 : dir.y;
+  dir.z = (dir.z == 0.f) ? (float)1e-15 : dir.z;
+  const float S = v.size;
+  float tmin = fmaxf(fmaxf(((dir.x > 0 ? 0.f : S) - org.x) / dir.x, ((dir.y > 0 ? 0.f : S) - org.y) / dir.y), ((dir.z > 0 ? 0.f : S) - org.z) / dir.z);
+  float tmax = fminf(fminf(((dir.x > 0 ? S : 0.f) - org.x) / dir.x, ((dir.y > 0 ? S : 0.f) - org.y) / dir.y), ((dir.z > 0 ? S : 0.f) - org.z) / dir.z);
+  tmin = fmaxf(tmin, a.near_plane / cam_dir.z);
+  tmax = fminf(tmax, a.far_plane / cam_dir.z);
+  if (tmin < tmax) {
+    // raySample :65-119
+    const int R = v.res;
+    const float rf = (float)R;
+    const int zs0 = v.bz0 * KF_BRICK, zs1 = v.bz1 * KF_BRICK;
+    float t = tmin;
+    float last_sdf = 0.f; bool have_last = true;
+    float3 last_pos = kf3(0.f, 0.f, 0.f);
+    size_t last_idx = 0; bool last_stored = false;
+    while (t < tmax) {
+      const float3 pos = kf_add(org, kf_scale(dir, t));
+      // tsdfvolume::getVoxel(world) tsdfVolume.h:81-97: nearest voxel, index clamped
+      int gx = kf_to_int((double)(pos.x * rf / S)), gy = kf_to_int((double)(pos.y * rf / S)), gz = kf_to_int((double)(pos.z * rf / S));
+      gx = max(0, min(gx, R - 1)); gy = max(0, min(gy, R - 1)); gz = max(0, min(gz, R - 1));
+      const bool stored = gz >= zs0 && gz < zs1;
+      size_t slot = 0; unsigned flag = 0;
+      if (stored) { slot = kf_brick_slot(v, gx >> 3, gy >> 3, gz >> 3); flag = v.flags[slot]; }
+      const size_t idx = slot * KF_BRICK_VOX + (size_t)(((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7));
+      if (!(flag & KF_FLAG_HASNEG)) {
+        // tsdf >= 0 everywhere in this brick: not the negative side of a crossing; remember where we were
+        have_last = false; last_idx = idx; last_stored = stored; last_pos = pos;
+        t += a.inc;
+        continue;
+      }
+      const float sdf = v.tw[idx].x;
+      if (sdf < 0.0f) {
+        if (!have_last) { last_sdf = last_stored ? v.tw[last_idx].x : 0.f; have_last = true; }
+        if (last_sdf > 0.0f) {                                             // zero crossing :83
+          float ftdt, ft;
+          if (!kf_interpolate_sdf(v, pos, ftdt)) break;
+          if (!kf_interpolate_sdf(v, last_pos, ft)) break;
+          const float alpha = t - a.inc * ftdt / (ftdt - ft);
+          const float3 vtx = kf_add(org, kf_scale(dir, alpha));
+          if (a.has_color) { uchar4 c = make_uchar4(0, 0, 0, 0); kf_interpolate_color(v, vtx, c); out_c = c; }
+          float3 grad;
+          if (!gradient_for_point(v, last_pos, vtx, grad)) break;
+          out_v = make_float4(vtx.x, vtx.y, vtx.z, 1.0f);
+          out_n = make_float4(grad.x, grad.y, grad.z, 0.f);
+          break;
+        }
+      }
+      last_sdf = sdf; have_last = true; last_pos = pos; last_idx = idx; last_stored = stored;
+      t += a.inc;
+    }
+  }
+  a.out_v[pix] = out_v; a.out_n[pix] = out_n;
+  if (a.has_color) a.out_rgb[pix] = out_c;
+}
+
+extern "C" int kf_raycast_volume(kf_ctx* c, int has_color, const kf_mat44* transform, const kf_raycast_params* rp,
+                                 const kf_camera_params* cam, float near_plane, float far_plane) {
+  if (!c || !rp || !cam) return KF_ERR_ARG;
+  if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
+  if (has_color && (!c->vol.color || !c->raycast_rgb)) return KF_ERR_STATE;
+  RaycastArgs a;
+  a.vol = c->vol;
+  a.cam.cols = (int)cam->cols; a.cam.rows = (int)cam->rows; a.cam.cx = cam->cx; a.cam.cy = cam->cy; a.cam.fx = cam->fx; a.cam.fy = cam->fy;
+  if (transform) { for (int i = 0; i < 16; ++i) a.pose_val.m[i] = transform->m[i]; a.pose = nullptr; }
+  else a.pose = c->track->pose;
+  a.out_v = c->model_v[0]; a.out_n = c->model_n[0]; a.out_rgb = c->raycast_rgb;
+  a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
+  dim3 grid(kf_div_up(c->cols, 16), kf_div_up(c->rows, 16));
+  kf_evt_begin(c, KF_STAGE_RAYCAST);
+  hipLaunchKernelGGL(k_raycast, grid, dim3(256), 0, c->stream, a);
+  kf_evt_end(c, KF_STAGE_RAYCAST);
+  return (int)hipGetLastError();
+}

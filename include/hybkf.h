@@ -1,0 +1,175 @@
+/*
+ * hybkf.h -- C ABI of the MI355X-native KinectFusion core (libhybkf.so).
+ *
+ * This is the drop-in boundary for the reference's per-frame path: every entry point replaces one of
+ * the reference's `extern "C" void cuda*()` launch wrappers (src/cuda/CudaWrappers.h:22-36) or one of the
+ * direct accesses its host classes make to the CudaDeviceDataMan singleton (src/cuda/CudaDeviceDataMan.h:54-67).
+ * Differences from the reference boundary, all deliberate:
+ *   - state lives in an explicit, opaque `kf_ctx` (one per GPU / z-slab) instead of a process singleton;
+ *   - every call returns an int status (0 = ok) instead of void, and never throws;
+ *   - calls are asynchronous on the context's HIP stream; only the kf_read_ and kf_download_ calls and kf_synchronize block;
+ *   - the Gauss-Newton loops of CameraPoseFinderICP/SDF can run entirely on the device (kf_icp_track /
+ *     kf_sdf_track) so the 19 host round trips per frame of the reference (src/CameraPoseFinderICP.cpp:117)
+ *     disappear; the per-iteration wrappers are still exported for drop-in use and for parity tests.
+ * Plain pointers and sizes only; no C++ or torch types.  Paths cited are relative to /root/reference.
+ */
+#ifndef HYBKF_H_
+#define HYBKF_H_
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kf_ctx kf_ctx;
+
+/* src/AppParams.h:36-43 (24 bytes) */
+typedef struct kf_camera_params { uint32_t cols, rows; float cx, cy, fx, fy; } kf_camera_params;
+/* src/cuda/Mat.h:196-206: row-major 4x4, m[3], m[7], m[11] = translation, camera -> world */
+typedef struct kf_mat44 { float m[16]; } kf_mat44;
+/* src/AppParams.h:86-90 */
+typedef struct kf_integrate_params { float sdf_truncation; float max_integrate_dist; } kf_integrate_params;
+/* src/AppParams.h:59-62 */
+typedef struct kf_raycast_params { float ray_increment; } kf_raycast_params;
+/* src/AppParams.h:70-75 */
+typedef struct kf_volume_params { uint32_t resolution; float size_m; float max_weight; } kf_volume_params;
+/* src/AppParams.h:22-30 */
+typedef struct kf_icp_params { uint32_t pyramid_levels; float norm_sin_thres, dist_thres, dist_shake, angle_shake; } kf_icp_params;
+/* src/AppParams.h:31-35 */
+typedef struct kf_sdf_tracker_params { uint32_t max_iter_nums; float dist_shake, angle_shake; } kf_sdf_tracker_params;
+/* src/cuda/MarchingcubeData.h:15-27 (24 / 72 bytes) */
+typedef struct kf_vertex { float pos[3]; float color[3]; } kf_vertex;
+typedef struct kf_triangle { kf_vertex v0, v1, v2; } kf_triangle;
+
+/* What CudaDeviceDataMan::init() reads from AppParams (src/cuda/CudaDeviceDataMan.h:24-51), plus the z-slab. */
+typedef struct kf_config {
+  kf_camera_params depth_camera;
+  kf_camera_params rgb_camera;
+  kf_volume_params volume;        /* resolution must be a multiple of 8 */
+  uint32_t pyramid_levels;        /* 1..3 */
+  uint32_t max_triangles;
+  int32_t  has_color;             /* allocate the colour plane + rgb maps */
+  int32_t  device;                /* HIP device ordinal */
+  uint32_t slab_z_begin;          /* z range of voxel layers this context OWNS; 0 / resolution for one GPU */
+  uint32_t slab_z_end;
+  uint32_t slab_halo;             /* extra layers stored (and integrated) on each side, clipped to the volume */
+} kf_config;
+
+/* map ids for kf_download_map / kf_upload_map (members of CudaDeviceDataMan.h:56-67) */
+enum {
+  KF_MAP_RAW_DEPTH = 0, KF_MAP_TRUNCED_DEPTH = 1, KF_MAP_FILTERED_DEPTH = 2,   /* float,  cols*rows    */
+  KF_MAP_NEW_VERTICES = 3, KF_MAP_NEW_NORMALS = 4,                             /* float4, per level    */
+  KF_MAP_MODEL_VERTICES = 5, KF_MAP_MODEL_NORMALS = 6,                         /* float4, per level    */
+  KF_MAP_RAW_RGB = 7, KF_MAP_RAYCAST_RGB = 8                                   /* uchar3, cols*rows    */
+};
+
+/* status of the device-side tracker after kf_icp_track / kf_sdf_track */
+enum { KF_TRACK_OK = 0, KF_TRACK_LOST_DET = 1, KF_TRACK_LOST_SHAKE = 2 };
+
+typedef struct kf_track_result {
+  kf_mat44 pose;            /* CameraPoseFinder::_pose after the call (unchanged when lost) */
+  int32_t  tracked;         /* bool returned by findCameraPose */
+  int32_t  status;          /* KF_TRACK_* */
+  int32_t  iterations;      /* Gauss-Newton iterations actually applied */
+  int32_t  reserved;
+} kf_track_result;
+
+typedef struct kf_volume_stats {
+  uint64_t updated_last;    /* N_upd: voxels that passed the update predicate in the last integrate */
+  uint64_t weight_gt0;      /* voxels with weight > 0 (owned slab only) */
+  uint64_t bricks_active;   /* 8^3 bricks visited by the last integrate */
+  uint64_t bricks_total;
+  uint64_t updated_total;   /* running sum of updated_last since kf_reset_volume */
+  uint64_t frames_fused;    /* integrate calls that ran */
+  uint64_t frames_lost;     /* integrate calls skipped because the device-side tracker reported lost */
+} kf_volume_stats;
+
+const char* kf_error_string(int status);
+const char* kf_version(void);
+
+/* CudaDeviceDataMan::init  src/cuda/CudaDeviceDataMan.h:24-51 */
+int kf_create(const kf_config* cfg, kf_ctx** out);
+int kf_destroy(kf_ctx* ctx);
+int kf_synchronize(kf_ctx* ctx);
+void* kf_stream(kf_ctx* ctx);                        /* hipStream_t of the context */
+int kf_reset_volume(kf_ctx* ctx);                    /* tsdfvolume::init clearData  src/cuda/tsdfVolume.h:29-37 */
+
+/* HybKinectfu::copyFrameToGPU  src/HybKinectfu.cpp:63-96 : u16 mm -> f32 m ((float)((double)mm*0.001)) into raw_depth */
+int kf_upload_depth_mm(kf_ctx* ctx, const uint16_t* host_mm, uint32_t cols, uint32_t rows);
+int kf_set_depth_mm_device(kf_ctx* ctx, const uint16_t* dev_mm, uint32_t cols, uint32_t rows);   /* frame already in HBM */
+int kf_upload_rgb(kf_ctx* ctx, const uint8_t* host_bgr, uint32_t cols, uint32_t rows);
+
+/* cudaTruncDepth  src/cuda/DataPreprocesser.cu:80-88 */
+int kf_trunc_depth(kf_ctx* ctx, float trunc_min, float trunc_max);
+/* cudaBiliearFilterDepth  src/cuda/DataPreprocesser.cu:89-100 */
+int kf_bilateral_filter_depth(kf_ctx* ctx, float sigma_pixel, float sigma_depth);
+/* cudaCalculateNewVertices / cudaCalculateNewNormals  src/cuda/VerticesNormalsCalculater.cu:67-85 */
+int kf_calculate_new_vertices(kf_ctx* ctx, const kf_camera_params* depth_camera);
+int kf_calculate_new_normals(kf_ctx* ctx);
+/* the four above fused (what HybKinectfu::processNewFrame runs, src/HybKinectfu.cpp:106-110) */
+int kf_preprocess(kf_ctx* ctx, float trunc_min, float trunc_max, float sigma_pixel, float sigma_depth,
+                  const kf_camera_params* depth_camera);
+
+/* cudaDownSample{New,Model}{Vertices,Normals}  src/cuda/sample.cu:63-112 */
+int kf_downsample_new_vertices(kf_ctx* ctx);
+int kf_downsample_new_normals(kf_ctx* ctx);
+int kf_downsample_model_vertices(kf_ctx* ctx);
+int kf_downsample_model_normals(kf_ctx* ctx);
+
+/* cudaCalPointToPlaneErrSolverParams  src/cuda/CalPointToPlaneErrSolverParams.cu:110-129 -> rigid_align_buf_reduced */
+int kf_cal_point_to_plane_solver_params(kf_ctx* ctx, uint32_t pyramid_level, const kf_mat44* cur_transform,
+                                        const kf_mat44* last_transform_inv, const kf_camera_params* cam,
+                                        float dist_thres, float norm_sin_thres);
+/* cudaCalSDFSolverParams  src/cuda/CalSDFErrSolverParams.cu:110-138 */
+int kf_cal_sdf_solver_params(kf_ctx* ctx, const kf_camera_params* cam, const kf_mat44* cur_transform);
+/* rigid_align_buf_reduced.clone(CPU)  src/CameraPoseFinderICP.cpp:117 : blocking 27-float read-back */
+int kf_read_solver_params(kf_ctx* ctx, float out27[27]);
+
+/* Device-resident pose + whole Gauss-Newton loops.
+ * kf_set_pose: CameraPoseFinder::init / setCameraPose (src/CameraPoseFinder.h:22-36).
+ * kf_icp_track: CameraPoseFinderICP::estimateCameraPose (src/CameraPoseFinderICP.cpp:50-94) incl. the four pyramid builds.
+ * kf_sdf_track: CameraPoseFinderSDF::estimateCameraPose (src/CameraPoseFinderSDF.cpp:44-106).
+ * frame_id == 0 returns "tracked" without touching the pose, as the reference does.  Asynchronous. */
+int kf_set_pose(kf_ctx* ctx, const kf_mat44* pose);
+int kf_icp_track(kf_ctx* ctx, uint32_t frame_id, const kf_icp_params* icp, const kf_camera_params* depth_camera);
+int kf_sdf_track(kf_ctx* ctx, uint32_t frame_id, const kf_sdf_tracker_params* sdf, const kf_camera_params* depth_camera);
+int kf_read_track_result(kf_ctx* ctx, kf_track_result* out);          /* blocking */
+
+/* cudaIntegrateVolume  src/cuda/integrateVolume.cu:78-96.  transform == NULL: use the device-resident pose and
+ * integrate only if the last kf_*_track call tracked (src/HybKinectfu.cpp:123-140). */
+int kf_integrate_volume(kf_ctx* ctx, int has_color, int use_angle_weight_color, const kf_mat44* transform,
+                        const kf_integrate_params* integrate_params, const kf_camera_params* depth_camera,
+                        const kf_camera_params* rgb_camera);
+/* cudaRaycastingVolume  src/cuda/raycastingVolume.cu:158-176.  transform == NULL: device-resident pose. */
+int kf_raycast_volume(kf_ctx* ctx, int has_color, const kf_mat44* transform, const kf_raycast_params* raycast_params,
+                      const kf_camera_params* depth_camera, float near_plane, float far_plane);
+
+/* cudaMarchingcube  src/cuda/marchingcube.cu:154-164.  Triangles are appended after those already stored
+ * (the reference never clears its counter, src/cuda/MarchingcubeData.h:56,99) in the canonical order (z, y, x, k). */
+int kf_marching_cubes(kf_ctx* ctx, int has_color, float threshold_marchingcube);
+int kf_clear_triangles(kf_ctx* ctx);                                   /* MarchingcubeData::clearData */
+int kf_triangle_count(kf_ctx* ctx, uint32_t* count);                   /* MarchingcubeData::triangleNums, blocking */
+int kf_read_triangles(kf_ctx* ctx, kf_triangle* dst, uint32_t first, uint32_t count);   /* MarchingcubeData::clone(CPU) */
+
+/* CudaMap2D::clone(CPU) / copyDataFrom on the singleton's maps (debug + parity; blocking) */
+int kf_download_map(kf_ctx* ctx, int map_id, uint32_t level, void* dst, size_t dst_bytes);
+int kf_upload_map(kf_ctx* ctx, int map_id, uint32_t level, const void* src, size_t src_bytes);
+/* volume in the reference's index order (z*R+y)*R+x for stored layers [z_begin, z_end): tsdf, weight (float) and
+ * colour (3 bytes/voxel, may be NULL).  Blocking. */
+int kf_download_volume(kf_ctx* ctx, uint32_t z_begin, uint32_t z_end, float* tsdf, float* weight, uint8_t* color);
+int kf_upload_volume(kf_ctx* ctx, uint32_t z_begin, uint32_t z_end, const float* tsdf, const float* weight, const uint8_t* color);
+int kf_get_volume_stats(kf_ctx* ctx, kf_volume_stats* out);                /* blocking */
+int kf_stored_z_range(kf_ctx* ctx, uint32_t* z_begin, uint32_t* z_end);
+
+/* Per-stage device timers (hipEvent pairs on the context's stream).  `stage_mask` bit s enables stage s:
+ * 0 depth upload/convert, 1 preprocess, 2 track, 3 integrate (all passes), 4 raycast, 5 integrate fusion kernel only,
+ * 6 marching cubes, 7 raycast kernel only.  kf_stage_timers resets the accumulators; kf_read_stage_ms blocks and returns
+ * accumulated milliseconds and the number of timed intervals per stage. */
+int kf_stage_timers(kf_ctx* ctx, int stage_mask);
+int kf_read_stage_ms(kf_ctx* ctx, float out_ms[8], uint32_t counts[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYBKF_H_ */

@@ -1,0 +1,276 @@
+"""GPU parity: every HIP stage, called through the C ABI (libhybkf.so), against the CPU oracle on identical inputs.
+
+Bit-exact: depth conversion, gate, vertices, normals, pyramids, TSDF planes + update counts, raycast maps, marching-cubes
+triangle sequence.  Tolerance (stated per test): bilateral (device __expf), the 27 fp32 ICP/SDF sums, tracked poses.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from hybkinectfu_amd import lib as K
+from hybkinectfu_amd import scene as S
+
+pytestmark = pytest.mark.gpu
+
+P = S.STOCK
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def small_cam():
+    return (64, 48, 31.5, 23.5, 52.5, 52.5)
+
+
+def mid_cam():
+    return (160, 120, 79.5, 59.5, 131.25, 131.25)
+
+
+def oracle_preprocess(mm, ocam):
+    d = O.depth_mm_to_m(mm)
+    tr = O.trunc_depth(d, P["depth_trunc_min"], P["depth_trunc_max"])
+    fl = O.bilateral(tr, P["filter_sigma_pixel"], P["filter_sigma_depth"])
+    v = O.depth_to_vertices(fl, ocam)
+    n = O.vertices_to_normals(v)
+    return d, tr, fl, v, n
+
+
+@pytest.mark.parametrize("cam", [small_cam(), mid_cam(), S.vga_camera()])
+def test_preprocess_chain(cam):
+    size = 3.0
+    ocam, kcam = O.Cam.make(*cam), K.camera(*cam)
+    mm = S.render_depth_mm(S.trajectory_pose(7, size), cam, size)
+    mm[5:9, 10:20] = 0            # holes
+    mm[20, :] = 60000             # beyond trunc_max
+    d, tr, fl, v, n = oracle_preprocess(mm, ocam)
+    ctx = K.Context(kcam, 32, size, levels=3)
+    ctx.upload_depth_mm(mm)
+    ctx.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+    assert np.array_equal(bits(ctx.download_map(K.MAP_RAW_DEPTH)), bits(d))
+    assert np.array_equal(bits(ctx.download_map(K.MAP_TRUNCED_DEPTH)), bits(tr))
+    g_fl = ctx.download_map(K.MAP_FILTERED_DEPTH)
+    # device __expf vs libm expf: a few ulp on the weights -> 2e-6 relative on the filtered depth
+    assert np.allclose(g_fl, fl, rtol=2e-6, atol=0)
+    assert np.array_equal(g_fl == 0, fl == 0)
+    # vertices / normals are exact functions of the filtered depth: feed the oracle the device's own filtered map
+    v2 = O.depth_to_vertices(g_fl, ocam)
+    n2 = O.vertices_to_normals(v2)
+    assert np.array_equal(bits(ctx.download_map(K.MAP_NEW_VERTICES)), bits(v2))
+    assert np.array_equal(bits(ctx.download_map(K.MAP_NEW_NORMALS)), bits(n2))
+    # pyramids (new maps), levels 1 and 2
+    ctx.downsample(model=False)
+    for lvl, (ov, on) in enumerate(zip(O.pyramid(v2, 3), O.pyramid(n2, 3, normals=True))):
+        assert np.array_equal(bits(ctx.download_map(K.MAP_NEW_VERTICES, lvl)), bits(ov))
+        assert np.array_equal(bits(ctx.download_map(K.MAP_NEW_NORMALS, lvl)), bits(on))
+    ctx.close()
+
+
+def test_empty_and_invalid_depth():
+    cam = small_cam()
+    ocam, kcam = O.Cam.make(*cam), K.camera(*cam)
+    ctx = K.Context(kcam, 32, 3.0, levels=3)
+    mm = np.zeros((48, 64), np.uint16)
+    ctx.upload_depth_mm(mm)
+    ctx.preprocess(0.3, 4.0, 2.0, 0.03)
+    assert not ctx.download_map(K.MAP_NEW_VERTICES).any() and not ctx.download_map(K.MAP_NEW_NORMALS).any()
+    ctx.integrate(S.pose0(3.0), 0.1, 2.0)
+    assert ctx.stats()["updated_last"] == 0 and ctx.stats()["weight_gt0"] == 0
+    ctx.raycast(S.pose0(3.0), 0.07, 0.3, 4.0)
+    assert not ctx.download_map(K.MAP_MODEL_VERTICES).any()
+    ctx.close()
+
+
+def _fuse_sequence(res, size, cam, n_frames, sdf_trunc, max_dist, color=False):
+    """Integrate n_frames of Scene S with ground-truth poses on both sides; returns (ctx, ovol, last pose, maps)."""
+    ocam, kcam = O.Cam.make(*cam), K.camera(*cam)
+    ovol = O.OVolume(res, size, P["volume_max_weight"])
+    ctx = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=400000, has_color=color)
+    rng = np.random.default_rng(5)
+    pose = None
+    for k in range(n_frames):
+        pose = S.trajectory_pose(3 * k, size).astype(np.float32)
+        mm = S.render_depth_mm(pose, cam, size)
+        d, tr, fl, v, n = oracle_preprocess(mm, ocam)
+        rgb = rng.integers(0, 256, (cam[1], cam[0], 3)).astype(np.uint8) if color else None
+        n_o = O.integrate(ovol, tr, n, rgb, color, color, pose, sdf_trunc, max_dist, ocam, ocam)
+        ctx.upload_depth_mm(mm)
+        ctx.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+        if color:
+            ctx.upload_rgb(rgb)
+            ctx.upload_map(K.MAP_NEW_NORMALS, 0, n)      # colour weights read normal.z: use the oracle's normals exactly
+        ctx.integrate(pose, sdf_trunc, max_dist, has_color=color, angle_weight=color)
+        st = ctx.stats()
+        assert st["updated_last"] == n_o, (k, st, n_o)
+        assert st["weight_gt0"] == O.count_weight_gt0(ovol)
+    return ctx, ovol, pose, ocam
+
+
+@pytest.mark.parametrize("res,size,cam,trunc", [(32, 3.0, small_cam(), 0.2), (64, 3.0, mid_cam(), 0.1), (128, 3.0, S.vga_camera(), 0.05)])
+def test_integrate_raycast_mc_bit_exact(res, size, cam, trunc):
+    ctx, ovol, pose, ocam = _fuse_sequence(res, size, cam, 3, trunc, 2.5)
+    t, w = ctx.download_volume()
+    assert np.array_equal(bits(t), bits(ovol.tsdf)) and np.array_equal(bits(w), bits(ovol.weight))
+    inc = 0.7 * trunc
+    ov, on, _ = O.raycast(ovol, False, pose, inc, ocam, P["depth_trunc_min"], P["depth_trunc_max"])
+    ctx.raycast(pose, inc, P["depth_trunc_min"], P["depth_trunc_max"])
+    gv, gn = ctx.download_map(K.MAP_MODEL_VERTICES), ctx.download_map(K.MAP_MODEL_NORMALS)
+    assert int((ov[..., 3] != 0).sum()) > 100                      # the case exercises real hits
+    assert np.array_equal(bits(gv), bits(ov)) and np.array_equal(bits(gn), bits(on))
+    # model pyramids from the raycast maps
+    ctx.downsample(model=True)
+    for lvl, (pv, pn) in enumerate(zip(O.pyramid(ov, 3), O.pyramid(on, 3, normals=True))):
+        assert np.array_equal(bits(ctx.download_map(K.MAP_MODEL_VERTICES, lvl)), bits(pv))
+        assert np.array_equal(bits(ctx.download_map(K.MAP_MODEL_NORMALS, lvl)), bits(pn))
+    thr = 300 * size / res
+    otris = O.marching_cubes(ovol, False, thr, 400000)
+    ctx.marching_cubes(thr)
+    gtris = ctx.triangles()
+    assert len(otris) > 50 and len(gtris) == len(otris)
+    assert np.array_equal(gtris["v"]["pos"].view(np.uint32), otris["v"]["pos"].view(np.uint32))   # same sequence, (z,y,x,k) order
+    # appending: a second extraction lands after the first (MarchingcubeData never clears its counter)
+    ctx.marching_cubes(thr)
+    assert len(ctx.triangles()) == 2 * len(otris)
+    ctx.clear_triangles()
+    assert len(ctx.triangles()) == 0
+    ctx.close()
+
+
+def test_triangle_cap():
+    ctx, ovol, pose, ocam = _fuse_sequence(32, 3.0, small_cam(), 2, 0.2, 2.5)
+    thr = 300 * 3.0 / 32
+    full = O.marching_cubes(ovol, False, thr, 400000)
+    cap = len(full) // 2
+    ctx2 = K.Context(K.camera(*small_cam()), 32, 3.0, P["volume_max_weight"], levels=3, max_triangles=cap)
+    t, w = ctx.download_volume()
+    ctx2.upload_volume(t, w)
+    ctx2.marching_cubes(thr)
+    g = ctx2.triangles()
+    assert len(g) == cap and np.array_equal(g["v"]["pos"].view(np.uint32), full[:cap]["v"]["pos"].view(np.uint32))
+    ctx.close(); ctx2.close()
+
+
+def test_integrate_color_bit_exact():
+    ctx, ovol, pose, ocam = _fuse_sequence(32, 3.0, small_cam(), 3, 0.2, 2.5, color=True)
+    t, w, c = ctx.download_volume(color=True)
+    assert np.array_equal(bits(t), bits(ovol.tsdf)) and np.array_equal(bits(w), bits(ovol.weight))
+    seen = ovol.weight > 0
+    assert np.array_equal(c[seen], ovol.color[seen])
+    ov, on, orgb = O.raycast(ovol, True, pose, 0.14, ocam, 0.3, 4.0)
+    ctx.raycast(pose, 0.14, 0.3, 4.0, has_color=True)
+    assert np.array_equal(bits(ctx.download_map(K.MAP_MODEL_VERTICES)), bits(ov))
+    assert np.array_equal(ctx.download_map(K.MAP_RAYCAST_RGB), orgb)
+    thr = 300 * 3.0 / 32
+    otris = O.marching_cubes(ovol, True, thr, 400000)
+    ctx.marching_cubes(thr, has_color=True)
+    g = ctx.triangles()
+    assert len(g) == len(otris) and np.array_equal(g.view(np.uint32), otris.view(np.uint32))
+    ctx.close()
+
+
+def _tracking_case(res, size, cam, trunc, n_warm=2):
+    """Fuse a few frames, raycast from the last pose, then present the NEXT frame: returns everything ICP needs."""
+    ctx, ovol, pose, ocam = _fuse_sequence(res, size, cam, n_warm, trunc, 2.5)
+    inc = 0.7 * trunc
+    ov, on, _ = O.raycast(ovol, False, pose, inc, ocam, P["depth_trunc_min"], P["depth_trunc_max"])
+    ctx.raycast(pose, inc, P["depth_trunc_min"], P["depth_trunc_max"])
+    nxt = S.trajectory_pose(3 * n_warm, size).astype(np.float32)
+    mm = S.render_depth_mm(nxt, cam, size)
+    d, tr, fl, v, n = oracle_preprocess(mm, ocam)
+    ctx.upload_depth_mm(mm)
+    ctx.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+    # make the inputs of the tracker identical on both sides (bilateral differs in the last ulps)
+    ctx.upload_map(K.MAP_NEW_VERTICES, 0, v)
+    ctx.upload_map(K.MAP_NEW_NORMALS, 0, n)
+    return ctx, ovol, pose, nxt, ocam, (v, n, ov, on, tr)
+
+
+@pytest.mark.parametrize("res,cam,trunc", [(64, mid_cam(), 0.1), (128, S.vga_camera(), 0.05)])
+def test_icp_system_and_track(res, cam, trunc):
+    size = 3.0
+    ctx, ovol, pose, nxt, ocam, (v, n, ov, on, tr) = _tracking_case(res, size, cam, trunc)
+    nv, nn = O.pyramid(v, 3), O.pyramid(n, 3, normals=True)
+    mv, mn = O.pyramid(ov, 3), O.pyramid(on, 3, normals=True)
+    ctx.downsample(model=False); ctx.downsample(model=True)
+    last_inv = O.mat44_inverse(pose)
+    ocams = [ocam, ocam.half(), ocam.half().half()]
+    kcams = [ctx.cam, K.half_camera(ctx.cam), K.half_camera(K.half_camera(ctx.cam))]
+    for lvl in range(3):
+        sd, sf, valid = O.icp_system(nv[lvl], nn[lvl], mv[lvl], mn[lvl], ocams[lvl], pose, last_inv, P["icp_thre_dist"], P["icp_thre_sin_angle"])
+        g = ctx.icp_system(lvl, pose, last_inv, kcams[lvl], P["icp_thre_dist"], P["icp_thre_sin_angle"])
+        assert valid > 50
+        # fp32 sums in a different association than the double ground truth: 1e-5 of the largest entry
+        assert np.max(np.abs(g - sd)) <= 1e-5 * np.max(np.abs(sd)), (lvl, g, sd)
+    ok_o, pose_o = O.icp_estimate(nv, nn, mv, mn, ocam, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"], pose)
+    ctx.set_pose(pose)
+    ctx.icp_track(1, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+    ok_g, pose_g, status, iters = ctx.track_result()
+    assert ok_o and ok_g and status == 0 and iters == 19
+    # north-star tolerance: 1e-4 m / 1e-4 rad
+    assert np.max(np.abs(pose_g[:3, 3] - pose_o[:3, 3])) < 1e-4
+    assert np.max(np.abs(pose_g[:3, :3] - pose_o[:3, :3])) < 1e-4
+    # and the estimate moved towards the true pose of the new frame
+    assert np.linalg.norm(pose_g[:3, 3] - nxt[:3, 3]) < np.linalg.norm(pose[:3, 3] - nxt[:3, 3]) + 1e-3
+    # frame 0 never tracks and never changes the pose
+    ctx.set_pose(pose)
+    ctx.icp_track(0, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+    ok0, pose0, _, it0 = ctx.track_result()
+    assert ok0 and it0 == 0 and np.array_equal(pose0, pose)
+    ctx.close()
+
+
+def test_icp_lost_keeps_pose():
+    """Shake threshold 0 -> the first step is rejected: findCameraPose false, pose unchanged, integrate skipped."""
+    ctx, ovol, pose, nxt, ocam, maps = _tracking_case(64, 3.0, mid_cam(), 0.1)
+    ctx.set_pose(pose)
+    before = ctx.stats()["weight_gt0"]
+    ctx.icp_track(1, P["icp_thre_dist"], P["icp_thre_sin_angle"], 0.0, 0.0)
+    ok, pose_g, status, iters = ctx.track_result()
+    assert not ok and status == 2 and iters == 0 and np.array_equal(pose_g, pose)
+    ctx.integrate(None, 0.1, 2.5)                   # device-resident pose path: skipped because tracking failed
+    st = ctx.stats()
+    assert st["updated_last"] == 0 and st["weight_gt0"] == before
+    ctx.close()
+
+
+def test_sdf_system_and_track():
+    size, res, cam, trunc = 3.0, 64, mid_cam(), 0.15
+    ctx, ovol, pose, nxt, ocam, (v, n, ov, on, tr) = _tracking_case(res, size, cam, trunc, n_warm=3)
+    sd, sf, valid = O.sdf_system(ovol, tr, ocam, pose)
+    g = ctx.sdf_system(pose)
+    assert valid > 200
+    assert np.max(np.abs(g - sd)) <= 1e-5 * np.max(np.abs(sd)), (g, sd)
+    ok_o, pose_o, it_o = O.sdf_estimate(ovol, tr, ocam, P["sdf_max_iter_nums"], P["camera_shake_dist"], P["camera_shake_angle"], pose)
+    ctx.set_pose(pose)
+    ctx.sdf_track(1, P["sdf_max_iter_nums"], P["camera_shake_dist"], P["camera_shake_angle"])
+    ok_g, pose_g, status, iters = ctx.track_result()
+    assert ok_o == ok_g
+    if ok_o:
+        assert iters == it_o
+        assert np.max(np.abs(pose_g - pose_o)) < 1e-4
+    ctx.close()
+
+
+def test_full_size_integrate_counts_512():
+    """BASELINE config C2 geometry (512^3 @ 4 m, VGA): update count and observed-voxel count equal the oracle's;
+    linearity property: integrating the same frame twice doubles no count but saturates weights identically."""
+    size, res, cam = 4.0, 512, S.vga_camera()
+    ocam, kcam = O.Cam.make(*cam), K.camera(*cam)
+    ctx = K.Context(kcam, res, size, P["volume_max_weight"], levels=3)
+    ovol = O.OVolume(res, size, P["volume_max_weight"])
+    for k in (0, 5):
+        pose = S.trajectory_pose(k, size).astype(np.float32)
+        mm = S.render_depth_mm(pose, cam, size)
+        d, tr, fl, v, n = oracle_preprocess(mm, ocam)
+        n_o = O.integrate(ovol, tr, n, None, False, False, pose, P["integrate_sdf_trunc"], P["integrate_depth_trunc"], ocam, ocam)
+        ctx.upload_depth_mm(mm)
+        ctx.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+        ctx.integrate(pose, P["integrate_sdf_trunc"], P["integrate_depth_trunc"])
+        st = ctx.stats()
+        assert st["updated_last"] == n_o and n_o > 1000000
+        assert st["weight_gt0"] == O.count_weight_gt0(ovol)
+        assert st["bricks_active"] < st["bricks_total"] // 4          # the cull pass really skips most of the volume
+    # checksum of the planes over the slab the camera sees
+    t, w = ctx.download_volume(0, 256)
+    assert np.array_equal(bits(t), bits(ovol.tsdf[:256])) and np.array_equal(bits(w), bits(ovol.weight[:256]))
+    ctx.close()
