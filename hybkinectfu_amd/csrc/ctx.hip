@@ -30,7 +30,7 @@ extern "C" int kf_destroy(kf_ctx* c) {
   hipSetDevice(c->cfg.device);
   if (c->stream) hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->depth_mm, c->raw_depth, c->trunced_depth, c->filtered_depth, c->raw_rgb, c->raycast_rgb, c->icp_partials,
-                  c->track, c->counters, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->active_bricks,
+                  c->track, c->counters, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macro, c->active_bricks,
                   c->tile_max_depth, c->triangles, c->mc_block_counts};
   for (void* p : ptrs) if (p) hipFree(p);
   for (int l = 0; l < KF_MAX_LEVELS; ++l) {
@@ -82,7 +82,7 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
     TRY((int)hipMemsetAsync(c->new_n[l], 0, n * sizeof(float4), c->stream));
     lc >>= 1; lr >>= 1;
   }
-  TRY(dev_alloc(&c->icp_partials, (size_t)KF_ICP_MAX_WG * 32));
+  TRY(dev_alloc(&c->icp_partials, (size_t)2 * KF_ICP_MAX_WG * 32));      // double-buffered by Gauss-Newton step parity
   TRY(dev_alloc(&c->track, 1)); TRY(dev_alloc(&c->counters, 1)); TRY(dev_alloc(&c->scratch_mats, 8 * 16));
   TRY((int)hipMemsetAsync(c->track, 0, sizeof(KfTrackState), c->stream));
   TRY((int)hipMemsetAsync(c->counters, 0, sizeof(KfCounters), c->stream));
@@ -99,7 +99,9 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
   c->n_stored_vox = c->n_stored_bricks * KF_BRICK_VOX;
   TRY(dev_alloc(&v.tw, c->n_stored_vox));
   if (cfg->has_color) TRY(dev_alloc(&v.color, c->n_stored_vox));
-  TRY(dev_alloc(&v.flags, c->n_stored_bricks));
+  TRY(dev_alloc(&v.flags, c->n_stored_bricks + 4));      // updated with 32-bit atomics: keep the last word whole
+  v.nm = (v.res + KF_MACRO - 1) / KF_MACRO;
+  TRY(dev_alloc(&v.macro, (size_t)v.nm * v.nm * v.nm));
   TRY(dev_alloc(&c->active_bricks, c->n_stored_bricks));
   TRY(dev_alloc(&c->tile_max_depth, (size_t)kf_div_up(c->cols, 16) * kf_div_up(c->rows, 16)));
   c->max_triangles = cfg->max_triangles;
@@ -120,6 +122,7 @@ extern "C" int kf_reset_volume(kf_ctx* c) {
   KF_CHECK(hipMemsetAsync(c->vol.tw, 0, c->n_stored_vox * sizeof(float2), c->stream));
   if (c->vol.color) KF_CHECK(hipMemsetAsync(c->vol.color, 0, c->n_stored_vox * sizeof(uchar4), c->stream));
   KF_CHECK(hipMemsetAsync(c->vol.flags, 0, c->n_stored_bricks, c->stream));
+  KF_CHECK(hipMemsetAsync(c->vol.macro, 0, (size_t)c->vol.nm * c->vol.nm * c->vol.nm, c->stream));
   KF_CHECK(hipMemsetAsync(c->counters, 0, sizeof(KfCounters), c->stream));
   return 0;
 }
@@ -277,7 +280,13 @@ __global__ void __launch_bounds__(256) k_rebuild_flags(KfVolume v, size_t n_bric
     }
     if (f) atomicOr(&s_flag, f);
     __syncthreads();
-    if (threadIdx.x == 0) v.flags[b] = (uint8_t)s_flag;
+    if (threadIdx.x == 0) {
+      v.flags[b] = (uint8_t)s_flag;
+      if (s_flag & KF_FLAG_HASNEG) {
+        const int bx = (int)(b % v.nb), by = (int)((b / v.nb) % v.nb), bz = (int)(b / ((size_t)v.nb * v.nb)) + v.bz0;
+        v.macro[((size_t)(bz >> 2) * v.nm + (by >> 2)) * v.nm + (bx >> 2)] = 1;
+      }
+    }
     __syncthreads();
   }
 }
@@ -340,9 +349,11 @@ extern "C" int kf_get_volume_stats(kf_ctx* c, kf_volume_stats* out) {
   KfCounters h;
   KF_CHECK(hipMemcpyAsync(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   KF_CHECK(hipStreamSynchronize(c->stream));
-  out->updated_last = h.n_upd; out->weight_gt0 = h.weight_gt0;
+  unsigned long long last = 0, total = 0;
+  for (int i = 0; i < 64; ++i) { last += h.upd_shard[i * 16]; total += h.upd_total_shard[i]; }
+  out->updated_last = last; out->weight_gt0 = h.weight_gt0;
   out->bricks_active = h.n_active_bricks; out->bricks_total = c->n_stored_bricks;
-  out->updated_total = h.n_upd_total; out->frames_fused = h.frames_fused; out->frames_lost = h.frames_lost;
+  out->updated_total = total + last; out->frames_fused = h.frames_fused; out->frames_lost = h.frames_lost;
   return 0;
 }
 

@@ -44,11 +44,15 @@ __global__ void __launch_bounds__(256) k_integrate_prepare(IntegrateArgs a) {
   for (int off = 32; off > 0; off >>= 1) d = fmaxf(d, __shfl_down(d, off, 64));
   if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = d;
   __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < 64) {                // fold the previous frame's sharded update count, then clear it
+    a.cnt->upd_total_shard[threadIdx.x] += a.cnt->upd_shard[threadIdx.x * 16];
+    a.cnt->upd_shard[threadIdx.x * 16] = 0ull;
+  }
   if (threadIdx.x == 0) {
     a.tile_max[blockIdx.x] = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
     if (blockIdx.x == 0) {
       kf_mat44_inverse(a.pose ? a.pose : a.pose_val.m, a.tinv);   // integrateVolume.cu:84
-      a.cnt->n_upd = 0ull; a.cnt->n_active_bricks = 0u;
+      a.cnt->n_active_bricks = 0u;
     }
   }
 }
@@ -110,8 +114,10 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
   const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8], m9 = m[9], m10 = m[10], m11 = m[11];
   const float cell = v.cell;
   const int lx = (threadIdx.x & 3) * 2, ly = (threadIdx.x >> 2) & 7, lz = threadIdx.x >> 5;
-  __shared__ unsigned s_flags;
-  unsigned long long upd_total = 0;
+  __shared__ unsigned s_upd;
+  unsigned upd_total = 0;
+  if (threadIdx.x == 0) s_upd = 0;
+  __syncthreads();
   for (unsigned qi = blockIdx.x; qi < n_active; qi += gridDim.x) {
     const unsigned slot = a.queue[qi];
     const int bx = (int)(slot % v.nb), by = (int)((slot / v.nb) % v.nb), bz = (int)(slot / ((unsigned)v.nb * v.nb)) + v.bz0;
@@ -119,63 +125,80 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
     // tsdfVolume.h:38-49 voxel centre; Mat.h:230-238 row*vector summed left to right; the (x,y) part is shared by the pair
     const float wy = ((float)y + 0.5f) * cell, wz = ((float)z + 0.5f) * cell;
     float4* p = reinterpret_cast<float4*>(v.tw + (size_t)slot * KF_BRICK_VOX) + threadIdx.x;
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool loaded = false;
     unsigned flags = 0, n_upd = 0;
+    // Phase A for both voxels of the pair: project and issue the depth gathers back to back (one memory round trip, not two)
+    float pfx[2], pfy[2], pfz[2], d[2]; int pix[2]; bool ok[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int x = bx * 8 + lx + k;
       const float wx = ((float)x + 0.5f) * cell;
-      const float pfx = m0 * wx + m1 * wy + m2 * wz + m3 * 1.0f;
-      const float pfy = m4 * wx + m5 * wy + m6 * wz + m7 * 1.0f;
-      const float pfz = m8 * wx + m9 * wy + m10 * wz + m11 * 1.0f;
-      if (pfz <= 0.f) continue;                                                             // :39
-      int2 sp = kf_project(kf3(pfx, pfy, pfz), a.dcam);
-      if (sp.x >= a.dcam.cols - 1 || sp.y >= a.dcam.rows - 1 || sp.x < 1 || sp.y < 1) continue;   // :43
-      const float d = a.depth[sp.y * a.dcam.cols + sp.x];
-      if (d == 0.f) continue;                                                               // :50
-      uchar4 col = make_uchar4(0, 0, 0, 0);
-      float normalz = 0.f;
-      if (HAS_COLOR) {
-        normalz = a.normals[sp.y * a.dcam.cols + sp.x].z;
-        int cxp = kf_to_int((double)(pfx * 525 / pfz + 320)), cyp = kf_to_int((double)(pfy * 525 / pfz + 240));   // :56-57
-        if (cxp >= a.rcam.cols - 1 || cyp >= a.rcam.rows - 1 || cxp < 1 || cyp < 1) continue;
-        col = a.rgb[(size_t)cyp * a.rcam.cols + cxp];
-      }
-      if (!(d < a.max_dist)) continue;                                                      // :64
-      const float sdf = d - pfz;
-      if (!(sdf > -a.sdf_trunc)) continue;                                                  // :67
-      const float tsdf = fminf(1.0f, sdf / a.sdf_trunc);
-      if (!loaded) { q = *p; loaded = true; }
-      float ot = k ? q.z : q.x, ow = k ? q.w : q.y;
-      const float nw = fminf(ow + 1.f, v.max_weight);                                       // tsdfVolume.h:65
-      const float nt = (ot * ow + tsdf * 1.f) / (ow + 1.f);                                 // tsdfVolume.h:66
-      if (k) { q.z = nt; q.w = nw; } else { q.x = nt; q.y = nw; }
-      if (HAS_COLOR) {
-        // :72 `(color_angled?fminf(1.0,abs(normalz)/0.75):1.0)*2.0` -- the division and the doubling run in double
-        const float wc = a.color_angled ? (float)((double)fminf(1.0f, (float)((double)fabsf(normalz) / 0.75)) * 2.0) : 2.0f;
-        uchar4* cp = v.color + (size_t)slot * KF_BRICK_VOX + threadIdx.x * 2 + k;
-        uchar4 oc = *cp;
-        float c0 = fminf(255.0f, ((float)oc.x * ow + (float)col.x * wc) / (ow + wc));       // tsdfVolume.h:68-70
-        float c1 = fminf(255.0f, ((float)oc.y * ow + (float)col.y * wc) / (ow + wc));
-        float c2 = fminf(255.0f, ((float)oc.z * ow + (float)col.z * wc) / (ow + wc));
-        *cp = make_uchar4((unsigned char)c0, (unsigned char)c1, (unsigned char)c2, 0);
-      }
-      ++n_upd;
-      flags |= KF_FLAG_OBSERVED | (nt < 0.f ? KF_FLAG_HASNEG : 0u);
+      pfx[k] = m0 * wx + m1 * wy + m2 * wz + m3 * 1.0f;
+      pfy[k] = m4 * wx + m5 * wy + m6 * wz + m7 * 1.0f;
+      pfz[k] = m8 * wx + m9 * wy + m10 * wz + m11 * 1.0f;
+      ok[k] = pfz[k] > 0.f;                                                                 // :39 `if (pf.z <= 0) continue`
+      int2 sp = make_int2(0, 0);
+      if (ok[k]) sp = kf_project(kf3(pfx[k], pfy[k], pfz[k]), a.dcam);
+      ok[k] = ok[k] && !(sp.x >= a.dcam.cols - 1 || sp.y >= a.dcam.rows - 1 || sp.x < 1 || sp.y < 1);   // :43
+      pix[k] = ok[k] ? sp.y * a.dcam.cols + sp.x : 0;
     }
-    if (loaded) *p = q;
-    // brick flags + update count: one LDS word per brick, one global byte per brick
-    if (threadIdx.x == 0) s_flags = 0;
-    __syncthreads();
-    if (flags) atomicOr(&s_flags, flags);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) d[k] = ok[k] ? a.depth[pix[k]] : 0.f;
+    // Phase B: the reference's remaining predicates (:50-67), then one 16-byte read-modify-write for the pair
+    uchar4 col[2]; float normalz[2]; bool upd[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      upd[k] = ok[k] && d[k] != 0.f;                                                        // :50
+      col[k] = make_uchar4(0, 0, 0, 0); normalz[k] = 0.f;
+      if (HAS_COLOR) {
+        if (upd[k]) {
+          normalz[k] = a.normals[pix[k]].z;
+          const int cxp = kf_to_int((double)(pfx[k] * 525 / pfz[k] + 320)), cyp = kf_to_int((double)(pfy[k] * 525 / pfz[k] + 240));   // :56-57
+          upd[k] = !(cxp >= a.rcam.cols - 1 || cyp >= a.rcam.rows - 1 || cxp < 1 || cyp < 1);
+          if (upd[k]) col[k] = a.rgb[(size_t)cyp * a.rcam.cols + cxp];
+        }
+      }
+      upd[k] = upd[k] && (d[k] < a.max_dist) && ((d[k] - pfz[k]) > -a.sdf_trunc);          // :64, :67
+    }
+    if (upd[0] || upd[1]) {
+      float4 q = *p;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (!upd[k]) continue;
+        const float sdf = d[k] - pfz[k];
+        const float tsdf = fminf(1.0f, sdf / a.sdf_trunc);
+        const float ot = k ? q.z : q.x, ow = k ? q.w : q.y;
+        const float nw = fminf(ow + 1.f, v.max_weight);                                     // tsdfVolume.h:65
+        const float nt = (ot * ow + tsdf * 1.f) / (ow + 1.f);                               // tsdfVolume.h:66
+        if (k) { q.z = nt; q.w = nw; } else { q.x = nt; q.y = nw; }
+        if (HAS_COLOR) {
+          // :72 `(color_angled?fminf(1.0,abs(normalz)/0.75):1.0)*2.0` -- the division and the doubling run in double
+          const float wc = a.color_angled ? (float)((double)fminf(1.0f, (float)((double)fabsf(normalz[k]) / 0.75)) * 2.0) : 2.0f;
+          uchar4* cp = v.color + (size_t)slot * KF_BRICK_VOX + threadIdx.x * 2 + k;
+          const uchar4 oc = *cp;
+          const float c0 = fminf(255.0f, ((float)oc.x * ow + (float)col[k].x * wc) / (ow + wc));   // tsdfVolume.h:68-70
+          const float c1 = fminf(255.0f, ((float)oc.y * ow + (float)col[k].y * wc) / (ow + wc));
+          const float c2 = fminf(255.0f, ((float)oc.z * ow + (float)col[k].z * wc) / (ow + wc));
+          *cp = make_uchar4((unsigned char)c0, (unsigned char)c1, (unsigned char)c2, 0);
+        }
+        ++n_upd;
+        flags |= KF_FLAG_OBSERVED | (nt < 0.f ? KF_FLAG_HASNEG : 0u);
+      }
+      *p = q;
+    }
     upd_total += n_upd;
-    __syncthreads();
-    if (threadIdx.x == 0 && s_flags) v.flags[slot] = (uint8_t)(v.flags[slot] | s_flags);
+    // brick flags: each wave ORs its own bits into the brick's byte with a fire-and-forget 32-bit atomic -- no barrier and
+    // no read-modify-write round trip on the brick loop's critical path (the four waves of a brick never wait for each other)
+    const unsigned wflags = (__ballot(flags & KF_FLAG_OBSERVED) ? KF_FLAG_OBSERVED : 0u) | (__ballot(flags & KF_FLAG_HASNEG) ? KF_FLAG_HASNEG : 0u);
+    if (wflags && (threadIdx.x & 63) == 0) {
+      atomicOr(reinterpret_cast<unsigned*>(v.flags) + (slot >> 2), wflags << (8u * (slot & 3u)));
+      if (wflags & KF_FLAG_HASNEG) v.macro[((size_t)(bz >> 2) * v.nm + (by >> 2)) * v.nm + (bx >> 2)] = 1;   // 4 bricks per macro edge
+    }
   }
-  // N_upd: wave sum then one atomic per wave
+  // N_upd: wave sum -> LDS -> ONE atomic per workgroup, spread over 64 counter lines
   float s = kf_wave_sum((float)upd_total);          // < 2^24 per wave: exact
-  if ((threadIdx.x & 63) == 0 && s > 0.f) { atomicAdd(&a.cnt->n_upd, (unsigned long long)s); atomicAdd(&a.cnt->n_upd_total, (unsigned long long)s); }
+  if ((threadIdx.x & 63) == 0 && s > 0.f) atomicAdd(&s_upd, (unsigned)s);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_upd) atomicAdd(&a.cnt->upd_shard[(blockIdx.x & 63) * 16], (unsigned long long)s_upd);
 }
 
 static inline KfCam to_cam(const kf_camera_params* p) {

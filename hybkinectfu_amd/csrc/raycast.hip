@@ -74,12 +74,30 @@ __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
     const int R = v.res;
     const float rf = (float)R;
     const int zs0 = v.bz0 * KF_BRICK, zs1 = v.bz1 * KF_BRICK;
-    float t = tmin;
+    float t = tmin, t_prev = tmin;
     float last_sdf = 0.f; bool have_last = true;
-    float3 last_pos = kf3(0.f, 0.f, 0.f);
-    size_t last_idx = 0; bool last_stored = false;
+    const float mcell = (float)KF_MACRO * v.cell, inv_mcell = 1.f / mcell, eps = 1e-4f * mcell;
+    const int nm = v.nm;
     while (t < tmax) {
       const float3 pos = kf_add(org, kf_scale(dir, t));
+      // level 1: 32^3-voxel macro cell without any negative voxel -> none of the samples inside it can be the negative
+      // side of a crossing.  Advance t by the reference's own repeated addition (no memory traffic) until the ray is
+      // about to leave the cell; the exit bound is shrunk by eps so rounding can never skip a sample of a neighbour.
+      {
+        const int mx = max(0, min((int)floorf(pos.x * inv_mcell), nm - 1));
+        const int my = max(0, min((int)floorf(pos.y * inv_mcell), nm - 1));
+        const int mz = max(0, min((int)floorf(pos.z * inv_mcell), nm - 1));
+        if (!v.macro[((size_t)mz * nm + my) * nm + mx]) {
+          const float bx = dir.x > 0.f ? (float)(mx + 1) * mcell - eps : (float)mx * mcell + eps;
+          const float by = dir.y > 0.f ? (float)(my + 1) * mcell - eps : (float)my * mcell + eps;
+          const float bz = dir.z > 0.f ? (float)(mz + 1) * mcell - eps : (float)mz * mcell + eps;
+          const float dt = fminf(fminf((bx - pos.x) / dir.x, (by - pos.y) / dir.y), (bz - pos.z) / dir.z);
+          const float t_exit = fminf(t + dt - 1e-6f * t, tmax);
+          do { t_prev = t; t += a.inc; } while (t < t_exit);
+          have_last = false;
+          continue;
+        }
+      }
       // tsdfvolume::getVoxel(world) tsdfVolume.h:81-97: nearest voxel, index clamped
       int gx = kf_to_int((double)(pos.x * rf / S)), gy = kf_to_int((double)(pos.y * rf / S)), gz = kf_to_int((double)(pos.z * rf / S));
       gx = max(0, min(gx, R - 1)); gy = max(0, min(gy, R - 1)); gz = max(0, min(gz, R - 1));
@@ -88,14 +106,21 @@ __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
       if (stored) { slot = kf_brick_slot(v, gx >> 3, gy >> 3, gz >> 3); flag = v.flags[slot]; }
       const size_t idx = slot * KF_BRICK_VOX + (size_t)(((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7));
       if (!(flag & KF_FLAG_HASNEG)) {
-        // tsdf >= 0 everywhere in this brick: not the negative side of a crossing; remember where we were
-        have_last = false; last_idx = idx; last_stored = stored; last_pos = pos;
+        // level 2: tsdf >= 0 everywhere in this 8^3 brick: not the negative side of a crossing
+        have_last = false; t_prev = t;
         t += a.inc;
         continue;
       }
       const float sdf = v.tw[idx].x;
+      float3 last_pos = kf3(0.f, 0.f, 0.f);
       if (sdf < 0.0f) {
-        if (!have_last) { last_sdf = last_stored ? v.tw[last_idx].x : 0.f; have_last = true; }
+        last_pos = kf_add(org, kf_scale(dir, t_prev));                     // the previous sample of the march, recomputed exactly
+        if (!have_last) {                                                  // its tsdf was never fetched: fetch it now
+          int lx = kf_to_int((double)(last_pos.x * rf / S)), ly = kf_to_int((double)(last_pos.y * rf / S)), lz = kf_to_int((double)(last_pos.z * rf / S));
+          lx = max(0, min(lx, R - 1)); ly = max(0, min(ly, R - 1)); lz = max(0, min(lz, R - 1));
+          last_sdf = (lz >= zs0 && lz < zs1) ? v.tw[kf_vox_index(v, lx, ly, lz)].x : 0.f;
+          have_last = true;
+        }
         if (last_sdf > 0.0f) {                                             // zero crossing :83
           float ftdt, ft;
           if (!kf_interpolate_sdf(v, pos, ftdt)) break;
@@ -110,7 +135,7 @@ __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
           break;
         }
       }
-      last_sdf = sdf; have_last = true; last_pos = pos; last_idx = idx; last_stored = stored;
+      last_sdf = sdf; have_last = true; t_prev = t;
       t += a.inc;
     }
   }

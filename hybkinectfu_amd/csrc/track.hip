@@ -6,16 +6,20 @@
 // (src/cuda/CalSDFErrSolverParams.cu:7-138), CameraPoseFinderICP (src/CameraPoseFinderICP.cpp:12-145),
 // CameraPoseFinderSDF (src/CameraPoseFinderSDF.cpp:25-106), direct_exponential_map (src/utils/eigen_utils.cpp:60-127).
 //
-// gfx950 design: the reference builds the 6x6 system with 27 sequential 256-wide shared-memory tree reductions
-// (54 barriers) per launch, a second 27-block launch, a device sync and a 108-byte read-back, 19 times per frame.
-// Here one launch per Gauss-Newton step does everything:
+// gfx950 design.  The reference builds the 6x6 system with 27 sequential 256-wide shared-memory tree reductions
+// (54 barriers) per launch, a second 27-block launch, a device sync and a 108-byte read-back, 19 times per frame; the
+// loop is latency-bound.  Here a Gauss-Newton step is ONE launch and the host never sees the 27 floats:
 //   * every lane keeps the 27 partial sums of its pixels in registers (no MFMA: a 6x6 outer product is far too small);
-//   * a wave64 __shfl_down tree folds them, LDS holds the four per-wave partials, 27 lanes write the workgroup partial;
-//   * the workgroups arrive on an agent-scope ticket (release fence -> relaxed atomic); the last one to arrive acquires,
-//     sums the partials in a fixed order (bitwise reproducible run to run), and ONE lane runs the 6x6 determinant test,
-//     the Cholesky solve, the shake test and the pose update in place.  The host never sees the 27 floats.
-// The sums are fp32 in a different association than the reference's tree, so parity for this stage is by tolerance
-// (pose within 1e-4 m / 1e-4 rad), as SURVEY.md section 8a row a6 states.
+//     a wave64 __shfl_down tree folds them, LDS holds the four per-wave partials, 27 lanes write the workgroup partial;
+//   * there is no second "reduce" launch, no atomic and no fence: the NEXT step's launch starts by having every workgroup
+//     sum the previous step's workgroup partials (<= 512 x 27 floats, L2 resident) in the same fixed order and run the same
+//     6x6 determinant test / Cholesky solve / shake test / pose composition on one lane, so all workgroups hold the
+//     identical new transform (bitwise) and go straight on to their pixels.  Partials and the running transform are
+//     double-buffered by step parity; the kernel boundary is the only synchronisation (1.5-2 us, MI355X_MICROARCH.md
+//     'boundary') -- cheaper than a ticket on one contended word plus a release/acquire pair per step;
+//   * a last 1-workgroup launch folds the final step and commits CameraPoseFinder::_pose.
+// Sums are fp32 in a fixed (reproducible) association that differs from the reference's tree, so parity for this stage is
+// by tolerance (pose within 1e-4 m / 1e-4 rad), as SURVEY.md section 8a row a6 states.
 #include "kf_internal.h"
 #include <string.h>
 
@@ -24,21 +28,257 @@
 struct TrackArgs {
   const float4* new_v; const float4* new_n; const float4* model_v; const float4* model_n;
   KfCam cam;
-  const float* cur_ptr; const float* linv_ptr;   // device-resident transforms, or null -> *_val
-  KfMat cur_val, linv_val;
+  KfMat cur_val, linv_val;                       // host-supplied transforms (per-call wrappers only)
+  int use_state;                                 // 1: transforms come from the device-resident KfTrackState
   float dist_thres, sin_thres, dist_shake, angle_shake;
-  float* partials;                               // gridDim.x x 32
+  float* partials;                               // 2 x KF_ICP_MAX_WG x 32 floats, indexed by step parity
   KfTrackState* track;
-  int solve;                                     // 1: fused Gauss-Newton step, 0: only leave the 27 sums in track->reduced
-  int final_step;                                // 1: commit cur -> pose when the step succeeds
+  int step;                                      // index of this Gauss-Newton step within the frame (buffer parity)
+  int consume;                                   // 1: first fold + apply the previous step's system
+  int n_prev_wg;                                 // workgroups that wrote the previous step's partials
+  int sdf;                                       // consume with the SDF tracker's update rule (exp map, convergence test)
   // SDF tracker only
   KfVolume vol; const float* depth;
 };
 
-// ---- workgroup reduction + arrival ticket --------------------------------------------------------------------------
-// Returns true in every thread of the LAST workgroup to arrive, after which s_tot[0..26] hold the grand totals.
-__device__ __forceinline__ bool reduce27_and_arrive(float acc[27], float* partials, KfTrackState* track, float* s_wave /*[4][32]*/,
-                                                    float* s_tot /*[8][32]*/, int* s_last) {
+// ---- 6x6 dense algebra on one lane (stands in for Eigen); every index is static after unrolling -> registers only ----
+// src/CameraPoseFinderICP.cpp:119-136
+__device__ __forceinline__ void unpack27(const float* in, float A[36], float b[6]) {
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 7; ++j) {
+      float v = in[s++];
+      if (j == 6) b[i] = v; else { A[i * 6 + j] = v; A[j * 6 + i] = v; }
+    }
+}
+// determinant by partial-pivot LU (Eigen's path for a 6x6 `determinant()`), fp32; destroys m
+__device__ __forceinline__ float det6(float m[36]) {
+  float det = 1.f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int p = k; float best = fabsf(m[k * 6 + k]);
+#pragma unroll
+    for (int r = k + 1; r < 6; ++r) { float v = fabsf(m[r * 6 + k]); if (v > best) { best = v; p = r; } }
+    if (best == 0.f) return 0.f;
+#pragma unroll
+    for (int r = k + 1; r < 6; ++r)
+      if (p == r) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { float t = m[k * 6 + c]; m[k * 6 + c] = m[r * 6 + c]; m[r * 6 + c] = t; }
+        det = -det;
+      }
+    const float piv = m[k * 6 + k];
+    det *= piv;
+#pragma unroll
+    for (int r = k + 1; r < 6; ++r) {
+      const float f = m[r * 6 + k] / piv;
+#pragma unroll
+      for (int c = k + 1; c < 6; ++c) m[r * 6 + c] -= f * m[k * 6 + c];
+    }
+  }
+  return det;
+}
+// x = LLT(A) \ b, fp32 (ICP.cpp:143, SDF.cpp:79)
+__device__ __forceinline__ void llt_solve6(const float A[36], const float b[6], float x[6]) {
+  float L[36];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float s = A[j * 6 + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= L[j * 6 + k] * L[j * 6 + k];
+    const float d = sqrtf(s);
+    L[j * 6 + j] = d;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      float t = A[i * 6 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i * 6 + k] * L[j * 6 + k];
+      L[i * 6 + j] = t / d;
+    }
+  }
+  float y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float t = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) t -= L[i * 6 + k] * y[k];
+    y[i] = t / L[i * 6 + i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    float t = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) t -= L[k * 6 + i] * x[k];
+    x[i] = t / L[i * 6 + i];
+  }
+}
+__device__ __forceinline__ void mat3_mul(const float a[9], const float b[9], float o[9]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[r * 3 + c] = a[r * 3] * b[c] + a[r * 3 + 1] * b[3 + c] + a[r * 3 + 2] * b[6 + c];
+}
+// Mat.h:240-262
+__device__ __forceinline__ void mat44_mul(const float* a, const float* b, float* out) {
+  float r[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[i * 4 + j] = a[i * 4] * b[j] + a[i * 4 + 1] * b[4 + j] + a[i * 4 + 2] * b[8 + j] + a[i * 4 + 3] * b[12 + j];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) out[i] = r[i];
+}
+// vector6ToTransformMatrix (ICP.cpp:95-111, SDF.cpp:25-43): R = Rx Ry Rz, shake test on the rotation angle and |t|
+__device__ __forceinline__ bool vector6_to_transform(const float x[6], float dist_shake, float angle_shake, float t[16]) {
+  const float c0 = cosf(x[0]), s0 = sinf(x[0]), c1 = cosf(x[1]), s1 = sinf(x[1]), c2 = cosf(x[2]), s2 = sinf(x[2]);
+  const float Rx[9] = {1, 0, 0, 0, c0, -s0, 0, s0, c0};
+  const float Ry[9] = {c1, 0, s1, 0, 1, 0, -s1, 0, c1};
+  const float Rz[9] = {c2, -s2, 0, s2, c2, 0, 0, 0, 1};
+  float Rxy[9], R[9];
+  mat3_mul(Rx, Ry, Rxy); mat3_mul(Rxy, Rz, R);
+  float ca = (R[0] + R[4] + R[8] - 1.f) * 0.5f;
+  ca = fminf(1.f, fmaxf(-1.f, ca));
+  const float angle = acosf(ca);                             // == AngleAxisf(R).angle()
+  const float d = sqrtf(x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
+  if (!(angle <= angle_shake) || !(d <= dist_shake)) return false;   // a NaN increment counts as shaking: never applied
+  const float o[16] = {R[0], R[1], R[2], x[3], R[3], R[4], R[5], x[4], R[6], R[7], R[8], x[5], 0, 0, 0, 1};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t[i] = o[i];
+  return true;
+}
+
+// ---- fold the previous step's partial sums: identical order in every workgroup ------------------------------------------
+// s_tot must hold 8 x 32 floats; on return s_tot[0..26] are the totals (all threads, after the barrier)
+// (blockDim/32 interleaved chains per sum; the loads of a chain are issued four at a time so the chain costs
+// ceil(n/4) memory round trips instead of n; the additions keep their fixed order.)  s_tot: 32 x 32 floats.
+__device__ __forceinline__ void fold_partials(const float* __restrict__ partials, int n_wg, float* s_tot) {
+  const int k = threadIdx.x & 31, part = threadIdx.x >> 5, parts = blockDim.x >> 5;
+  float s = 0.f;
+  if (k < 27) {
+    for (int w = part; w < n_wg; w += 4 * parts) {
+      const int w1 = w + parts, w2 = w + 2 * parts, w3 = w + 3 * parts;
+      const float v0 = partials[w * 32 + k];
+      const float v1 = (w1 < n_wg) ? partials[w1 * 32 + k] : 0.f;
+      const float v2 = (w2 < n_wg) ? partials[w2 * 32 + k] : 0.f;
+      const float v3 = (w3 < n_wg) ? partials[w3 * 32 + k] : 0.f;
+      s += v0; s += v1; s += v2; s += v3;
+    }
+  }
+  s_tot[part * 32 + k] = s;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x < 27) {
+    t = s_tot[threadIdx.x];
+    for (int p = 1; p < parts; ++p) t += s_tot[p * 32 + threadIdx.x];
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) s_tot[threadIdx.x] = t;
+  __syncthreads();
+}
+
+// direct_exponential_map (eigen_utils.cpp:84-127) in double, then SDF.cpp:92-100: R' = R_exp^T R_cur, t' = t_cur - R_exp^T t_exp
+__device__ __forceinline__ void sdf_apply_increment(const float x[6], const float* cur, float ncur[16]) {
+  const double u0 = (double)x[0], u1 = (double)x[1], u2 = (double)x[2], t3 = (double)x[3], t4 = (double)x[4], t5 = (double)x[5];
+  const double theta = sqrt(u0 * u0 + u1 * u1 + u2 * u2);
+  const double si = sin(theta), co = cos(theta);
+  const double sinc = fabs(theta) < 1.0e-8 ? 1.0 : si / theta;
+  const double mcosc = fabs(theta) < 2.5e-4 ? 0.5 : (1.0 - co) / theta / theta;
+  const double msinc = fabs(theta) < 2.5e-4 ? (1. / 6.0) : (1.0 - si / theta) / theta / theta;
+  double R[9];
+  R[0] = co + mcosc * u0 * u0;         R[1] = -sinc * u2 + mcosc * u0 * u1; R[2] = sinc * u1 + mcosc * u0 * u2;
+  R[3] = sinc * u2 + mcosc * u1 * u0;  R[4] = co + mcosc * u1 * u1;         R[5] = -sinc * u0 + mcosc * u1 * u2;
+  R[6] = -sinc * u1 + mcosc * u2 * u0; R[7] = sinc * u0 + mcosc * u2 * u1;  R[8] = co + mcosc * u2 * u2;
+  double dt[3];
+  dt[0] = t3 * (sinc + u0 * u0 * msinc) + t4 * (u0 * u1 * msinc - u2 * mcosc) + t5 * (u0 * u2 * msinc + u1 * mcosc);
+  dt[1] = t3 * (u0 * u1 * msinc + u2 * mcosc) + t4 * (sinc + u1 * u1 * msinc) + t5 * (u1 * u2 * msinc - u0 * mcosc);
+  dt[2] = t3 * (u0 * u2 * msinc - u1 * mcosc) + t4 * (u1 * u2 * msinc + u0 * mcosc) + t5 * (sinc + u2 * u2 * msinc);
+  float Rt[9], tf[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Rt[r * 3 + c] = (float)R[c * 3 + r];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) tf[k] = (float)dt[k];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ncur[r * 4 + c] = Rt[r * 3] * cur[c] + Rt[r * 3 + 1] * cur[4 + c] + Rt[r * 3 + 2] * cur[8 + c];
+    ncur[r * 4 + 3] = cur[r * 4 + 3] - (Rt[r * 3] * tf[0] + Rt[r * 3 + 1] * tf[1] + Rt[r * 3 + 2] * tf[2]);
+  }
+  ncur[12] = 0.f; ncur[13] = 0.f; ncur[14] = 0.f; ncur[15] = 1.f;
+}
+
+enum { STEP_APPLIED = 0, STEP_LOST_DET = 1, STEP_LOST_SHAKE = 2, STEP_CONVERGED = 3 };
+
+// Apply one Gauss-Newton update from the folded sums in s_tot to s_cur (in place).  Runs on lane 0 of every workgroup with
+// identical inputs -> identical outputs.  Returns STEP_* through *s_code (LDS).
+//   ICP: minimizePointToPlaneErrFunc (ICP.cpp:117-143) + loop body of estimateCameraPose (:71-82)
+//   SDF: loop body of CameraPoseFinderSDF::estimateCameraPose (SDF.cpp:62-101)
+__device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_tot, float* s_cur, int* s_code) {
+  if (threadIdx.x == 0) {
+    float A[36], b[6], x[6], T[16], ncur[16];
+    unpack27(s_tot, A, b);
+    int code = STEP_APPLIED;
+    if (!a.sdf) {
+      float m[36];
+#pragma unroll
+      for (int i = 0; i < 36; ++i) m[i] = A[i];
+      if ((double)det6(m) < 1E-10) code = STEP_LOST_DET;                 // ICP.cpp:138
+    }
+    if (code == STEP_APPLIED) {
+      llt_solve6(A, b, x);
+      if (!vector6_to_transform(x, a.dist_shake, a.angle_shake, T)) code = STEP_LOST_SHAKE;
+      else if (a.sdf) {
+        const float nx = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
+        if (nx < 0.001f) code = STEP_CONVERGED;                            // SDF.cpp:87-90: stop before applying x
+        else { sdf_apply_increment(x, s_cur, ncur); for (int i = 0; i < 16; ++i) s_cur[i] = ncur[i]; }
+      } else {
+        mat44_mul(T, s_cur, ncur);                                         // ICP.cpp:81 cur = T * cur
+        for (int i = 0; i < 16; ++i) s_cur[i] = ncur[i];
+      }
+    }
+    *s_code = code;
+  }
+  __syncthreads();
+}
+
+// Common prologue of a step launch: load the running transform, fold + apply the previous step if asked.
+// Returns false when the loop has ended (lost / converged); workgroup 0 records that in the track state.
+__device__ __forceinline__ bool step_prologue(const TrackArgs& a, float* s_cur, float* s_linv, float* s_tot, int* s_code) {
+  KfTrackState* st = a.track;
+  if (a.use_state) {
+    if (st->status != KF_TRACK_OK || st->converged) return false;          // uniform: written by an earlier launch
+    if (threadIdx.x < 16) s_cur[threadIdx.x] = st->cur[a.step & 1][threadIdx.x];
+    else if (threadIdx.x < 32) s_linv[threadIdx.x - 16] = st->last_inv[threadIdx.x - 16];
+  } else {
+    if (threadIdx.x < 16) s_cur[threadIdx.x] = a.cur_val.m[threadIdx.x];
+    else if (threadIdx.x < 32) s_linv[threadIdx.x - 16] = a.linv_val.m[threadIdx.x - 16];
+  }
+  __syncthreads();
+  if (!a.consume) {
+    if (a.use_state && blockIdx.x == 0 && threadIdx.x < 16) st->cur[(a.step + 1) & 1][threadIdx.x] = s_cur[threadIdx.x];
+    return true;
+  }
+  fold_partials(a.partials + (size_t)((a.step + 1) & 1) * KF_ICP_MAX_WG * 32, a.n_prev_wg, s_tot);
+  apply_step(a, s_tot, s_cur, s_code);
+  const int code = *s_code;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 27) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
+    if (code == STEP_APPLIED) {
+      if (threadIdx.x < 16) st->cur[(a.step + 1) & 1][threadIdx.x] = s_cur[threadIdx.x];
+      if (threadIdx.x == 0) st->iterations += 1;
+    } else if (threadIdx.x == 0) {
+      if (code == STEP_CONVERGED) { st->converged = 1; for (int i = 0; i < 16; ++i) st->pose[i] = s_cur[i]; st->tracked = 1; }
+      else { st->status = code; st->tracked = 0; }                          // KF_TRACK_LOST_* share the STEP_LOST_* values
+    }
+  }
+  return code == STEP_APPLIED;
+}
+
+// wave + workgroup reduction of the 27 sums, written as this workgroup's partial for the NEXT launch to fold
+__device__ __forceinline__ void store_partial(float acc[27], float* partials_out, float* s_wave) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
@@ -47,134 +287,29 @@ __device__ __forceinline__ bool reduce27_and_arrive(float acc[27], float* partia
   }
   __syncthreads();
   if (threadIdx.x < 27) {
-    float s = ((s_wave[threadIdx.x] + s_wave[32 + threadIdx.x]) + s_wave[64 + threadIdx.x]) + s_wave[96 + threadIdx.x];
-    partials[blockIdx.x * 32 + threadIdx.x] = s;
+    const int waves = blockDim.x >> 6;
+    float s = s_wave[threadIdx.x];
+    for (int w = 1; w < waves; ++w) s += s_wave[w * 32 + threadIdx.x];
+    partials_out[blockIdx.x * 32 + threadIdx.x] = s;
   }
-  // publish: every storing wave drains its stores, the workgroup meets, one lane releases at agent scope, then the ticket
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned t = __hip_atomic_fetch_add(&track->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *s_last = (t == gridDim.x - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!*s_last) return false;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    track->ticket = 0u;                                     // re-armed for the next launch (kernel boundary orders it)
-  }
-  __syncthreads();
-  const int k = threadIdx.x & 31, part = threadIdx.x >> 5;  // 8 interleaved partial chains per sum, fixed order
-  float s = 0.f;
-  if (k < 27) for (unsigned w = part; w < gridDim.x; w += 8) s += partials[w * 32 + k];
-  s_tot[part * 32 + k] = s;
-  __syncthreads();
-  if (threadIdx.x < 27) {
-    float t = s_tot[threadIdx.x];
-#pragma unroll
-    for (int p = 1; p < 8; ++p) t += s_tot[p * 32 + threadIdx.x];
-    s_tot[threadIdx.x] = t;
-    track->reduced[threadIdx.x] = t;                        // rigid_align_buf_reduced
-  }
-  __syncthreads();
-  return true;
-}
-
-// ---- 6x6 dense algebra on one lane (stands in for Eigen) ------------------------------------------------------------
-// src/CameraPoseFinderICP.cpp:119-136
-__device__ static void unpack27(const float* in, float A[36], float b[6]) {
-  int s = 0;
-  for (int i = 0; i < 6; ++i)
-    for (int j = i; j < 7; ++j) {
-      float v = in[s++];
-      if (j == 6) b[i] = v; else { A[i * 6 + j] = v; A[j * 6 + i] = v; }
-    }
-}
-// determinant by partial-pivot LU (Eigen's path for a 6x6 `determinant()`), fp32
-__device__ static float det6(const float A[36]) {
-  float m[36];
-  for (int i = 0; i < 36; ++i) m[i] = A[i];
-  float det = 1.f;
-  for (int k = 0; k < 6; ++k) {
-    int p = k; float best = fabsf(m[k * 6 + k]);
-    for (int r = k + 1; r < 6; ++r) { float v = fabsf(m[r * 6 + k]); if (v > best) { best = v; p = r; } }
-    if (best == 0.f) return 0.f;
-    if (p != k) { for (int c = 0; c < 6; ++c) { float t = m[k * 6 + c]; m[k * 6 + c] = m[p * 6 + c]; m[p * 6 + c] = t; } det = -det; }
-    float piv = m[k * 6 + k];
-    det *= piv;
-    for (int r = k + 1; r < 6; ++r) {
-      float f = m[r * 6 + k] / piv;
-      for (int c = k + 1; c < 6; ++c) m[r * 6 + c] -= f * m[k * 6 + c];
-    }
-  }
-  return det;
-}
-// x = LLT(A) \ b, fp32 (ICP.cpp:143, SDF.cpp:79)
-__device__ static void llt_solve6(const float A[36], const float b[6], float x[6]) {
-  float L[36];
-  for (int i = 0; i < 36; ++i) L[i] = 0.f;
-  for (int j = 0; j < 6; ++j) {
-    float s = A[j * 6 + j];
-    for (int k = 0; k < j; ++k) s -= L[j * 6 + k] * L[j * 6 + k];
-    float d = sqrtf(s);
-    L[j * 6 + j] = d;
-    for (int i = j + 1; i < 6; ++i) {
-      float t = A[i * 6 + j];
-      for (int k = 0; k < j; ++k) t -= L[i * 6 + k] * L[j * 6 + k];
-      L[i * 6 + j] = t / d;
-    }
-  }
-  float y[6];
-  for (int i = 0; i < 6; ++i) { float t = b[i]; for (int k = 0; k < i; ++k) t -= L[i * 6 + k] * y[k]; y[i] = t / L[i * 6 + i]; }
-  for (int i = 5; i >= 0; --i) { float t = y[i]; for (int k = i + 1; k < 6; ++k) t -= L[k * 6 + i] * x[k]; x[i] = t / L[i * 6 + i]; }
-}
-__device__ static void mat3_mul(const float a[9], const float b[9], float o[9]) {
-  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
-    o[r * 3 + c] = a[r * 3] * b[c] + a[r * 3 + 1] * b[3 + c] + a[r * 3 + 2] * b[6 + c];
-}
-// Mat.h:240-262
-__device__ static void mat44_mul(const float* a, const float* b, float* out) {
-  float r[16];
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j)
-      r[i * 4 + j] = a[i * 4] * b[j] + a[i * 4 + 1] * b[4 + j] + a[i * 4 + 2] * b[8 + j] + a[i * 4 + 3] * b[12 + j];
-  for (int i = 0; i < 16; ++i) out[i] = r[i];
-}
-// vector6ToTransformMatrix (ICP.cpp:95-111, SDF.cpp:25-43): R = Rx Ry Rz, shake test on the rotation angle and |t|
-__device__ static bool vector6_to_transform(const float x[6], float dist_shake, float angle_shake, float t[16]) {
-  float c0 = cosf(x[0]), s0 = sinf(x[0]), c1 = cosf(x[1]), s1 = sinf(x[1]), c2 = cosf(x[2]), s2 = sinf(x[2]);
-  float Rx[9] = {1, 0, 0, 0, c0, -s0, 0, s0, c0};
-  float Ry[9] = {c1, 0, s1, 0, 1, 0, -s1, 0, c1};
-  float Rz[9] = {c2, -s2, 0, s2, c2, 0, 0, 0, 1};
-  float Rxy[9], R[9];
-  mat3_mul(Rx, Ry, Rxy); mat3_mul(Rxy, Rz, R);
-  float ca = (R[0] + R[4] + R[8] - 1.f) * 0.5f;
-  ca = fminf(1.f, fmaxf(-1.f, ca));
-  float angle = acosf(ca);                                   // == AngleAxisf(R).angle()
-  float d = sqrtf(x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
-  if (!(angle <= angle_shake) || !(d <= dist_shake)) return false;   // NaN counts as shaking: never applied
-  float o[16] = {R[0], R[1], R[2], x[3], R[3], R[4], R[5], x[4], R[6], R[7], R[8], x[5], 0, 0, 0, 1};
-  for (int i = 0; i < 16; ++i) t[i] = o[i];
-  return true;
 }
 
 // ---- ICP ------------------------------------------------------------------------------------------------------------
-// findCorrs (:17-60) + buildPointToPlaneSolverRows (:7-16) for one pixel
-__device__ __forceinline__ bool icp_row(const TrackArgs& a, const float* cur, const float* linv, int x, int y, float row[7]) {
-  const int cols = a.cam.cols, rows = a.cam.rows;
-  const float4 iv = a.new_v[y * cols + x], in_ = a.new_n[y * cols + x];
-  if (kf_is_zero4(in_)) return false;
-  const float4 vg = kf_mat_vec(cur, iv);
-  const float4 ng = kf_mat_vec(cur, in_);
+// findCorrs (:17-60) + buildPointToPlaneSolverRows (:7-16), split so the 4 pixels of a lane overlap their memory round trips:
+// stage A (icp_project) needs only the lane's own vertex/normal and yields the model-map index; stage B (icp_finish)
+// consumes the gathered model vertex/normal.
+__device__ __forceinline__ int icp_project(const TrackArgs& a, const float* cur, const float* linv, float4 iv, float4 in_,
+                                           float4& vg, float4& ng) {
+  if (kf_is_zero4(in_)) return -1;
+  vg = kf_mat_vec(cur, iv);
+  ng = kf_mat_vec(cur, in_);
   const float4 vcp = kf_mat_vec(linv, vg);
   const int2 sp = kf_project(kf3(vcp.x, vcp.y, vcp.z), a.cam);
-  if (sp.x < 0 || sp.x >= cols || sp.y < 0 || sp.y >= rows) return false;
-  const float4 nt = a.model_n[sp.y * cols + sp.x];
+  if (sp.x < 0 || sp.x >= a.cam.cols || sp.y < 0 || sp.y >= a.cam.rows) return -1;
+  return sp.y * a.cam.cols + sp.x;
+}
+__device__ __forceinline__ bool icp_finish(const TrackArgs& a, float4 vg, float4 ng, float4 vt, float4 nt, float row[7]) {
   if (kf_is_zero4(nt)) return false;
-  const float4 vt = a.model_v[sp.y * cols + sp.x];
   const float d = kf_norm(kf3(vt.x - vg.x, vt.y - vg.y, vt.z - vg.z));
   const float s = kf_norm(kf_cross(kf3(nt.x, nt.y, nt.z), kf3(ng.x, ng.y, ng.z)));
   if (d > a.dist_thres || s > a.sin_thres) return false;
@@ -185,58 +320,61 @@ __device__ __forceinline__ bool icp_row(const TrackArgs& a, const float* cur, co
   return true;
 }
 
-__global__ void __launch_bounds__(TRK_THREADS) k_icp_step(TrackArgs a) {
-  KfTrackState* st = a.track;
-  if (a.solve && st->status != KF_TRACK_OK) return;         // an earlier step lost the camera: the loop has ended
+// 1024 lanes x 4 pixels per workgroup: 75 / 19 / 5 workgroups at VGA level 0 / 1 / 2, so the next launch folds few partials.
+#define ICP_THREADS 1024
+#define ICP_PX 4
+__global__ void __launch_bounds__(ICP_THREADS) k_icp_step(TrackArgs a) {
   __shared__ float s_cur[16], s_linv[16];
-  __shared__ float s_wave[4 * 32], s_tot[8 * 32];
-  __shared__ int s_last;
-  if (threadIdx.x < 16) s_cur[threadIdx.x] = a.cur_ptr ? a.cur_ptr[threadIdx.x] : a.cur_val.m[threadIdx.x];
-  else if (threadIdx.x < 32) s_linv[threadIdx.x - 16] = a.linv_ptr ? a.linv_ptr[threadIdx.x - 16] : a.linv_val.m[threadIdx.x - 16];
-  __syncthreads();
+  __shared__ float s_wave[16 * 32], s_tot[32 * 32];
+  __shared__ int s_code;
+  // the lane's own vertices / normals do not depend on the running transform: request them before the fold + solve
+  const int npx = a.cam.cols * a.cam.rows;
+  const int base = blockIdx.x * (ICP_THREADS * ICP_PX) + threadIdx.x;
+  float4 iv[ICP_PX], in_[ICP_PX];
+#pragma unroll
+  for (int j = 0; j < ICP_PX; ++j) {
+    const int i = base + j * ICP_THREADS;
+    iv[j] = make_float4(0.f, 0.f, 0.f, 0.f); in_[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < npx) { iv[j] = a.new_v[i]; in_[j] = a.new_n[i]; }
+  }
+  if (!step_prologue(a, s_cur, s_linv, s_tot, &s_code)) return;
+  float4 vg[ICP_PX], ng[ICP_PX], vt[ICP_PX], nt[ICP_PX];
+  int mi[ICP_PX];
+#pragma unroll
+  for (int j = 0; j < ICP_PX; ++j) mi[j] = icp_project(a, s_cur, s_linv, iv[j], in_[j], vg[j], ng[j]);
+#pragma unroll
+  for (int j = 0; j < ICP_PX; ++j) {
+    nt[j] = make_float4(0.f, 0.f, 0.f, 0.f); vt[j] = nt[j];
+    if (mi[j] >= 0) { nt[j] = a.model_n[mi[j]]; vt[j] = a.model_v[mi[j]]; }
+  }
   float acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.f;
-  const int npx = a.cam.cols * a.cam.rows;
-  for (int i = blockIdx.x * TRK_THREADS + threadIdx.x; i < npx; i += gridDim.x * TRK_THREADS) {
+#pragma unroll
+  for (int j = 0; j < ICP_PX; ++j) {
     float row[7];
-    if (!icp_row(a, s_cur, s_linv, i % a.cam.cols, i / a.cam.cols, row)) continue;
+    if (mi[j] < 0 || !icp_finish(a, vg[j], ng[j], vt[j], nt[j], row)) continue;
     int s = 0;
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
       for (int c = r; c < 7; ++c) acc[s++] += row[r] * row[c];            // :92-105 packing
   }
-  if (!reduce27_and_arrive(acc, a.partials, st, s_wave, s_tot, &s_last)) return;
-  if (!a.solve || threadIdx.x != 0) return;
-  // minimizePointToPlaneErrFunc (ICP.cpp:117-143) + the loop body of estimateCameraPose (:71-82)
-  float A[36], b[6], x[6], T[16];
-  unpack27(s_tot, A, b);
-  if ((double)det6(A) < 1E-10) { st->status = KF_TRACK_LOST_DET; st->tracked = 0; return; }
-  llt_solve6(A, b, x);
-  if (!vector6_to_transform(x, a.dist_shake, a.angle_shake, T)) { st->status = KF_TRACK_LOST_SHAKE; st->tracked = 0; return; }
-  float ncur[16];
-  mat44_mul(T, s_cur, ncur);                                               // cur = T * cur
-  for (int i = 0; i < 16; ++i) st->cur[i] = ncur[i];
-  st->iterations += 1;
-  if (a.final_step) { for (int i = 0; i < 16; ++i) st->pose[i] = ncur[i]; st->tracked = 1; }
+  store_partial(acc, a.partials + (size_t)(a.step & 1) * KF_ICP_MAX_WG * 32, s_wave);
 }
 
 // ---- SDF tracker ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(TRK_THREADS) k_sdf_step(TrackArgs a) {
-  KfTrackState* st = a.track;
-  if (a.solve && (st->status != KF_TRACK_OK || st->converged)) return;
   __shared__ float s_m[7][16];                 // cur, then delta*cur for +w1,-w1,+w2,-w2,+w3,-w3 (CalSDFErrSolverParams.cu:118-133)
-  __shared__ float s_wave[4 * 32], s_tot[8 * 32];
-  __shared__ int s_last;
+  __shared__ float s_linv[16];
+  __shared__ float s_wave[4 * 32], s_tot[32 * 32];
+  __shared__ int s_code;
+  if (!step_prologue(a, s_m[0], s_linv, s_tot, &s_code)) return;
   const float w_h = 0.001f;                                               // :119 `float w_h = 0.001;`
   const float v_h = a.vol.size / (float)a.vol.res;                        // :120
-  if (threadIdx.x < 16) s_m[0][threadIdx.x] = a.cur_ptr ? a.cur_ptr[threadIdx.x] : a.cur_val.m[threadIdx.x];
-  __syncthreads();
   if (threadIdx.x < 96) {
     const int mi = threadIdx.x >> 4, e = threadIdx.x & 15, r = e >> 2, cidx = e & 3;
-    // (row, col) pairs that carry -/+ w_h for axis mi/2 ; second matrix of a pair flips the sign
-    const int axis = mi >> 1; const float sg = (mi & 1) ? -1.f : 1.f;
+    const int axis = mi >> 1; const float sg = (mi & 1) ? -1.f : 1.f;     // second matrix of a pair flips the sign
     float d[4] = {0.f, 0.f, 0.f, 0.f}; d[r] = 1.f;
     if (axis == 0) { if (r == 1) d[2] = -sg * w_h; if (r == 2) d[1] = sg * w_h; }          // m23 = -w, m32 = +w
     else if (axis == 1) { if (r == 0) d[2] = sg * w_h; if (r == 2) d[0] = -sg * w_h; }     // m13 = +w, m31 = -w
@@ -284,74 +422,44 @@ __global__ void __launch_bounds__(TRK_THREADS) k_sdf_step(TrackArgs a) {
 #pragma unroll
       for (int c = r; c < 7; ++c) acc[s++] += row[r] * row[c];
   }
-  if (!reduce27_and_arrive(acc, a.partials, st, s_wave, s_tot, &s_last)) return;
-  if (!a.solve || threadIdx.x != 0) return;
-  // CameraPoseFinderSDF::estimateCameraPose loop body (SDF.cpp:62-101)
-  float A[36], b[6], x[6], T[16];
-  unpack27(s_tot, A, b);
-  llt_solve6(A, b, x);                                                     // no determinant test (:79)
-  if (!vector6_to_transform(x, a.dist_shake, a.angle_shake, T)) { st->status = KF_TRACK_LOST_SHAKE; st->tracked = 0; return; }
-  const float nx = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
-  const float* cur = s_m[0];
-  if (nx < 0.001f) {                                                       // :87-90 stop before applying x
-    st->converged = 1;
-    for (int i = 0; i < 16; ++i) st->pose[i] = cur[i];
-    st->tracked = 1;
-    return;
-  }
-  // direct_exponential_map (eigen_utils.cpp:84-127) in double
-  const double u0 = (double)x[0], u1 = (double)x[1], u2 = (double)x[2], t3 = (double)x[3], t4 = (double)x[4], t5 = (double)x[5];
-  const double theta = sqrt(u0 * u0 + u1 * u1 + u2 * u2);
-  const double si = sin(theta), co = cos(theta);
-  const double sinc = fabs(theta) < 1.0e-8 ? 1.0 : si / theta;
-  const double mcosc = fabs(theta) < 2.5e-4 ? 0.5 : (1.0 - co) / theta / theta;
-  const double msinc = fabs(theta) < 2.5e-4 ? (1. / 6.0) : (1.0 - si / theta) / theta / theta;
-  double R[9];
-  R[0] = co + mcosc * u0 * u0;        R[1] = -sinc * u2 + mcosc * u0 * u1; R[2] = sinc * u1 + mcosc * u0 * u2;
-  R[3] = sinc * u2 + mcosc * u1 * u0; R[4] = co + mcosc * u1 * u1;         R[5] = -sinc * u0 + mcosc * u1 * u2;
-  R[6] = -sinc * u1 + mcosc * u2 * u0; R[7] = sinc * u0 + mcosc * u2 * u1; R[8] = co + mcosc * u2 * u2;
-  double dt[3];
-  dt[0] = t3 * (sinc + u0 * u0 * msinc) + t4 * (u0 * u1 * msinc - u2 * mcosc) + t5 * (u0 * u2 * msinc + u1 * mcosc);
-  dt[1] = t3 * (u0 * u1 * msinc + u2 * mcosc) + t4 * (sinc + u1 * u1 * msinc) + t5 * (u1 * u2 * msinc - u0 * mcosc);
-  dt[2] = t3 * (u0 * u2 * msinc - u1 * mcosc) + t4 * (u1 * u2 * msinc + u0 * mcosc) + t5 * (sinc + u2 * u2 * msinc);
-  // SDF.cpp:96-97: R' = R_exp^T * R_cur ; t' = t_cur - R_exp^T * t_exp  (fp32 after the casts)
-  float Rt[9], tf[3], ncur[16];
-  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rt[r * 3 + c] = (float)R[c * 3 + r];
-  for (int k = 0; k < 3; ++k) tf[k] = (float)dt[k];
-  for (int r = 0; r < 3; ++r) {
-    for (int c = 0; c < 3; ++c) ncur[r * 4 + c] = Rt[r * 3] * cur[c] + Rt[r * 3 + 1] * cur[4 + c] + Rt[r * 3 + 2] * cur[8 + c];
-    ncur[r * 4 + 3] = cur[r * 4 + 3] - (Rt[r * 3] * tf[0] + Rt[r * 3 + 1] * tf[1] + Rt[r * 3 + 2] * tf[2]);
-  }
-  ncur[12] = 0.f; ncur[13] = 0.f; ncur[14] = 0.f; ncur[15] = 1.f;
-  for (int i = 0; i < 16; ++i) st->cur[i] = ncur[i];
-  st->iterations += 1;
-  if (a.final_step) { for (int i = 0; i < 16; ++i) st->pose[i] = ncur[i]; st->tracked = 1; }
+  store_partial(acc, a.partials + (size_t)(a.step & 1) * KF_ICP_MAX_WG * 32, s_wave);
 }
 
 // ---- loop control ---------------------------------------------------------------------------------------------------
 // mode 0: frame 0 (no tracking, "tracked"); mode 1: start of a Gauss-Newton loop
 __global__ void k_track_begin(KfTrackState* st, int mode) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  st->status = KF_TRACK_OK; st->iterations = 0; st->converged = 0; st->ticket = 0u;
+  st->status = KF_TRACK_OK; st->iterations = 0; st->converged = 0;
   if (mode == 0) { st->tracked = 1; return; }
   st->tracked = 0;
-  for (int i = 0; i < 16; ++i) st->cur[i] = st->pose[i];                    // ICP.cpp:62
+  for (int i = 0; i < 16; ++i) st->cur[0][i] = st->pose[i];                 // ICP.cpp:62
   kf_mat44_inverse(st->pose, st->last_inv);                                // ICP.cpp:63 last_transform_inv = _pose.getInverse()
 }
 
-// SDF loop that ran out of iterations without converging still commits (SDF.cpp:103-105)
-__global__ void k_sdf_end(KfTrackState* st) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (st->status == KF_TRACK_OK && !st->tracked) { for (int i = 0; i < 16; ++i) st->pose[i] = st->cur[i]; st->tracked = 1; }
+// Last launch of a loop: fold + apply the final step (a.step = number of steps launched), then commit _pose (ICP.cpp:84,
+// SDF.cpp:103).  With use_state == 0 it only leaves the 27 sums in track->reduced (per-call wrappers).
+__global__ void __launch_bounds__(ICP_THREADS) k_track_finish(TrackArgs a) {
+  __shared__ float s_cur[16], s_linv[16], s_tot[32 * 32];
+  __shared__ int s_code;
+  KfTrackState* st = a.track;
+  if (!a.use_state) {
+    fold_partials(a.partials + (size_t)((a.step + 1) & 1) * KF_ICP_MAX_WG * 32, a.n_prev_wg, s_tot);
+    if (threadIdx.x < 27) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
+    return;
+  }
+  if (!step_prologue(a, s_cur, s_linv, s_tot, &s_code)) return;            // lost or converged: already recorded
+  if (threadIdx.x < 16) st->pose[threadIdx.x] = s_cur[threadIdx.x];
+  if (threadIdx.x == 0) st->tracked = 1;
 }
 
 static inline KfCam to_cam(const kf_camera_params* p) {
   KfCam c; c.cols = (int)p->cols; c.rows = (int)p->rows; c.cx = p->cx; c.cy = p->cy; c.fx = p->fx; c.fy = p->fy; return c;
 }
-static inline int track_grid(int npx) {
+static inline int track_grid(int npx) {           // SDF tracker: 256 lanes, grid-stride
   int g = kf_div_up(npx, TRK_THREADS * 4);
   return g < 1 ? 1 : (g > KF_ICP_MAX_WG ? KF_ICP_MAX_WG : g);
 }
+static inline int icp_grid(int npx) { return kf_div_up(npx, ICP_THREADS * ICP_PX); }   // ICP: every pixel exactly once
 
 extern "C" int kf_set_pose(kf_ctx* c, const kf_mat44* pose) {
   if (!c || !pose) return KF_ERR_ARG;
@@ -370,8 +478,12 @@ extern "C" int kf_cal_point_to_plane_solver_params(kf_ctx* c, uint32_t level, co
   a.cam = to_cam(cam);
   for (int i = 0; i < 16; ++i) { a.cur_val.m[i] = cur->m[i]; a.linv_val.m[i] = last_inv->m[i]; }
   a.dist_thres = dist_thres; a.sin_thres = sin_thres;
-  a.partials = c->icp_partials; a.track = c->track; a.solve = 0; a.final_step = 0;
-  hipLaunchKernelGGL(k_icp_step, dim3(track_grid(a.cam.cols * a.cam.rows)), dim3(TRK_THREADS), 0, c->stream, a);
+  a.partials = c->icp_partials; a.track = c->track;
+  const int grid = icp_grid(a.cam.cols * a.cam.rows);
+  if (grid > KF_ICP_MAX_WG) return KF_ERR_ARG;
+  hipLaunchKernelGGL(k_icp_step, dim3(grid), dim3(ICP_THREADS), 0, c->stream, a);
+  a.step = 1; a.n_prev_wg = grid;
+  hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, a);
   return (int)hipGetLastError();
 }
 
@@ -379,10 +491,13 @@ extern "C" int kf_cal_sdf_solver_params(kf_ctx* c, const kf_camera_params* cam, 
   if (!c || !cam || !cur) return KF_ERR_ARG;
   if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
   TrackArgs a; memset(&a, 0, sizeof(a));
-  a.cam = to_cam(cam); a.vol = c->vol; a.depth = c->trunced_depth;
+  a.cam = to_cam(cam); a.vol = c->vol; a.depth = c->trunced_depth; a.sdf = 1;
   for (int i = 0; i < 16; ++i) a.cur_val.m[i] = cur->m[i];
-  a.partials = c->icp_partials; a.track = c->track; a.solve = 0;
-  hipLaunchKernelGGL(k_sdf_step, dim3(track_grid(c->cols * c->rows)), dim3(TRK_THREADS), 0, c->stream, a);
+  a.partials = c->icp_partials; a.track = c->track;
+  const int grid = track_grid(c->cols * c->rows);
+  hipLaunchKernelGGL(k_sdf_step, dim3(grid), dim3(TRK_THREADS), 0, c->stream, a);
+  a.step = 1; a.n_prev_wg = grid;
+  hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, a);
   return (int)hipGetLastError();
 }
 
@@ -413,16 +528,23 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
     cams[l].cols = cams[l - 1].cols / 2; cams[l].rows = cams[l - 1].rows / 2;
     cams[l].cx = cams[l - 1].cx / 2; cams[l].cy = cams[l - 1].cy / 2; cams[l].fx = cams[l - 1].fx / 2; cams[l].fy = cams[l - 1].fy / 2;
   }
-  for (int l = c->levels - 1; l >= 0; --l)
+  TrackArgs a; memset(&a, 0, sizeof(a));
+  a.use_state = 1;
+  a.dist_thres = icp->dist_thres; a.sin_thres = icp->norm_sin_thres; a.dist_shake = icp->dist_shake; a.angle_shake = icp->angle_shake;
+  a.partials = c->icp_partials; a.track = c->track;
+  int step = 0, prev_grid = 0;
+  for (int l = c->levels - 1; l >= 0; --l)                   // coarse -> fine, ICP.cpp:65
     for (int it = 0; it < iters[l]; ++it) {
-      TrackArgs a; memset(&a, 0, sizeof(a));
       a.new_v = c->new_v[l]; a.new_n = c->new_n[l]; a.model_v = c->model_v[l]; a.model_n = c->model_n[l];
       a.cam = to_cam(&cams[l]);
-      a.cur_ptr = c->track->cur; a.linv_ptr = c->track->last_inv;
-      a.dist_thres = icp->dist_thres; a.sin_thres = icp->norm_sin_thres; a.dist_shake = icp->dist_shake; a.angle_shake = icp->angle_shake;
-      a.partials = c->icp_partials; a.track = c->track; a.solve = 1; a.final_step = (l == 0 && it == iters[0] - 1) ? 1 : 0;
-      hipLaunchKernelGGL(k_icp_step, dim3(track_grid(a.cam.cols * a.cam.rows)), dim3(TRK_THREADS), 0, c->stream, a);
+      a.step = step; a.consume = step > 0; a.n_prev_wg = prev_grid;
+      const int grid = icp_grid(a.cam.cols * a.cam.rows);
+      if (grid > KF_ICP_MAX_WG) return KF_ERR_ARG;
+      hipLaunchKernelGGL(k_icp_step, dim3(grid), dim3(ICP_THREADS), 0, c->stream, a);
+      prev_grid = grid; ++step;
     }
+  a.step = step; a.consume = 1; a.n_prev_wg = prev_grid;
+  hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, a);
   kf_evt_end(c, KF_STAGE_TRACK);
   return (int)hipGetLastError();
 }
@@ -436,15 +558,20 @@ extern "C" int kf_sdf_track(kf_ctx* c, uint32_t frame_id, const kf_sdf_tracker_p
   }
   kf_evt_begin(c, KF_STAGE_TRACK);
   hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, 1);
+  TrackArgs a; memset(&a, 0, sizeof(a));
+  a.use_state = 1; a.sdf = 1;
+  a.cam = to_cam(cam); a.vol = c->vol; a.depth = c->trunced_depth;
+  a.dist_shake = sp->dist_shake; a.angle_shake = sp->angle_shake;
+  a.partials = c->icp_partials; a.track = c->track;
+  const int grid = track_grid(c->cols * c->rows);
+  int step = 0;
   for (uint32_t it = 0; it < sp->max_iter_nums; ++it) {
-    TrackArgs a; memset(&a, 0, sizeof(a));
-    a.cam = to_cam(cam); a.vol = c->vol; a.depth = c->trunced_depth;
-    a.cur_ptr = c->track->cur;
-    a.dist_shake = sp->dist_shake; a.angle_shake = sp->angle_shake;
-    a.partials = c->icp_partials; a.track = c->track; a.solve = 1; a.final_step = (it + 1 == sp->max_iter_nums) ? 1 : 0;
-    hipLaunchKernelGGL(k_sdf_step, dim3(track_grid(c->cols * c->rows)), dim3(TRK_THREADS), 0, c->stream, a);
+    a.step = step; a.consume = step > 0; a.n_prev_wg = grid;
+    hipLaunchKernelGGL(k_sdf_step, dim3(grid), dim3(TRK_THREADS), 0, c->stream, a);
+    ++step;
   }
-  hipLaunchKernelGGL(k_sdf_end, dim3(1), dim3(64), 0, c->stream, c->track);
+  a.step = step; a.consume = step > 0; a.n_prev_wg = grid;
+  hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, a);
   kf_evt_end(c, KF_STAGE_TRACK);
   return (int)hipGetLastError();
 }

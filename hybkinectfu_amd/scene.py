@@ -5,7 +5,10 @@ delivers 16-bit millimetre depth, 0 = invalid (src/FrameData.h:57,70).  No datas
 bench and the parity tests render an analytic scene in float64 and quantise it to that sensor contract.
 
 Scene S: the interior of an axis-aligned box [m, size-m]^3 (m = 0.25*size) seen through its open front
-face, plus a sphere of radius 0.15*size at the volume centre.  Camera k = pose0 o small circular motion
+face, plus a sphere of radius 0.15*size at the volume centre and four satellite spheres (radius 0.05*size) placed
+asymmetrically in front of it.  The satellites are an addition to SURVEY.md's sketch: box + one sphere leaves one
+translation almost unconstrained inside the 2 m integration gate, and the reference solves its 6x6 normal equations in
+fp32 in world coordinates, so on that scene last-bit differences decide the pose (see DESIGN.md "Tracking parity").  Camera k = pose0 o small circular motion
 (radius 2 cm, period 100 frames, yaw +-1 degree), pose0 = reference initial pose (src/HybKinectfu.cpp:51-54).
 """
 import math
@@ -19,6 +22,10 @@ STOCK = dict(
     icp_thre_dist=0.1, icp_thre_sin_angle=0.1, camera_shake_dist=0.3, camera_shake_angle=0.3,
     sdf_max_iter_nums=6, max_triangle_num=6500000,
 )
+
+
+# (centre / size, radius / size): the central sphere of SURVEY.md's Scene S and four satellites
+SPHERES = [(0.5, 0.5, 0.5, 0.15), (0.36, 0.40, 0.30, 0.05), (0.66, 0.37, 0.34, 0.05), (0.40, 0.65, 0.38, 0.05), (0.63, 0.62, 0.28, 0.05)]
 
 
 def vga_camera(scale=1):
@@ -67,17 +74,18 @@ def render_depth_mm(pose, cam, size, sphere=True, plane_depth=None):
     hit = (tfar > np.maximum(tnear, 0.0))
     depth = np.where(hit, tfar, 0.0)                                  # interior wall = exit point of the box
     if sphere:
-        ctr = np.array([size / 2.0] * 3)
-        r = 0.15 * size
-        oc = o - ctr
         a = np.sum(d * d, axis=-1)
-        b = 2.0 * (d @ oc)
-        c = float(oc @ oc) - r * r
-        disc = b * b - 4 * a * c
-        with np.errstate(invalid="ignore"):
-            ts = (-b - np.sqrt(disc)) / (2 * a)
-        sph = (disc > 0) & (ts > 0)
-        depth = np.where(sph & ((ts < depth) | (depth == 0)), ts, depth)
+        for (cx_, cy_, cz_, rr) in SPHERES:
+            ctr = np.array([cx_, cy_, cz_]) * size
+            r = rr * size
+            oc = o - ctr
+            b = 2.0 * (d @ oc)
+            c = float(oc @ oc) - r * r
+            disc = b * b - 4 * a * c
+            with np.errstate(invalid="ignore"):
+                ts = (-b - np.sqrt(disc)) / (2 * a)
+            sph = (disc > 0) & (ts > 0)
+            depth = np.where(sph & ((ts < depth) | (depth == 0)), ts, depth)
     mm = np.floor(depth * 1000.0 + 0.5)
     return np.clip(mm, 0, 65535).astype(np.uint16)
 

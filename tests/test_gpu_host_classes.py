@@ -1,0 +1,86 @@
+"""GPU: the C++ host classes (HybKinectfu / CameraPoseFinderICP / CameraPoseFinderSDF / MeshGeneratorMarchingcube) run a
+short sequence end to end; poses are compared with the CPU oracle running the same per-frame path."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from hybkinectfu_amd import host_app as H
+from hybkinectfu_amd import scene as S
+
+pytestmark = pytest.mark.gpu
+P = S.STOCK
+
+
+def oracle_sequence(res, size, cam, trunc, n, sdf=False):
+    ocam = O.Cam.make(*cam)
+    vol = O.OVolume(res, size, P["volume_max_weight"])
+    pose = S.pose0(size)
+    poses, tracked = [], []
+    mv = mn = None
+    for k in range(n):
+        mm = S.render_depth_mm(S.trajectory_pose(k, size), cam, size)
+        tr = O.trunc_depth(O.depth_mm_to_m(mm), P["depth_trunc_min"], P["depth_trunc_max"])
+        fl = O.bilateral(tr, P["filter_sigma_pixel"], P["filter_sigma_depth"])
+        v = O.depth_to_vertices(fl, ocam)
+        nn = O.vertices_to_normals(v)
+        ok = True
+        if k > 0:
+            if sdf:
+                ok, pose, _ = O.sdf_estimate(vol, tr, ocam, P["sdf_max_iter_nums"], P["camera_shake_dist"], P["camera_shake_angle"], pose)
+            else:
+                ok, pose = O.icp_estimate(O.pyramid(v, 3), O.pyramid(nn, 3, True), O.pyramid(mv, 3), O.pyramid(mn, 3, True), ocam,
+                                          P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"], pose)
+        if ok:
+            O.integrate(vol, tr, nn, None, False, False, pose, trunc, 2.0, ocam, ocam)
+        mv, mn, _ = O.raycast(vol, False, pose, 0.7 * trunc, ocam, P["depth_trunc_min"], P["depth_trunc_max"])
+        poses.append(np.array(pose).copy()); tracked.append(ok)
+    return poses, tracked, vol
+
+
+@pytest.mark.parametrize("host_loop", [False, True])
+def test_hybkinectfu_icp_sequence(host_loop):
+    res, size, cam = 128, 3.0, S.vga_camera()
+    trunc = 5 * size / res
+    n = 5
+    o_poses, o_tracked, ovol = oracle_sequence(res, size, cam, trunc, n)
+    app = H.App(res, size, cam, host_loop=host_loop, sdf_trunc=trunc, max_triangles=600000)
+    for k in range(n):
+        mm = S.render_depth_mm(S.trajectory_pose(k, size), cam, size)
+        ok = app.process_frame(mm, k)
+        tracked, pose = app.pose()
+        assert ok == o_tracked[k] == True
+        gt = S.trajectory_pose(k, size)
+        # End to end the two sides do NOT see identical tracker inputs (device __expf in the bilateral filter, a volume fused
+        # with last-bit-different poses), and the reference solves its 6x6 normal equations in fp32 in WORLD coordinates
+        # (condition number ~1e6 on this scene), so last-bit input differences move the weakly constrained direction by
+        # up to ~1 mm on either implementation.  The 1e-4 m / 1e-4 rad bar is asserted where it is meaningful -- identical
+        # tracker inputs -- in test_gpu_parity.py::test_icp_system_and_track.  Here: same verdicts, both near the truth.
+        assert np.max(np.abs(pose[:3, 3] - o_poses[k][:3, 3])) < 2e-3, (k, pose, o_poses[k])
+        assert np.max(np.abs(pose[:3, :3] - o_poses[k][:3, :3])) < 2e-3
+        assert np.max(np.abs(pose[:3, 3] - gt[:3, 3])) < 6e-3
+    ntri = app.generate_mesh()
+    otris = O.marching_cubes(ovol, False, 300 * size / res, 600000)
+    assert abs(ntri - len(otris)) <= 0.05 * len(otris)          # the volumes differ only through the mm-level pose differences
+    path = "/tmp/hybkf_test_mesh.obj"
+    ok, nv, nf = app.save_mesh(path)
+    assert ok and os.path.getsize(path) > 1000 and nf <= ntri and nv < 3 * ntri // 2
+    txt = open(path).read().splitlines()
+    assert sum(1 for l in txt if l.startswith("v ")) == nv and sum(1 for l in txt if l.startswith("f ")) == nf
+    app.close()
+
+
+def test_hybkinectfu_sdf_tracker_sequence():
+    res, size, cam = 128, 3.0, S.vga_camera()
+    trunc = 5 * size / res
+    n = 4
+    o_poses, o_tracked, _ = oracle_sequence(res, size, cam, trunc, n, sdf=True)
+    app = H.App(res, size, cam, sdf_tracker=True, sdf_trunc=trunc)
+    for k in range(n):
+        ok = app.process_frame(S.render_depth_mm(S.trajectory_pose(k, size), cam, size), k)
+        tracked, pose = app.pose()
+        assert ok == o_tracked[k]
+        if ok:
+            assert np.max(np.abs(pose - o_poses[k])) < 2e-3, (k, pose, o_poses[k])
+    app.close()

@@ -185,7 +185,9 @@ def _tracking_case(res, size, cam, trunc, n_warm=2):
     return ctx, ovol, pose, nxt, ocam, (v, n, ov, on, tr)
 
 
-@pytest.mark.parametrize("res,cam,trunc", [(64, mid_cam(), 0.1), (128, S.vga_camera(), 0.05)])
+# truncation = 5 voxels: thinner bands leave the raycast gradient taps at grazing walls unobserved (no model normals there),
+# the 6x6 system then loses rank and the fp32 solve of the reference is meaningless on either side
+@pytest.mark.parametrize("res,cam,trunc", [(64, mid_cam(), 5 * 3.0 / 64), (128, S.vga_camera(), 5 * 3.0 / 128)])
 def test_icp_system_and_track(res, cam, trunc):
     size = 3.0
     ctx, ovol, pose, nxt, ocam, (v, n, ov, on, tr) = _tracking_case(res, size, cam, trunc)
@@ -221,7 +223,7 @@ def test_icp_system_and_track(res, cam, trunc):
 
 def test_icp_lost_keeps_pose():
     """Shake threshold 0 -> the first step is rejected: findCameraPose false, pose unchanged, integrate skipped."""
-    ctx, ovol, pose, nxt, ocam, maps = _tracking_case(64, 3.0, mid_cam(), 0.1)
+    ctx, ovol, pose, nxt, ocam, maps = _tracking_case(64, 3.0, mid_cam(), 5 * 3.0 / 64)
     ctx.set_pose(pose)
     before = ctx.stats()["weight_gt0"]
     ctx.icp_track(1, P["icp_thre_dist"], P["icp_thre_sin_angle"], 0.0, 0.0)
@@ -234,7 +236,7 @@ def test_icp_lost_keeps_pose():
 
 
 def test_sdf_system_and_track():
-    size, res, cam, trunc = 3.0, 64, mid_cam(), 0.15
+    size, res, cam, trunc = 3.0, 64, mid_cam(), 5 * 3.0 / 64
     ctx, ovol, pose, nxt, ocam, (v, n, ov, on, tr) = _tracking_case(res, size, cam, trunc, n_warm=3)
     sd, sf, valid = O.sdf_system(ovol, tr, ocam, pose)
     g = ctx.sdf_system(pose)

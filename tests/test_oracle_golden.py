@@ -37,8 +37,8 @@ def test_reference_recorded_smoke_numbers():
     assert len(O.marching_cubes(vol, False, 300 * size / res, 6500000)) == 34656
 
 
-@pytest.mark.parametrize("name,res,cam,trunc", [("s32", 32, (64, 48, 31.5, 23.5, 52.5, 52.5), 0.2),
-                                                ("s64", 64, (160, 120, 79.5, 59.5, 131.25, 131.25), 0.1)])
+@pytest.mark.parametrize("name,res,cam,trunc", [("s32", 32, (64, 48, 31.5, 23.5, 52.5, 52.5), 5 * 3.0 / 32),
+                                                ("s64", 64, (160, 120, 79.5, 59.5, 131.25, 131.25), 5 * 3.0 / 64)])
 def test_oracle_matches_golden(name, res, cam, trunc):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     size = 3.0

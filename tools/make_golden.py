@@ -71,5 +71,5 @@ def case(name, res, size, cam, trunc, n_frames):
 
 
 if __name__ == "__main__":
-    case("s32", 32, 3.0, (64, 48, 31.5, 23.5, 52.5, 52.5), 0.2, 2)
-    case("s64", 64, 3.0, (160, 120, 79.5, 59.5, 131.25, 131.25), 0.1, 2)
+    case("s32", 32, 3.0, (64, 48, 31.5, 23.5, 52.5, 52.5), 5 * 3.0 / 32, 2)
+    case("s64", 64, 3.0, (160, 120, 79.5, 59.5, 131.25, 131.25), 5 * 3.0 / 64, 2)
