@@ -28,10 +28,12 @@ P = S.STOCK
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def workload(n_gpus):
-    if n_gpus == 1:
+def workload(n_gpus, name="auto"):
+    if name == "auto":
+        name = "c2" if n_gpus == 1 else "c4"
+    if name == "c2":
         return dict(name="C2", res=512, size=4.0, cam=S.vga_camera(), trunc_max=P["depth_trunc_max"], integ_dist=P["integrate_depth_trunc"],
-                    desc="C2: synthetic 640x480 depth stream (Scene S), 512^3 @ 4 m TSDF, 3-level ICP 10/5/4, 1xMI355X")
+                    desc="C2: synthetic 640x480 depth stream (Scene S), 512^3 @ 4 m TSDF, 3-level ICP 10/5/4, %dxMI355X" % n_gpus)
     # C4: depth gates raised to the volume size so the whole 6 m volume is exercised
     return dict(name="C4", res=1024, size=6.0, cam=S.vga_camera(), trunc_max=6.0, integ_dist=6.0,
                 desc="C4: synthetic 640x480 depth (Scene S), 1024^3 @ 6 m TSDF, z-slab per GPU, %d GPUs" % n_gpus)
@@ -70,6 +72,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="extra instrumented pass: per-stage milliseconds to stderr")
+    ap.add_argument("--config", default="auto", choices=["auto", "c2", "c4"],
+                    help="auto: C2 (512^3 @ 4 m) on 1 GPU, C4 (1024^3 @ 6 m, z-slabs) on N > 1, as BASELINE.json's metric states")
+    ap.add_argument("--force-slab", action="store_true", help="run the z-slab pipeline (and its collectives) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -82,11 +87,16 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_slab:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    wl = workload(world)
+    wl = workload(world, args.config)
     cam, res, size = wl["cam"], wl["res"], wl["size"]
     kcam = K.camera(*cam)
     period = 100
@@ -95,7 +105,7 @@ def main():
     dev_frames = torch.from_numpy(frames.astype(np.int16)).cuda()        # u16 bits, resident in HBM
     frame_bytes = cam[0] * cam[1] * 2
 
-    if world == 1:
+    if world == 1 and not args.force_slab:
         from hybkinectfu_amd.pipeline import SingleGpuPipeline as Pipe
         pipe = Pipe(kcam, res, size, wl, device=local_rank)
     else:

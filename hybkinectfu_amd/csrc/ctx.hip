@@ -29,6 +29,7 @@ extern "C" int kf_destroy(kf_ctx* c) {
   if (!c) return KF_ERR_ARG;
   hipSetDevice(c->cfg.device);
   if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->own_stream) hipStreamSynchronize(c->own_stream);
   void* ptrs[] = {c->depth_mm, c->raw_depth, c->trunced_depth, c->filtered_depth, c->raw_rgb, c->raycast_rgb, c->icp_partials,
                   c->track, c->counters, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macro, c->active_bricks,
                   c->tile_max_depth, c->triangles, c->mc_block_counts};
@@ -41,6 +42,7 @@ extern "C" int kf_destroy(kf_ctx* c) {
   }
   for (int s = 0; s < 8; ++s) for (int k = 0; k < 2; ++k) for (int i = 0; i < 64; ++i) if (c->ev[s][k][i]) hipEventDestroy(c->ev[s][k][i]);
   if (c->host_pinned) hipHostFree(c->host_pinned);
+  if (c->own_stream) c->stream = c->own_stream;
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -133,6 +135,15 @@ extern "C" int kf_synchronize(kf_ctx* c) {
   return 0;
 }
 extern "C" void* kf_stream(kf_ctx* c) { return c ? (void*)c->stream : nullptr; }
+// Adopt a caller-owned HIP stream (e.g. the stream torch.distributed/RCCL work is ordered on) for everything the context
+// enqueues from now on; the context's own stream is kept for destruction.  Pass NULL to return to the private stream.
+extern "C" int kf_set_stream(kf_ctx* c, void* hip_stream) {
+  if (!c) return KF_ERR_ARG;
+  KF_CHECK(hipStreamSynchronize(c->stream));
+  if (!c->own_stream) c->own_stream = c->stream;
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return 0;
+}
 
 extern "C" int kf_stored_z_range(kf_ctx* c, uint32_t* z_begin, uint32_t* z_end) {
   if (!c || !z_begin || !z_end) return KF_ERR_ARG;

@@ -12,6 +12,7 @@
 //     updated-voxel count and the tsdf/weight bits match the CPU oracle exactly;
 //   * per-brick flags (observed / has-negative) are maintained here; raycast and marching cubes use them to skip space.
 #include "kf_internal.h"
+#include <stdlib.h>
 
 struct IntegrateArgs {
   KfVolume vol;
@@ -105,8 +106,10 @@ __global__ void __launch_bounds__(256) k_integrate_cull(IntegrateArgs a) {
   a.queue[pos] = (unsigned)slot;
 }
 
-// pass 2: one workgroup per queued brick, one lane per x-adjacent voxel pair (16 contiguous bytes).
-template <bool HAS_COLOR>
+// pass 2: one workgroup walks the queue BR bricks at a time, one lane per x-adjacent voxel pair (16 contiguous bytes) of
+// each brick.  The phases of the BR bricks are interleaved (all projections, all depth gathers, all predicates, all 16-byte
+// loads, all updates) so a workgroup keeps BR x 4 KiB of HBM requests in flight instead of one dependent chain at a time.
+template <bool HAS_COLOR, int BR>
 __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
   const KfVolume& v = a.vol;
   const unsigned n_active = a.cnt->n_active_bricks;
@@ -118,80 +121,95 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
   unsigned upd_total = 0;
   if (threadIdx.x == 0) s_upd = 0;
   __syncthreads();
-  for (unsigned qi = blockIdx.x; qi < n_active; qi += gridDim.x) {
-    const unsigned slot = a.queue[qi];
-    const int bx = (int)(slot % v.nb), by = (int)((slot / v.nb) % v.nb), bz = (int)(slot / ((unsigned)v.nb * v.nb)) + v.bz0;
-    const int y = by * 8 + ly, z = bz * 8 + lz;
-    // tsdfVolume.h:38-49 voxel centre; Mat.h:230-238 row*vector summed left to right; the (x,y) part is shared by the pair
-    const float wy = ((float)y + 0.5f) * cell, wz = ((float)z + 0.5f) * cell;
-    float4* p = reinterpret_cast<float4*>(v.tw + (size_t)slot * KF_BRICK_VOX) + threadIdx.x;
-    unsigned flags = 0, n_upd = 0;
-    // Phase A for both voxels of the pair: project and issue the depth gathers back to back (one memory round trip, not two)
-    float pfx[2], pfy[2], pfz[2], d[2]; int pix[2]; bool ok[2];
+  for (unsigned q0 = blockIdx.x * BR; q0 < n_active; q0 += gridDim.x * BR) {
+    unsigned slot[BR]; int bx[BR], by[BR], bz[BR];
+    float pfx[BR][2], pfy[BR][2], pfz[BR][2], d[BR][2]; int pix[BR][2]; bool ok[BR][2];
+    // Phase A: project every voxel (tsdfVolume.h:38-49 voxel centre; Mat.h:230-238 row*vector summed left to right)
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int x = bx * 8 + lx + k;
-      const float wx = ((float)x + 0.5f) * cell;
-      pfx[k] = m0 * wx + m1 * wy + m2 * wz + m3 * 1.0f;
-      pfy[k] = m4 * wx + m5 * wy + m6 * wz + m7 * 1.0f;
-      pfz[k] = m8 * wx + m9 * wy + m10 * wz + m11 * 1.0f;
-      ok[k] = pfz[k] > 0.f;                                                                 // :39 `if (pf.z <= 0) continue`
-      int2 sp = make_int2(0, 0);
-      if (ok[k]) sp = kf_project(kf3(pfx[k], pfy[k], pfz[k]), a.dcam);
-      ok[k] = ok[k] && !(sp.x >= a.dcam.cols - 1 || sp.y >= a.dcam.rows - 1 || sp.x < 1 || sp.y < 1);   // :43
-      pix[k] = ok[k] ? sp.y * a.dcam.cols + sp.x : 0;
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) d[k] = ok[k] ? a.depth[pix[k]] : 0.f;
-    // Phase B: the reference's remaining predicates (:50-67), then one 16-byte read-modify-write for the pair
-    uchar4 col[2]; float normalz[2]; bool upd[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      upd[k] = ok[k] && d[k] != 0.f;                                                        // :50
-      col[k] = make_uchar4(0, 0, 0, 0); normalz[k] = 0.f;
-      if (HAS_COLOR) {
-        if (upd[k]) {
-          normalz[k] = a.normals[pix[k]].z;
-          const int cxp = kf_to_int((double)(pfx[k] * 525 / pfz[k] + 320)), cyp = kf_to_int((double)(pfy[k] * 525 / pfz[k] + 240));   // :56-57
-          upd[k] = !(cxp >= a.rcam.cols - 1 || cyp >= a.rcam.rows - 1 || cxp < 1 || cyp < 1);
-          if (upd[k]) col[k] = a.rgb[(size_t)cyp * a.rcam.cols + cxp];
-        }
-      }
-      upd[k] = upd[k] && (d[k] < a.max_dist) && ((d[k] - pfz[k]) > -a.sdf_trunc);          // :64, :67
-    }
-    if (upd[0] || upd[1]) {
-      float4 q = *p;
+    for (int b = 0; b < BR; ++b) {
+      const bool live = q0 + b < n_active;
+      slot[b] = live ? a.queue[q0 + b] : 0u;
+      bx[b] = (int)(slot[b] % v.nb); by[b] = (int)((slot[b] / v.nb) % v.nb); bz[b] = (int)(slot[b] / ((unsigned)v.nb * v.nb)) + v.bz0;
+      const float wy = ((float)(by[b] * 8 + ly) + 0.5f) * cell, wz = ((float)(bz[b] * 8 + lz) + 0.5f) * cell;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        if (!upd[k]) continue;
-        const float sdf = d[k] - pfz[k];
-        const float tsdf = fminf(1.0f, sdf / a.sdf_trunc);
-        const float ot = k ? q.z : q.x, ow = k ? q.w : q.y;
-        const float nw = fminf(ow + 1.f, v.max_weight);                                     // tsdfVolume.h:65
-        const float nt = (ot * ow + tsdf * 1.f) / (ow + 1.f);                               // tsdfVolume.h:66
-        if (k) { q.z = nt; q.w = nw; } else { q.x = nt; q.y = nw; }
-        if (HAS_COLOR) {
-          // :72 `(color_angled?fminf(1.0,abs(normalz)/0.75):1.0)*2.0` -- the division and the doubling run in double
-          const float wc = a.color_angled ? (float)((double)fminf(1.0f, (float)((double)fabsf(normalz[k]) / 0.75)) * 2.0) : 2.0f;
-          uchar4* cp = v.color + (size_t)slot * KF_BRICK_VOX + threadIdx.x * 2 + k;
-          const uchar4 oc = *cp;
-          const float c0 = fminf(255.0f, ((float)oc.x * ow + (float)col[k].x * wc) / (ow + wc));   // tsdfVolume.h:68-70
-          const float c1 = fminf(255.0f, ((float)oc.y * ow + (float)col[k].y * wc) / (ow + wc));
-          const float c2 = fminf(255.0f, ((float)oc.z * ow + (float)col[k].z * wc) / (ow + wc));
-          *cp = make_uchar4((unsigned char)c0, (unsigned char)c1, (unsigned char)c2, 0);
-        }
-        ++n_upd;
-        flags |= KF_FLAG_OBSERVED | (nt < 0.f ? KF_FLAG_HASNEG : 0u);
+        const float wx = ((float)(bx[b] * 8 + lx + k) + 0.5f) * cell;
+        pfx[b][k] = m0 * wx + m1 * wy + m2 * wz + m3 * 1.0f;
+        pfy[b][k] = m4 * wx + m5 * wy + m6 * wz + m7 * 1.0f;
+        pfz[b][k] = m8 * wx + m9 * wy + m10 * wz + m11 * 1.0f;
+        ok[b][k] = live && pfz[b][k] > 0.f;                                                 // :39 `if (pf.z <= 0) continue`
+        int2 sp = make_int2(0, 0);
+        if (ok[b][k]) sp = kf_project(kf3(pfx[b][k], pfy[b][k], pfz[b][k]), a.dcam);
+        ok[b][k] = ok[b][k] && !(sp.x >= a.dcam.cols - 1 || sp.y >= a.dcam.rows - 1 || sp.x < 1 || sp.y < 1);   // :43
+        pix[b][k] = ok[b][k] ? sp.y * a.dcam.cols + sp.x : 0;
       }
-      *p = q;
     }
-    upd_total += n_upd;
-    // brick flags: each wave ORs its own bits into the brick's byte with a fire-and-forget 32-bit atomic -- no barrier and
-    // no read-modify-write round trip on the brick loop's critical path (the four waves of a brick never wait for each other)
-    const unsigned wflags = (__ballot(flags & KF_FLAG_OBSERVED) ? KF_FLAG_OBSERVED : 0u) | (__ballot(flags & KF_FLAG_HASNEG) ? KF_FLAG_HASNEG : 0u);
-    if (wflags && (threadIdx.x & 63) == 0) {
-      atomicOr(reinterpret_cast<unsigned*>(v.flags) + (slot >> 2), wflags << (8u * (slot & 3u)));
-      if (wflags & KF_FLAG_HASNEG) v.macro[((size_t)(bz >> 2) * v.nm + (by >> 2)) * v.nm + (bx >> 2)] = 1;   // 4 bricks per macro edge
+    // depth gathers of all BR x 2 voxels back to back (L2-resident image)
+#pragma unroll
+    for (int b = 0; b < BR; ++b)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) d[b][k] = ok[b][k] ? a.depth[pix[b][k]] : 0.f;
+    // Phase B: the reference's remaining predicates (:50-67)
+    uchar4 col[BR][2]; float normalz[BR][2]; bool upd[BR][2];
+#pragma unroll
+    for (int b = 0; b < BR; ++b)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        upd[b][k] = ok[b][k] && d[b][k] != 0.f;                                             // :50
+        col[b][k] = make_uchar4(0, 0, 0, 0); normalz[b][k] = 0.f;
+        if (HAS_COLOR) {
+          if (upd[b][k]) {
+            normalz[b][k] = a.normals[pix[b][k]].z;
+            const int cxp = kf_to_int((double)(pfx[b][k] * 525 / pfz[b][k] + 320)), cyp = kf_to_int((double)(pfy[b][k] * 525 / pfz[b][k] + 240));   // :56-57
+            upd[b][k] = !(cxp >= a.rcam.cols - 1 || cyp >= a.rcam.rows - 1 || cxp < 1 || cyp < 1);
+            if (upd[b][k]) col[b][k] = a.rgb[(size_t)cyp * a.rcam.cols + cxp];
+          }
+        }
+        upd[b][k] = upd[b][k] && (d[b][k] < a.max_dist) && ((d[b][k] - pfz[b][k]) > -a.sdf_trunc);   // :64, :67
+      }
+    // one 16-byte read-modify-write per lane and brick, only where a voxel of the pair passed; the loads go out together
+    float4* p[BR]; float4 q[BR];
+#pragma unroll
+    for (int b = 0; b < BR; ++b) {
+      p[b] = reinterpret_cast<float4*>(v.tw + (size_t)slot[b] * KF_BRICK_VOX) + threadIdx.x;
+      q[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (upd[b][0] || upd[b][1]) q[b] = *p[b];
+    }
+#pragma unroll
+    for (int b = 0; b < BR; ++b) {
+      unsigned flags = 0;
+      if (upd[b][0] || upd[b][1]) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          if (!upd[b][k]) continue;
+          const float sdf = d[b][k] - pfz[b][k];
+          const float tsdf = fminf(1.0f, sdf / a.sdf_trunc);
+          const float ot = k ? q[b].z : q[b].x, ow = k ? q[b].w : q[b].y;
+          const float nw = fminf(ow + 1.f, v.max_weight);                                   // tsdfVolume.h:65
+          const float nt = (ot * ow + tsdf * 1.f) / (ow + 1.f);                             // tsdfVolume.h:66
+          if (k) { q[b].z = nt; q[b].w = nw; } else { q[b].x = nt; q[b].y = nw; }
+          if (HAS_COLOR) {
+            // :72 `(color_angled?fminf(1.0,abs(normalz)/0.75):1.0)*2.0` -- the division and the doubling run in double
+            const float wc = a.color_angled ? (float)((double)fminf(1.0f, (float)((double)fabsf(normalz[b][k]) / 0.75)) * 2.0) : 2.0f;
+            uchar4* cp = v.color + (size_t)slot[b] * KF_BRICK_VOX + threadIdx.x * 2 + k;
+            const uchar4 oc = *cp;
+            const float c0 = fminf(255.0f, ((float)oc.x * ow + (float)col[b][k].x * wc) / (ow + wc));   // tsdfVolume.h:68-70
+            const float c1 = fminf(255.0f, ((float)oc.y * ow + (float)col[b][k].y * wc) / (ow + wc));
+            const float c2 = fminf(255.0f, ((float)oc.z * ow + (float)col[b][k].z * wc) / (ow + wc));
+            *cp = make_uchar4((unsigned char)c0, (unsigned char)c1, (unsigned char)c2, 0);
+          }
+          ++upd_total;
+          flags |= KF_FLAG_OBSERVED | (nt < 0.f ? KF_FLAG_HASNEG : 0u);
+        }
+        *p[b] = q[b];
+      }
+      // brick flags: each wave ORs its own bits into the brick's byte with a fire-and-forget 32-bit atomic -- no barrier and
+      // no read-modify-write round trip on the loop's critical path (the four waves of a brick never wait for each other)
+      const unsigned wflags = (__ballot(flags & KF_FLAG_OBSERVED) ? KF_FLAG_OBSERVED : 0u) | (__ballot(flags & KF_FLAG_HASNEG) ? KF_FLAG_HASNEG : 0u);
+      if (wflags && (threadIdx.x & 63) == 0) {
+        atomicOr(reinterpret_cast<unsigned*>(v.flags) + (slot[b] >> 2), wflags << (8u * (slot[b] & 3u)));
+        if (wflags & KF_FLAG_HASNEG) v.macro[((size_t)(bz[b] >> 2) * v.nm + (by[b] >> 2)) * v.nm + (bx[b] >> 2)] = 1;   // 4 bricks per macro edge
+      }
     }
   }
   // N_upd: wave sum -> LDS -> ONE atomic per workgroup, spread over 64 counter lines
@@ -228,8 +246,14 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   hipLaunchKernelGGL(k_integrate_cull, dim3((unsigned)((c->n_stored_bricks + 255) / 256)), dim3(256), 0, c->stream, a);
   unsigned grid = (unsigned)(c->n_stored_bricks < 4096 ? c->n_stored_bricks : 4096);
   kf_evt_begin(c, KF_STAGE_INTEGRATE_KERNEL);
-  if (has_color) hipLaunchKernelGGL(k_integrate_bricks<true>, dim3(grid), dim3(256), 0, c->stream, a);
-  else hipLaunchKernelGGL(k_integrate_bricks<false>, dim3(grid), dim3(256), 0, c->stream, a);
+  if (has_color) hipLaunchKernelGGL((k_integrate_bricks<true, 1>), dim3(grid), dim3(256), 0, c->stream, a);
+  else {
+    static int br = 0;                                   // bricks in flight per workgroup: tuning knob, default 2
+    if (!br) { const char* e = getenv("KF_INTEGRATE_BR"); br = e ? atoi(e) : 2; if (br != 1 && br != 2 && br != 4) br = 2; }
+    if (br == 1) hipLaunchKernelGGL((k_integrate_bricks<false, 1>), dim3(grid), dim3(256), 0, c->stream, a);
+    else if (br == 2) hipLaunchKernelGGL((k_integrate_bricks<false, 2>), dim3(grid), dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_integrate_bricks<false, 4>), dim3(grid), dim3(256), 0, c->stream, a);
+  }
   kf_evt_end(c, KF_STAGE_INTEGRATE_KERNEL);
   kf_evt_end(c, KF_STAGE_INTEGRATE);
   return (int)hipGetLastError();

@@ -67,7 +67,8 @@ struct KfCounters {
 
 struct kf_ctx {
   kf_config cfg;
-  hipStream_t stream;
+  hipStream_t stream;                 // where work is enqueued (private, or adopted through kf_set_stream)
+  hipStream_t own_stream;             // the private stream once another one has been adopted
   int cols, rows;
   int levels;
   int lvl_cols[KF_MAX_LEVELS], lvl_rows[KF_MAX_LEVELS];

@@ -19,6 +19,7 @@ struct RaycastArgs {
   const float* pose;             // device pointer or null -> pose_val
   KfMat pose_val;
   float4* out_v; float4* out_n; uchar4* out_rgb;
+  float* out_t;                  // optional: ray parameter of the first crossing this context detected (+inf: none) -- z-slab merge
   float inc, near_plane, far_plane;
   int has_color;
 };
@@ -55,6 +56,7 @@ __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
   const int pix = y * a.cam.cols + x;
   float4 out_v = make_float4(0.f, 0.f, 0.f, 0.f), out_n = make_float4(0.f, 0.f, 0.f, 0.f);
   uchar4 out_c = make_uchar4(0, 0, 0, 0);
+  float t_cross = __builtin_huge_valf();
   const float* T = a.pose ? a.pose : a.pose_val.m;
   // raycastKernel :136-150
   const float3 cam_dir = kf_normalize(kf_depth_to_skeleton((unsigned)x, (unsigned)y, 1.0f, a.cam));
@@ -101,9 +103,11 @@ __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
       // tsdfvolume::getVoxel(world) tsdfVolume.h:81-97: nearest voxel, index clamped
       int gx = kf_to_int((double)(pos.x * rf / S)), gy = kf_to_int((double)(pos.y * rf / S)), gz = kf_to_int((double)(pos.z * rf / S));
       gx = max(0, min(gx, R - 1)); gy = max(0, min(gy, R - 1)); gz = max(0, min(gz, R - 1));
-      const bool stored = gz >= zs0 && gz < zs1;
+      // only samples whose voxel this context OWNS can be its crossing candidates (the whole volume on one GPU; with
+      // z-slabs the neighbour's layers are stored as halo and serve the previous-sample / trilinear / gradient reads only)
+      const bool owned = gz >= v.own_z0 && gz < v.own_z1;
       size_t slot = 0; unsigned flag = 0;
-      if (stored) { slot = kf_brick_slot(v, gx >> 3, gy >> 3, gz >> 3); flag = v.flags[slot]; }
+      if (owned) { slot = kf_brick_slot(v, gx >> 3, gy >> 3, gz >> 3); flag = v.flags[slot]; }
       const size_t idx = slot * KF_BRICK_VOX + (size_t)(((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7));
       if (!(flag & KF_FLAG_HASNEG)) {
         // level 2: tsdf >= 0 everywhere in this 8^3 brick: not the negative side of a crossing
@@ -122,6 +126,7 @@ __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
           have_last = true;
         }
         if (last_sdf > 0.0f) {                                             // zero crossing :83
+          t_cross = t;
           float ftdt, ft;
           if (!kf_interpolate_sdf(v, pos, ftdt)) break;
           if (!kf_interpolate_sdf(v, last_pos, ft)) break;
@@ -140,11 +145,12 @@ __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
     }
   }
   a.out_v[pix] = out_v; a.out_n[pix] = out_n;
+  if (a.out_t) a.out_t[pix] = t_cross;
   if (a.has_color) a.out_rgb[pix] = out_c;
 }
 
-extern "C" int kf_raycast_volume(kf_ctx* c, int has_color, const kf_mat44* transform, const kf_raycast_params* rp,
-                                 const kf_camera_params* cam, float near_plane, float far_plane) {
+static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, const kf_raycast_params* rp, const kf_camera_params* cam,
+                          float near_plane, float far_plane, float* out_t, float4* out_v, float4* out_n) {
   if (!c || !rp || !cam) return KF_ERR_ARG;
   if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
   if (has_color && (!c->vol.color || !c->raycast_rgb)) return KF_ERR_STATE;
@@ -153,11 +159,35 @@ extern "C" int kf_raycast_volume(kf_ctx* c, int has_color, const kf_mat44* trans
   a.cam.cols = (int)cam->cols; a.cam.rows = (int)cam->rows; a.cam.cx = cam->cx; a.cam.cy = cam->cy; a.cam.fx = cam->fx; a.cam.fy = cam->fy;
   if (transform) { for (int i = 0; i < 16; ++i) a.pose_val.m[i] = transform->m[i]; a.pose = nullptr; }
   else a.pose = c->track->pose;
-  a.out_v = c->model_v[0]; a.out_n = c->model_n[0]; a.out_rgb = c->raycast_rgb;
+  a.out_v = out_v ? out_v : c->model_v[0]; a.out_n = out_n ? out_n : c->model_n[0]; a.out_rgb = c->raycast_rgb; a.out_t = out_t;
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
   dim3 grid(kf_div_up(c->cols, 16), kf_div_up(c->rows, 16));
   kf_evt_begin(c, KF_STAGE_RAYCAST);
   hipLaunchKernelGGL(k_raycast, grid, dim3(256), 0, c->stream, a);
   kf_evt_end(c, KF_STAGE_RAYCAST);
   return (int)hipGetLastError();
+}
+
+extern "C" int kf_raycast_volume(kf_ctx* c, int has_color, const kf_mat44* transform, const kf_raycast_params* rp,
+                                 const kf_camera_params* cam, float near_plane, float far_plane) {
+  return raycast_launch(c, has_color, transform, rp, cam, near_plane, far_plane, nullptr, nullptr, nullptr);
+}
+
+// z-slab variant: this context marches every ray but reports only crossings whose negative sample lies in the voxel layers it
+// owns.  dev_t[pixel] = ray parameter of that crossing (+inf if none), dev_v / dev_n = the vertex / normal it produced
+// (zeros when the reference would have given up at that crossing).  The caller reduces over the slabs -- first crossing
+// along the ray wins, exactly the reference's sequential march -- and hands the result back with kf_set_model_maps_device.
+extern "C" int kf_raycast_volume_slab(kf_ctx* c, int has_color, const kf_mat44* transform, const kf_raycast_params* rp,
+                                      const kf_camera_params* cam, float near_plane, float far_plane,
+                                      float* dev_t, float* dev_v, float* dev_n) {
+  if (!dev_t || !dev_v || !dev_n) return KF_ERR_ARG;
+  return raycast_launch(c, has_color, transform, rp, cam, near_plane, far_plane, dev_t, (float4*)dev_v, (float4*)dev_n);
+}
+
+extern "C" int kf_set_model_maps_device(kf_ctx* c, const float* dev_v, const float* dev_n) {
+  if (!c || !dev_v || !dev_n) return KF_ERR_ARG;
+  const size_t bytes = (size_t)c->cols * c->rows * sizeof(float4);
+  KF_CHECK(hipMemcpyAsync(c->model_v[0], dev_v, bytes, hipMemcpyDeviceToDevice, c->stream));
+  KF_CHECK(hipMemcpyAsync(c->model_n[0], dev_n, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
 }

@@ -82,7 +82,7 @@ SYMBOLS = [
     "kf_icp_track", "kf_sdf_track", "kf_read_track_result", "kf_integrate_volume", "kf_raycast_volume",
     "kf_marching_cubes", "kf_clear_triangles", "kf_triangle_count", "kf_read_triangles", "kf_download_map",
     "kf_upload_map", "kf_download_volume", "kf_upload_volume", "kf_get_volume_stats", "kf_stored_z_range",
-    "kf_stage_timers", "kf_read_stage_ms",
+    "kf_stage_timers", "kf_read_stage_ms", "kf_set_stream", "kf_raycast_volume_slab", "kf_set_model_maps_device",
 ]
 
 
@@ -263,6 +263,18 @@ class Context:
         tp = C.byref(Mat44.of(pose)) if pose is not None else None
         _chk(self.lib.kf_raycast_volume(self.h, int(has_color), tp, C.byref(rp), C.byref(self.cam), C.c_float(near), C.c_float(far)),
              "kf_raycast_volume")
+
+    def raycast_slab(self, pose, inc, near, far, dev_t, dev_v, dev_n):
+        rp = RaycastParams(inc)
+        tp = C.byref(Mat44.of(pose)) if pose is not None else None
+        _chk(self.lib.kf_raycast_volume_slab(self.h, 0, tp, C.byref(rp), C.byref(self.cam), C.c_float(near), C.c_float(far),
+                                             C.c_void_p(dev_t), C.c_void_p(dev_v), C.c_void_p(dev_n)), "kf_raycast_volume_slab")
+
+    def set_model_maps_device(self, dev_v, dev_n):
+        _chk(self.lib.kf_set_model_maps_device(self.h, C.c_void_p(dev_v), C.c_void_p(dev_n)), "kf_set_model_maps_device")
+
+    def set_stream(self, hip_stream):
+        _chk(self.lib.kf_set_stream(self.h, C.c_void_p(hip_stream)), "kf_set_stream")
 
     def marching_cubes(self, thr, has_color=False):
         _chk(self.lib.kf_marching_cubes(self.h, int(has_color), C.c_float(thr)), "kf_marching_cubes")

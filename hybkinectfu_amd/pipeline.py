@@ -45,3 +45,100 @@ class SingleGpuPipeline:
 
     def close(self):
         self.ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# z-slab partitioning over the GPUs of one node: one process per GPU, torch.distributed over RCCL.
+# ---------------------------------------------------------------------------------------------------------------------------
+SLAB_HALO = 16      # voxel layers stored AND integrated on each side of the owned range: covers the previous ray sample
+                    # (ray increment <= ~6 voxels at 1024^3 @ 6 m), the 2x2x2 trilinear taps and the +-1-cell gradient taps
+
+
+def slab_ranges(res, world):
+    """Owned z range [z0, z1) of every rank: contiguous, brick (8-layer) aligned, sizes differing by at most one brick."""
+    nb = res // 8
+    base, extra = divmod(nb, world)
+    out, b = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((b * 8, (b + n) * 8))
+        b += n
+    return out
+
+
+def merge_candidates(t, v, n, all_reduce_min, all_reduce_sum_i32):
+    """First crossing along each ray wins (the reference's sequential march, raycastingVolume.cu:83-116).
+
+    t [H,W] float32 (+inf = no crossing in this slab), v / n [H,W,4] float32 candidates of this rank.  A ray sample belongs to
+    exactly one slab, so the minimum t has a unique owner; everyone else contributes zero bits and an INTEGER sum returns the
+    winner's vertex/normal bit for bit (a float sum would turn -0.0 into +0.0).  Works on any backend (RCCL on GPU, gloo on CPU).
+    """
+    import torch
+    tmin = t.clone()
+    all_reduce_min(tmin)
+    win = (t == tmin) & torch.isfinite(t)
+    vi = v.view(torch.int32) * win.unsqueeze(-1).to(torch.int32)
+    ni = n.view(torch.int32) * win.unsqueeze(-1).to(torch.int32)
+    all_reduce_sum_i32(vi)
+    all_reduce_sum_i32(ni)
+    return vi.view(torch.float32), ni.view(torch.float32)
+
+
+class SlabPipeline:
+    """One rank of the z-slab partitioned pipeline.
+
+    Replicated per rank (cheap, and bitwise identical everywhere): preprocess, pyramids, the whole ICP loop.
+    Partitioned: TSDF integrate (own slab + halo, no communication) and raycast (own samples only), followed by one
+    MIN all-reduce of the crossing parameter and one integer SUM all-reduce of the winning vertex/normal maps.
+    """
+
+    def __init__(self, kcam, res, size, wl=None, rank=0, world=1, device=0, max_triangles=0):
+        import torch
+        import torch.distributed as dist
+        wl = wl or {}
+        self.dist, self.torch = dist, torch
+        self.rank, self.world = rank, world
+        self.trunc_max = wl.get("trunc_max", P["depth_trunc_max"])
+        self.integ_dist = wl.get("integ_dist", P["integrate_depth_trunc"])
+        self.inc = P["raycast_increment_factor"] * P["integrate_sdf_trunc"]
+        self.slab = slab_ranges(res, world)[rank]
+        self.ctx = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=max_triangles, device=device,
+                             slab=self.slab, halo=SLAB_HALO)
+        self.ctx.set_pose(S.pose0(size))
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)     # kernels and RCCL collectives ordered on one stream
+        dev = torch.device("cuda", device)
+        self.t = torch.empty((kcam.rows, kcam.cols), dtype=torch.float32, device=dev)
+        self.v = torch.empty((kcam.rows, kcam.cols, 4), dtype=torch.float32, device=dev)
+        self.n = torch.empty((kcam.rows, kcam.cols, 4), dtype=torch.float32, device=dev)
+
+    def process_frame_device(self, dev_mm_ptr, frame_id):
+        c, dist = self.ctx, self.dist
+        c.set_depth_mm_device(dev_mm_ptr)
+        c.preprocess(P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
+        c.icp_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+        c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist)
+        c.raycast_slab(None, self.inc, P["depth_trunc_min"], self.trunc_max, self.t.data_ptr(), self.v.data_ptr(), self.n.data_ptr())
+        v, n = merge_candidates(self.t, self.v, self.n,
+                                lambda x: dist.all_reduce(x, op=dist.ReduceOp.MIN),
+                                lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM))
+        self._keep = (v, n)                                               # alive until the copies below have run
+        c.set_model_maps_device(v.data_ptr(), n.data_ptr())
+
+    def sync(self):
+        self.ctx.sync()
+        self.torch.cuda.synchronize()
+
+    def stats(self):
+        return self.ctx.stats()
+
+    def stage_timers(self, mask):
+        self.ctx.stage_timers(mask)
+
+    def read_stage_ms(self):
+        return self.ctx.read_stage_ms()
+
+    def track_result(self):
+        return self.ctx.track_result()
+
+    def close(self):
+        self.ctx.close()

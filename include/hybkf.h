@@ -93,6 +93,7 @@ int kf_create(const kf_config* cfg, kf_ctx** out);
 int kf_destroy(kf_ctx* ctx);
 int kf_synchronize(kf_ctx* ctx);
 void* kf_stream(kf_ctx* ctx);                        /* hipStream_t of the context */
+int kf_set_stream(kf_ctx* ctx, void* hip_stream);    /* enqueue on a caller-owned hipStream_t (NULL: back to the private one) */
 int kf_reset_volume(kf_ctx* ctx);                    /* tsdfvolume::init clearData  src/cuda/tsdfVolume.h:29-37 */
 
 /* HybKinectfu::copyFrameToGPU  src/HybKinectfu.cpp:63-96 : u16 mm -> f32 m ((float)((double)mm*0.001)) into raw_depth */
@@ -144,6 +145,15 @@ int kf_integrate_volume(kf_ctx* ctx, int has_color, int use_angle_weight_color, 
 /* cudaRaycastingVolume  src/cuda/raycastingVolume.cu:158-176.  transform == NULL: device-resident pose. */
 int kf_raycast_volume(kf_ctx* ctx, int has_color, const kf_mat44* transform, const kf_raycast_params* raycast_params,
                       const kf_camera_params* depth_camera, float near_plane, float far_plane);
+
+/* z-slab partitioning (no counterpart in the single-GPU reference).  Each slab context marches every
+ * ray and reports the first crossing whose negative sample lies in the layers it owns: dev_t[px] = its ray parameter (+inf
+ * if none), dev_v/dev_n[px] = float4 vertex / normal (zeros when the reference's march gives up at that crossing).  The
+ * caller takes, per pixel, the entry with the smallest t over all slabs and returns the merged maps to every context. */
+int kf_raycast_volume_slab(kf_ctx* ctx, int has_color, const kf_mat44* transform, const kf_raycast_params* raycast_params,
+                           const kf_camera_params* depth_camera, float near_plane, float far_plane,
+                           float* dev_t, float* dev_v, float* dev_n);
+int kf_set_model_maps_device(kf_ctx* ctx, const float* dev_v, const float* dev_n);   /* model_{vertices,normals}_pyramid[0] <- device buffers */
 
 /* cudaMarchingcube  src/cuda/marchingcube.cu:154-164.  Triangles are appended after those already stored
  * (the reference never clears its counter, src/cuda/MarchingcubeData.h:56,99) in the canonical order (z, y, x, k). */

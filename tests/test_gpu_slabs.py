@@ -1,0 +1,82 @@
+"""GPU (one device): N z-slab contexts, merged exactly as SlabPipeline merges them over RCCL, reproduce the whole-volume
+context bit for bit -- TSDF planes, update counts, raycast maps, tracked pose, marching-cubes triangle sequence."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from hybkinectfu_amd import lib as K
+from hybkinectfu_amd import pipeline as PL
+from hybkinectfu_amd import scene as S
+
+pytestmark = pytest.mark.gpu
+P = S.STOCK
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_slabs_equal_whole_volume(world):
+    cam = S.vga_camera()
+    kcam = K.camera(*cam)
+    size, res = 3.0, 128
+    trunc = 5 * size / res
+    inc = 0.7 * trunc
+    whole = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=600000)
+    slabs = [K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=600000, slab=r, halo=PL.SLAB_HALO)
+             for r in PL.slab_ranges(res, world)]
+    dev = torch.device("cuda", 0)
+    bufs = [(torch.empty((cam[1], cam[0]), dtype=torch.float32, device=dev), torch.empty((cam[1], cam[0], 4), dtype=torch.float32, device=dev),
+             torch.empty((cam[1], cam[0], 4), dtype=torch.float32, device=dev)) for _ in slabs]
+    pose = S.pose0(size)
+    for c in [whole] + slabs:
+        c.set_pose(pose)
+    for k in range(3):
+        mm = S.render_depth_mm(S.trajectory_pose(k, size), cam, size)
+        for c in [whole] + slabs:
+            c.upload_depth_mm(mm)
+            c.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+            c.icp_track(k, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+            c.integrate(None, trunc, 2.5)
+        ok_w, pose_w, _, _ = whole.track_result()
+        assert ok_w
+        for c in slabs:                                           # replicated tracking: identical bits on every rank
+            ok_s, pose_s, _, _ = c.track_result()
+            assert ok_s and np.array_equal(pose_s.view(np.uint32), pose_w.view(np.uint32))
+        whole.raycast(None, inc, P["depth_trunc_min"], P["depth_trunc_max"])
+        for c, (t, v, n) in zip(slabs, bufs):
+            c.raycast_slab(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], t.data_ptr(), v.data_ptr(), n.data_ptr())
+            c.sync()
+        # the collective, emulated in-process: MIN over ranks, then integer SUM of the masked candidates
+        ts = torch.stack([b[0] for b in bufs])
+        tmin = ts.min(dim=0).values
+        merged = []
+        for which in (1, 2):
+            acc = torch.zeros((cam[1], cam[0], 4), dtype=torch.int32, device=dev)
+            for b in bufs:
+                win = (b[0] == tmin) & torch.isfinite(b[0])
+                acc += b[which].view(torch.int32) * win.unsqueeze(-1).to(torch.int32)
+            merged.append(acc.view(torch.float32).contiguous())
+        wv, wn = whole.download_map(K.MAP_MODEL_VERTICES), whole.download_map(K.MAP_MODEL_NORMALS)
+        assert int((wv[..., 3] != 0).sum()) > 10000
+        assert np.array_equal(merged[0].cpu().numpy().view(np.uint32), wv.view(np.uint32))
+        assert np.array_equal(merged[1].cpu().numpy().view(np.uint32), wn.view(np.uint32))
+        for c in slabs:
+            c.set_model_maps_device(merged[0].data_ptr(), merged[1].data_ptr())
+            c.sync()
+    # volumes: owned layers of every slab equal the whole volume; update counts add up over the owned layers
+    tw, ww = whole.download_volume()
+    for c, (z0, z1) in zip(slabs, PL.slab_ranges(res, world)):
+        t, w = c.download_volume(z0, z1)
+        assert np.array_equal(t.view(np.uint32), tw[z0:z1].view(np.uint32)) and np.array_equal(w, ww[z0:z1])
+    assert sum(c.stats()["weight_gt0"] for c in slabs) == whole.stats()["weight_gt0"]
+    # marching cubes: slab-major concatenation == whole-volume sequence
+    thr = 300 * size / res
+    whole.marching_cubes(thr)
+    wt = whole.triangles()
+    parts = []
+    for c in slabs:
+        c.marching_cubes(thr)
+        parts.append(c.triangles())
+    cat = np.concatenate(parts)
+    assert len(wt) > 1000 and len(cat) == len(wt) and np.array_equal(cat.view(np.uint32), wt.view(np.uint32))
+    for c in [whole] + slabs:
+        c.close()
