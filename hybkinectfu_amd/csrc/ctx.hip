@@ -6,6 +6,11 @@
 #include <stdlib.h>
 #include <new>
 
+// contexts alive per device: the persistent ICP loop needs its workgroups co-resident, which only one context per GPU guarantees
+static int g_live_ctx[64];
+int kf_live_contexts(int device) { return (device >= 0 && device < 64) ? g_live_ctx[device] : 2; }
+extern "C" int kf_debug_live_contexts(int device) { return kf_live_contexts(device); }
+
 extern "C" const char* kf_version(void) { return "hybkf-gfx950 0.1"; }
 
 extern "C" const char* kf_error_string(int s) {
@@ -31,7 +36,7 @@ extern "C" int kf_destroy(kf_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->own_stream) hipStreamSynchronize(c->own_stream);
   void* ptrs[] = {c->depth_mm, c->raw_depth, c->trunced_depth, c->filtered_depth, c->raw_rgb, c->raycast_rgb, c->icp_partials,
-                  c->track, c->counters, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macro, c->active_bricks,
+                  c->track, c->counters, c->grid_barrier, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macro, c->active_bricks,
                   c->tile_max_depth, c->triangles, c->mc_block_counts};
   for (void* p : ptrs) if (p) hipFree(p);
   for (int l = 0; l < KF_MAX_LEVELS; ++l) {
@@ -44,6 +49,7 @@ extern "C" int kf_destroy(kf_ctx* c) {
   if (c->host_pinned) hipHostFree(c->host_pinned);
   if (c->own_stream) c->stream = c->own_stream;
   if (c->stream) hipStreamDestroy(c->stream);
+  if (c->registered && c->cfg.device >= 0 && c->cfg.device < 64) __atomic_fetch_sub(&g_live_ctx[c->cfg.device], 1, __ATOMIC_RELAXED);
   delete c;
   return 0;
 }
@@ -64,6 +70,7 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
   c->cfg = *cfg;
   c->cfg.slab_z_end = z1;
   c->cols = cfg->depth_camera.cols; c->rows = cfg->depth_camera.rows; c->levels = cfg->pyramid_levels;
+  { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess) cu = 0; c->num_cus = cu; }
   int st = 0;
 #define TRY(x) do { st = (x); if (st) { kf_destroy(c); return st; } } while (0)
   TRY((int)hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -85,7 +92,8 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
     lc >>= 1; lr >>= 1;
   }
   TRY(dev_alloc(&c->icp_partials, (size_t)2 * KF_ICP_MAX_WG * 32));      // double-buffered by Gauss-Newton step parity
-  TRY(dev_alloc(&c->track, 1)); TRY(dev_alloc(&c->counters, 1)); TRY(dev_alloc(&c->scratch_mats, 8 * 16));
+  TRY(dev_alloc(&c->track, 1)); TRY(dev_alloc(&c->counters, 1)); TRY(dev_alloc(&c->grid_barrier, 1));
+  TRY((int)hipMemsetAsync(c->grid_barrier, 0, sizeof(KfGridBarrier), c->stream)); TRY(dev_alloc(&c->scratch_mats, 8 * 16));
   TRY((int)hipMemsetAsync(c->track, 0, sizeof(KfTrackState), c->stream));
   TRY((int)hipMemsetAsync(c->counters, 0, sizeof(KfCounters), c->stream));
   // volume: tsdfvolume::init (tsdfVolume.h:29-37), bricked, slab + halo
@@ -114,6 +122,7 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
   TRY(kf_reset_volume(c));
   TRY((int)hipStreamSynchronize(c->stream));
 #undef TRY
+  if (cfg->device >= 0 && cfg->device < 64) { __atomic_fetch_add(&g_live_ctx[cfg->device], 1, __ATOMIC_RELAXED); c->registered = 1; }
   *out = c;
   return 0;
 }

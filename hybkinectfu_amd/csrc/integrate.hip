@@ -30,6 +30,7 @@ struct IntegrateArgs {
   float sdf_trunc, max_dist;
   int has_color, color_angled;
   int tiles_x, tiles_y;
+  int exp_mode;                  // timing experiments only (KF_INTEGRATE_EXP): 1 = no store, 2 = no load/store
 };
 
 
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(256) k_integrate_cull(IntegrateArgs a) {
     if (zn >= dmax + a.sdf_trunc) return;                              // every voxel lies behind every surface it can see
   }
   unsigned pos = atomicAdd(&a.cnt->n_active_bricks, 1u);               // wave-aggregated by the compiler
-  a.queue[pos] = (unsigned)slot;
+  a.queue[pos] = (unsigned)bx | ((unsigned)by << 10) | ((unsigned)(bz - v.bz0) << 20);   // packed brick coordinates: no div/mod to decode
 }
 
 // pass 2: one workgroup walks the queue BR bricks at a time, one lane per x-adjacent voxel pair (16 contiguous bytes) of
@@ -117,19 +118,22 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
   const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8], m9 = m[9], m10 = m[10], m11 = m[11];
   const float cell = v.cell;
   const int lx = (threadIdx.x & 3) * 2, ly = (threadIdx.x >> 2) & 7, lz = threadIdx.x >> 5;
+  const KfRecip rtrunc = kf_recip(a.sdf_trunc);
   __shared__ unsigned s_upd;
   unsigned upd_total = 0;
   if (threadIdx.x == 0) s_upd = 0;
   __syncthreads();
   for (unsigned q0 = blockIdx.x * BR; q0 < n_active; q0 += gridDim.x * BR) {
-    unsigned slot[BR]; int bx[BR], by[BR], bz[BR];
+    unsigned slot[BR], fold[BR]; int bx[BR], by[BR], bz[BR];
     float pfx[BR][2], pfy[BR][2], pfz[BR][2], d[BR][2]; int pix[BR][2]; bool ok[BR][2];
     // Phase A: project every voxel (tsdfVolume.h:38-49 voxel centre; Mat.h:230-238 row*vector summed left to right)
 #pragma unroll
     for (int b = 0; b < BR; ++b) {
       const bool live = q0 + b < n_active;
-      slot[b] = live ? a.queue[q0 + b] : 0u;
-      bx[b] = (int)(slot[b] % v.nb); by[b] = (int)((slot[b] / v.nb) % v.nb); bz[b] = (int)(slot[b] / ((unsigned)v.nb * v.nb)) + v.bz0;
+      const unsigned packed = live ? a.queue[q0 + b] : 0u;
+      bx[b] = (int)(packed & 1023u); by[b] = (int)((packed >> 10) & 1023u); bz[b] = (int)(packed >> 20) + v.bz0;
+      slot[b] = ((unsigned)(bz[b] - v.bz0) * (unsigned)v.nb + (unsigned)by[b]) * (unsigned)v.nb + (unsigned)bx[b];
+      fold[b] = v.flags[slot[b]];                           // current flags: the atomic below is only issued when a bit is new
       const float wy = ((float)(by[b] * 8 + ly) + 0.5f) * cell, wz = ((float)(bz[b] * 8 + lz) + 0.5f) * cell;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -139,7 +143,12 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
         pfz[b][k] = m8 * wx + m9 * wy + m10 * wz + m11 * 1.0f;
         ok[b][k] = live && pfz[b][k] > 0.f;                                                 // :39 `if (pf.z <= 0) continue`
         int2 sp = make_int2(0, 0);
-        if (ok[b][k]) sp = kf_project(kf3(pfx[b][k], pfy[b][k], pfz[b][k]), a.dcam);
+        if (ok[b][k]) {
+          // DepthCamera.h:30-43 `v.x*fx/v.z + cx`, `(int)(p + 0.5)`: both quotients share the divisor pf.z
+          const KfRecip rz = kf_recip(pfz[b][k]);
+          sp.x = kf_round_px(kf_div(pfx[b][k] * a.dcam.fx, rz) + a.dcam.cx);
+          sp.y = kf_round_px(kf_div(pfy[b][k] * a.dcam.fy, rz) + a.dcam.cy);
+        }
         ok[b][k] = ok[b][k] && !(sp.x >= a.dcam.cols - 1 || sp.y >= a.dcam.rows - 1 || sp.x < 1 || sp.y < 1);   // :43
         pix[b][k] = ok[b][k] ? sp.y * a.dcam.cols + sp.x : 0;
       }
@@ -173,7 +182,7 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
     for (int b = 0; b < BR; ++b) {
       p[b] = reinterpret_cast<float4*>(v.tw + (size_t)slot[b] * KF_BRICK_VOX) + threadIdx.x;
       q[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (upd[b][0] || upd[b][1]) q[b] = *p[b];
+      if ((upd[b][0] || upd[b][1]) && a.exp_mode < 2) q[b] = *p[b];
     }
 #pragma unroll
     for (int b = 0; b < BR; ++b) {
@@ -183,10 +192,10 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
         for (int k = 0; k < 2; ++k) {
           if (!upd[b][k]) continue;
           const float sdf = d[b][k] - pfz[b][k];
-          const float tsdf = fminf(1.0f, sdf / a.sdf_trunc);
+          const float tsdf = fminf(1.0f, kf_div(sdf, rtrunc));
           const float ot = k ? q[b].z : q[b].x, ow = k ? q[b].w : q[b].y;
           const float nw = fminf(ow + 1.f, v.max_weight);                                   // tsdfVolume.h:65
-          const float nt = (ot * ow + tsdf * 1.f) / (ow + 1.f);                             // tsdfVolume.h:66
+          const float nt = kf_div(ot * ow + tsdf * 1.f, kf_recip(ow + 1.f));                // tsdfVolume.h:66
           if (k) { q[b].z = nt; q[b].w = nw; } else { q[b].x = nt; q[b].y = nw; }
           if (HAS_COLOR) {
             // :72 `(color_angled?fminf(1.0,abs(normalz)/0.75):1.0)*2.0` -- the division and the doubling run in double
@@ -201,11 +210,14 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
           ++upd_total;
           flags |= KF_FLAG_OBSERVED | (nt < 0.f ? KF_FLAG_HASNEG : 0u);
         }
-        *p[b] = q[b];
+        if (a.exp_mode < 1) *p[b] = q[b];
+        else if (q[b].x == 123.456f) *p[b] = q[b];
       }
-      // brick flags: each wave ORs its own bits into the brick's byte with a fire-and-forget 32-bit atomic -- no barrier and
-      // no read-modify-write round trip on the loop's critical path (the four waves of a brick never wait for each other)
-      const unsigned wflags = (__ballot(flags & KF_FLAG_OBSERVED) ? KF_FLAG_OBSERVED : 0u) | (__ballot(flags & KF_FLAG_HASNEG) ? KF_FLAG_HASNEG : 0u);
+      // brick flags: each wave ORs its NEW bits into the brick's byte with a fire-and-forget 32-bit atomic -- no barrier and
+      // no dependent read-modify-write on the loop's critical path.  Memory-side atomics cost a CU ~50 ns per wave
+      // instruction (MI355X_MICROARCH.md 'Global float atomics'), so the flags read at the top of the iteration gates
+      // them: after the first frames almost no brick changes its flags and no atomic is issued at all.
+      const unsigned wflags = ((__ballot(flags & KF_FLAG_OBSERVED) ? KF_FLAG_OBSERVED : 0u) | (__ballot(flags & KF_FLAG_HASNEG) ? KF_FLAG_HASNEG : 0u)) & ~fold[b];
       if (wflags && (threadIdx.x & 63) == 0) {
         atomicOr(reinterpret_cast<unsigned*>(v.flags) + (slot[b] >> 2), wflags << (8u * (slot[b] & 3u)));
         if (wflags & KF_FLAG_HASNEG) v.macro[((size_t)(bz[b] >> 2) * v.nm + (by[b] >> 2)) * v.nm + (bx[b] >> 2)] = 1;   // 4 bricks per macro edge
@@ -235,6 +247,7 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   a.sdf_trunc = ip->sdf_truncation; a.max_dist = ip->max_integrate_dist;
   a.has_color = has_color; a.color_angled = use_angle_weight_color;
   a.tiles_x = kf_div_up(c->cols, 16); a.tiles_y = kf_div_up(c->rows, 16);
+  { static int em = -1; if (em < 0) { const char* e = getenv("KF_INTEGRATE_EXP"); em = e ? atoi(e) : 0; } a.exp_mode = em; }
   if (transform) {
     for (int i = 0; i < 16; ++i) a.pose_val.m[i] = transform->m[i];
     a.pose = nullptr; a.track = nullptr;
@@ -257,4 +270,35 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   kf_evt_end(c, KF_STAGE_INTEGRATE_KERNEL);
   kf_evt_end(c, KF_STAGE_INTEGRATE);
   return (int)hipGetLastError();
+}
+
+// ---- self-test of kf_div against the compiler's IEEE division (exported for the GPU test-suite) ----------------------------
+__global__ void __launch_bounds__(256) k_selftest_div(unsigned n, unsigned seed, int mode, unsigned* mismatches) {
+  unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  // two xorshift draws -> operands in the ranges the kernels use
+  unsigned s = seed ^ (i * 2654435761u); s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+  unsigned t = s * 1664525u + 1013904223u; t ^= t << 13; t ^= t >> 17; t ^= t << 5;
+  const float u = (float)(s >> 8) * (1.0f / 16777216.0f), w = (float)(t >> 8) * (1.0f / 16777216.0f);
+  float a, b;
+  if (mode == 0) { a = (u * 2.f - 1.f) * 8000.f; b = 1e-4f + w * 20.f; }            // pf.x*fx / pf.z
+  else if (mode == 1) { a = (u * 2.f - 1.f) * 3.f; b = 0.005f + w * 0.5f; }          // sdf / trunc
+  else if (mode == 2) { a = (u * 2.f - 1.f) * 300.f; b = (float)(1 + (t % 300u)); }  // (t*w + tsdf) / (w + 1)
+  else { a = u * 4096.f * (0.5f + w); b = 0.5f + w * 16.f; }                          // pos*R / size
+  const float ref = a / b;
+  const float got = kf_div(a, kf_recip(b));
+  if (__float_as_uint(ref) != __float_as_uint(got)) atomicAdd(mismatches, 1u);
+}
+extern "C" int kf_selftest_div(kf_ctx* c, unsigned n, unsigned seed, int mode, unsigned* mismatches) {
+  if (!c || !mismatches) return KF_ERR_ARG;
+  unsigned* d = nullptr;
+  KF_CHECK(hipMalloc((void**)&d, 4));
+  hipError_t e = hipMemsetAsync(d, 0, 4, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_selftest_div, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, seed, mode, d);
+    e = hipMemcpyAsync(mismatches, d, 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  }
+  hipFree(d);
+  return (int)e;
 }

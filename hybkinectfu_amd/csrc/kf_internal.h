@@ -46,8 +46,13 @@ struct KfTrackState {
   int   tracked;         // result of the last findCameraPose
   int   iterations;
   int   converged;       // SDF tracker: |x| < 1e-3 reached
-  unsigned pad_[4];
+  unsigned arrive;       // arrival counter of the persistent ICP loop's grid barrier (monotonic within a frame)
+  unsigned pad_[3];
 };
+
+// software grid barrier of the persistent ICP loop: every word on its own 128-byte line
+struct KfPaddedCounter { unsigned v; unsigned pad_[31]; };
+struct KfGridBarrier { KfPaddedCounter group[8]; KfPaddedCounter top; KfPaddedCounter gen; };
 
 struct KfCounters {
   unsigned long long n_upd;       // voxels updated by the last integrate
@@ -71,6 +76,8 @@ struct kf_ctx {
   hipStream_t own_stream;             // the private stream once another one has been adopted
   int cols, rows;
   int levels;
+  int registered;                     // counted in the per-device live-context registry
+  int num_cus;                        // compute units of the device (co-residency bound of the persistent ICP loop)
   int lvl_cols[KF_MAX_LEVELS], lvl_rows[KF_MAX_LEVELS];
   // frame maps (CudaDeviceDataMan.h:56-67)
   uint16_t* depth_mm;                 // staging for host uploads
@@ -81,6 +88,7 @@ struct kf_ctx {
   float* icp_partials;                // KF_ICP_MAX_WG x 32 floats
   KfTrackState* track;                // device
   KfCounters* counters;               // device
+  KfGridBarrier* grid_barrier;        // device
   float* scratch_mats;                // device: 8 x 16 floats for host-supplied transforms
   KfVolume vol;
   size_t n_stored_vox, n_stored_bricks;
@@ -147,6 +155,40 @@ __device__ __forceinline__ int kf_to_int(double v) {
   if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
   return (int)v;
 }
+// (int) of a float with the same out-of-range convention, without a trip through fp64
+__device__ __forceinline__ int kf_f2i(float v) {
+  if (!(v > -2147483904.f && v < 2147483648.f)) return (int)0x80000000;
+  return (int)v;
+}
+
+// Correctly rounded fp32 quotient a / b for operands in the normal range: the very FMA sequence hipcc emits for `a / b`
+// (v_rcp_f32, two reciprocal refinements, quotient, two residual corrections; LLVM legalizeFDIV32) minus the v_div_scale /
+// v_div_fixup steps that only act when an exponent is within 2^32 of the fp32 limits.  Splitting it lets a divisor that is
+// shared by several quotients (the voxel's depth pf.z, the truncation distance, the volume size) pay for its reciprocal
+// once.  kf_selftest_div compares it with `/` on the GPU (tests/test_gpu_parity.py::test_exact_division_helper).
+struct KfRecip { float den, r; };
+__device__ __forceinline__ KfRecip kf_recip(float b) {
+  const float r0 = __builtin_amdgcn_rcpf(b);
+  const float e0 = __builtin_fmaf(-b, r0, 1.0f);
+  KfRecip k; k.den = b; k.r = __builtin_fmaf(e0, r0, r0);
+  return k;
+}
+__device__ __forceinline__ float kf_div(float a, const KfRecip& k) {
+  const float q0 = a * k.r;
+  const float e1 = __builtin_fmaf(-k.den, q0, a);
+  const float q1 = __builtin_fmaf(e1, k.r, q0);
+  const float e2 = __builtin_fmaf(-k.den, q1, a);
+  return __builtin_fmaf(e2, k.r, q1);
+}
+// `(int)(p + 0.5)` of DepthCamera.h:42 (double literal) for callers that only accept results >= 1: for p >= 0.5 the double sum
+// is exact and its truncation equals floor(p) + (frac(p) >= 0.5), all exact in fp32; every p < 0.5, NaN or huge value maps to a
+// result the caller rejects in both formulations (0 here, <= 0 or INT_MIN there; saturated INT_MAX here, INT_MIN there).
+__device__ __forceinline__ int kf_round_px(float p) {
+  if (!(p >= 0.5f)) return 0;
+  const float t = floorf(p);
+  return (int)t + ((p - t) >= 0.5f ? 1 : 0);
+}
+
 // DepthCamera.h:19-29
 __device__ __forceinline__ float3 kf_depth_to_skeleton(unsigned ux, unsigned uy, float depth, const KfCam& c) {
   float vx = depth * ((float)ux - c.cx) / c.fx;
@@ -172,7 +214,7 @@ __device__ __forceinline__ bool kf_z_stored(const KfVolume& v, int z) { return z
 // tsdfVolume.h:50-56
 __device__ __forceinline__ int3 kf_world_to_voxel(const KfVolume& v, float3 p) {
   float r = (float)v.res;
-  return make_int3(kf_to_int((double)(p.x * r / v.size)), kf_to_int((double)(p.y * r / v.size)), kf_to_int((double)(p.z * r / v.size)));
+  return make_int3(kf_f2i(p.x * r / v.size), kf_f2i(p.y * r / v.size), kf_f2i(p.z * r / v.size));
 }
 // tsdfVolume.h:151-172
 __device__ __forceinline__ bool kf_interp_params(const KfVolume& v, float3 pos, int3& base, float& a, float& b, float& c) {
@@ -263,5 +305,17 @@ __host__ __device__ static inline void kf_mat44_inverse(const float* e, float* o
 }
 #undef T3
 
+// Sum over each 16-lane row with four DPP row-shift adds (an inclusive scan: lane 15 of a row ends with the row total).
+// One VALU instruction per step and no LDS round trip -- a `__shfl_down` tree costs a ds_bpermute (~110 cycles, serialised
+// by its waitcnt) per step, which made 27 wave sums the most expensive part of a Gauss-Newton step (measured 7.6 us).
+__device__ __forceinline__ float kf_row_scan_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));   // row_shr:1
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));   // row_shr:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));   // row_shr:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));   // row_shr:8
+  return v;
+}
+
 // entry points implemented across the .hip files (internal linkage between translation units)
 int kf_launch_pyramids(kf_ctx* ctx, bool model, bool vertices, bool normals);
+int kf_live_contexts(int device);

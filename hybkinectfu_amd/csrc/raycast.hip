@@ -75,6 +75,7 @@ __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
     // raySample :65-119
     const int R = v.res;
     const float rf = (float)R;
+    const KfRecip rS = kf_recip(S);                                       // `worldPos.x*_resolution.x/_size.x`: shared divisor
     const int zs0 = v.bz0 * KF_BRICK, zs1 = v.bz1 * KF_BRICK;
     float t = tmin, t_prev = tmin;
     float last_sdf = 0.f; bool have_last = true;
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
         }
       }
       // tsdfvolume::getVoxel(world) tsdfVolume.h:81-97: nearest voxel, index clamped
-      int gx = kf_to_int((double)(pos.x * rf / S)), gy = kf_to_int((double)(pos.y * rf / S)), gz = kf_to_int((double)(pos.z * rf / S));
+      int gx = kf_f2i(kf_div(pos.x * rf, rS)), gy = kf_f2i(kf_div(pos.y * rf, rS)), gz = kf_f2i(kf_div(pos.z * rf, rS));
       gx = max(0, min(gx, R - 1)); gy = max(0, min(gy, R - 1)); gz = max(0, min(gz, R - 1));
       // only samples whose voxel this context OWNS can be its crossing candidates (the whole volume on one GPU; with
       // z-slabs the neighbour's layers are stored as halo and serve the previous-sample / trilinear / gradient reads only)
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
       if (sdf < 0.0f) {
         last_pos = kf_add(org, kf_scale(dir, t_prev));                     // the previous sample of the march, recomputed exactly
         if (!have_last) {                                                  // its tsdf was never fetched: fetch it now
-          int lx = kf_to_int((double)(last_pos.x * rf / S)), ly = kf_to_int((double)(last_pos.y * rf / S)), lz = kf_to_int((double)(last_pos.z * rf / S));
+          int lx = kf_f2i(kf_div(last_pos.x * rf, rS)), ly = kf_f2i(kf_div(last_pos.y * rf, rS)), lz = kf_f2i(kf_div(last_pos.z * rf, rS));
           lx = max(0, min(lx, R - 1)); ly = max(0, min(ly, R - 1)); lz = max(0, min(lz, R - 1));
           last_sdf = (lz >= zs0 && lz < zs1) ? v.tw[kf_vox_index(v, lx, ly, lz)].x : 0.f;
           have_last = true;

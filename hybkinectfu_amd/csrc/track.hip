@@ -22,6 +22,7 @@
 // by tolerance (pose within 1e-4 m / 1e-4 rad), as SURVEY.md section 8a row a6 states.
 #include "kf_internal.h"
 #include <string.h>
+#include <stdlib.h>
 
 #define TRK_THREADS 256
 
@@ -277,19 +278,19 @@ __device__ __forceinline__ bool step_prologue(const TrackArgs& a, float* s_cur, 
   return code == STEP_APPLIED;
 }
 
-// wave + workgroup reduction of the 27 sums, written as this workgroup's partial for the NEXT launch to fold
-__device__ __forceinline__ void store_partial(float acc[27], float* partials_out, float* s_wave) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// workgroup reduction of the 27 sums (DPP row totals -> LDS -> fixed-order adds), written as this workgroup's partial for the
+// NEXT launch to fold.  s_rows: 27 x (blockDim / 16) floats.
+__device__ __forceinline__ void store_partial(float acc[27], float* partials_out, float* s_rows) {
+  const int rows = blockDim.x >> 4, row = threadIdx.x >> 4;
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
-    float s = kf_wave_sum(acc[k]);
-    if (lane == 0) s_wave[wave * 32 + k] = s;
+    const float s = kf_row_scan_sum(acc[k]);
+    if ((threadIdx.x & 15) == 15) s_rows[k * rows + row] = s;
   }
   __syncthreads();
   if (threadIdx.x < 27) {
-    const int waves = blockDim.x >> 6;
-    float s = s_wave[threadIdx.x];
-    for (int w = 1; w < waves; ++w) s += s_wave[w * 32 + threadIdx.x];
+    float s = s_rows[threadIdx.x * rows];
+    for (int w = 1; w < rows; ++w) s += s_rows[threadIdx.x * rows + w];
     partials_out[blockIdx.x * 32 + threadIdx.x] = s;
   }
 }
@@ -320,12 +321,12 @@ __device__ __forceinline__ bool icp_finish(const TrackArgs& a, float4 vg, float4
   return true;
 }
 
-// 1024 lanes x 4 pixels per workgroup: 75 / 19 / 5 workgroups at VGA level 0 / 1 / 2, so the next launch folds few partials.
-#define ICP_THREADS 1024
+// 512 lanes x 4 pixels per workgroup: 150 / 38 / 10 workgroups at VGA level 0 / 1 / 2 (few partials to fold, no register spills).
+#define ICP_THREADS 512
 #define ICP_PX 4
 __global__ void __launch_bounds__(ICP_THREADS) k_icp_step(TrackArgs a) {
   __shared__ float s_cur[16], s_linv[16];
-  __shared__ float s_wave[16 * 32], s_tot[32 * 32];
+  __shared__ float s_wave[27 * (ICP_THREADS / 16)], s_tot[(ICP_THREADS / 32) * 32];
   __shared__ int s_code;
   // the lane's own vertices / normals do not depend on the running transform: request them before the fold + solve
   const int npx = a.cam.cols * a.cam.rows;
@@ -363,11 +364,181 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_step(TrackArgs a) {
   store_partial(acc, a.partials + (size_t)(a.step & 1) * KF_ICP_MAX_WG * 32, s_wave);
 }
 
+// ---- persistent ICP: the whole 19-step loop in ONE launch ---------------------------------------------------------------------
+// One 1024-lane workgroup per CU (124 VGPRs -> exactly one per CU), at most 75 of them at VGA, all co-resident.  Between two
+// Gauss-Newton steps the workgroups meet at a software grid barrier built as the guide's hand-off recipe prescribes
+// (MI355X_MICROARCH.md "Valid forms", table row 1): every partial sum is stored write-through (sc1), each storing wave drains
+// its stores, the workgroup meets, ONE lane adds to an agent-scope arrival counter and polls it with sc1 loads, the rest of
+// the workgroup waits at a workgroup barrier, and every later load of the partials is an sc1 load.  No fence, no kernel
+// boundary: a step costs the barrier (~1-2 us) instead of a dependent dispatch (~5 us measured here) plus a cold start of the
+// 30 KB straight-line step code, which is what bounded the one-launch-per-step form at ~22 us per step.
+struct IcpLoopArgs {
+  const float4* new_v[KF_MAX_LEVELS]; const float4* new_n[KF_MAX_LEVELS];
+  const float4* model_v[KF_MAX_LEVELS]; const float4* model_n[KF_MAX_LEVELS];
+  KfCam cam[KF_MAX_LEVELS];
+  int iters[KF_MAX_LEVELS]; int levels;
+  float dist_thres, sin_thres, dist_shake, angle_shake;
+  float* partials;                               // 2 x KF_ICP_MAX_WG x 32, by step parity
+  KfTrackState* track;
+  KfGridBarrier* barrier;
+  int exp_mode;                                  // timing experiments only (KF_ICP_EXP)
+};
+
+__device__ __forceinline__ void fold_partials_sc1(const float* partials, int n_wg, float* s_tot) {
+  const int k = threadIdx.x & 31, part = threadIdx.x >> 5, parts = blockDim.x >> 5;
+  float s = 0.f;
+  if (k < 27) {
+    for (int w = part; w < n_wg; w += 4 * parts) {
+      const int w1 = w + parts, w2 = w + 2 * parts, w3 = w + 3 * parts;
+      const float v0 = __hip_atomic_load(&partials[w * 32 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float v1 = (w1 < n_wg) ? __hip_atomic_load(&partials[w1 * 32 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+      const float v2 = (w2 < n_wg) ? __hip_atomic_load(&partials[w2 * 32 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+      const float v3 = (w3 < n_wg) ? __hip_atomic_load(&partials[w3 * 32 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+      s += v0; s += v1; s += v2; s += v3;
+    }
+  }
+  s_tot[part * 32 + k] = s;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x < 27) {
+    t = s_tot[threadIdx.x];
+    for (int p = 1; p < parts; ++p) t += s_tot[p * 32 + threadIdx.x];
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) s_tot[threadIdx.x] = t;
+  __syncthreads();
+}
+
+#define ICP_SPIN_LIMIT 4000000u
+__global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
+  __shared__ float s_cur[16], s_linv[16];
+  __shared__ float s_wave[27 * (ICP_THREADS / 16)], s_tot[(ICP_THREADS / 32) * 32];
+  __shared__ int s_code, s_abort;
+  KfTrackState* st = L.track;
+  if (threadIdx.x < 16) s_cur[threadIdx.x] = st->pose[threadIdx.x];            // ICP.cpp:62 cur_transform = _pose
+  if (threadIdx.x == 0) s_abort = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) kf_mat44_inverse(s_cur, s_linv);                        // ICP.cpp:63 last_transform_inv
+  __syncthreads();
+  TrackArgs a;
+  a.dist_thres = L.dist_thres; a.sin_thres = L.sin_thres; a.dist_shake = L.dist_shake; a.angle_shake = L.angle_shake; a.sdf = 0;
+  int step = 0, n_prev = 0, applied = 0;
+  // diagnostic build path (KF_ICP_EXP=7): workgroup 0 accumulates shader-clock ticks per segment into track->reduced
+  const bool stamp = L.exp_mode == 7 && blockIdx.x == 0 && threadIdx.x == 0;
+  unsigned long long t_last = 0; float seg[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define KF_STAMP(i) do { if (stamp) { unsigned long long t_now = __builtin_amdgcn_s_memtime(); seg[i] += (float)(t_now - t_last); t_last = t_now; } } while (0)
+  if (stamp) t_last = __builtin_amdgcn_s_memtime();
+  for (int l = L.levels - 1; l >= 0; --l) {                                      // coarse -> fine, ICP.cpp:65
+    a.cam = L.cam[l];
+    const float4* __restrict__ new_v = L.new_v[l]; const float4* __restrict__ new_n = L.new_n[l];
+    const float4* __restrict__ model_v = L.model_v[l]; const float4* __restrict__ model_n = L.model_n[l];
+    const int npx = a.cam.cols * a.cam.rows;
+    const int grid_l = (npx + ICP_THREADS * ICP_PX - 1) / (ICP_THREADS * ICP_PX);
+    const bool has_px = (int)blockIdx.x < grid_l;
+    const int base = blockIdx.x * (ICP_THREADS * ICP_PX) + threadIdx.x;
+    for (int it = 0; it < L.iters[l]; ++it, ++step) {
+      // this lane's own vertices / normals do not depend on the running transform: request them before the fold + solve
+      float4 iv[ICP_PX], in_[ICP_PX];
+#pragma unroll
+      for (int j = 0; j < ICP_PX; ++j) {
+        const int i = base + j * ICP_THREADS;
+        iv[j] = make_float4(0.f, 0.f, 0.f, 0.f); in_[j] = iv[j];
+        if (has_px && i < npx) { iv[j] = new_v[i]; in_[j] = new_n[i]; }
+      }
+      KF_STAMP(0);
+      if (step > 0 && L.exp_mode != 6) {
+        if (L.exp_mode != 3) fold_partials_sc1(L.partials + (size_t)((step + 1) & 1) * KF_ICP_MAX_WG * 32, n_prev, s_tot);
+        KF_STAMP(1);
+        if (L.exp_mode == 1 || L.exp_mode == 3) { if (threadIdx.x == 0) s_code = STEP_APPLIED; __syncthreads(); } else
+        apply_step(a, s_tot, s_cur, &s_code);
+        if (s_code != STEP_APPLIED) {                                            // same verdict in every workgroup
+          if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; }
+          return;
+        }
+        ++applied;
+      }
+      KF_STAMP(2);
+      float acc[27];
+#pragma unroll
+      for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+      if (has_px && L.exp_mode != 2 && L.exp_mode != 6) {
+        float4 vg[ICP_PX], ng[ICP_PX], vt[ICP_PX], nt[ICP_PX]; int mi[ICP_PX];
+#pragma unroll
+        for (int j = 0; j < ICP_PX; ++j) mi[j] = icp_project(a, s_cur, s_linv, iv[j], in_[j], vg[j], ng[j]);
+#pragma unroll
+        for (int j = 0; j < ICP_PX; ++j) {
+          nt[j] = make_float4(0.f, 0.f, 0.f, 0.f); vt[j] = nt[j];
+          if (mi[j] >= 0) { nt[j] = model_n[mi[j]]; vt[j] = model_v[mi[j]]; }
+        }
+#pragma unroll
+        for (int j = 0; j < ICP_PX; ++j) {
+          float row[7];
+          if (mi[j] < 0 || !icp_finish(a, vg[j], ng[j], vt[j], nt[j], row)) continue;
+          int s = 0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 7; ++c) acc[s++] += row[r] * row[c];
+        }
+        KF_STAMP(3);
+        // workgroup partial, stored write-through (sc1) for the other CUs
+        // 16-lane row totals by DPP, one LDS word per (sum, row), then 27 lanes add the 32 row totals in a fixed order
+        const int row = threadIdx.x >> 4;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) { const float sw = kf_row_scan_sum(acc[k]); if ((threadIdx.x & 15) == 15) s_wave[k * (ICP_THREADS / 16) + row] = sw; }
+        __syncthreads();
+        if (threadIdx.x < 27) {
+          float sw = s_wave[threadIdx.x * (ICP_THREADS / 16)];
+          for (int w = 1; w < ICP_THREADS / 16; ++w) sw += s_wave[threadIdx.x * (ICP_THREADS / 16) + w];
+          __hip_atomic_store(L.partials + (size_t)(step & 1) * KF_ICP_MAX_WG * 32 + blockIdx.x * 32 + threadIdx.x, sw,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      KF_STAMP(4);
+      // grid barrier: drain, meet, one lane arrives; everyone else waits at the workgroup barrier behind it.
+      // Two levels so that no word is hammered: workgroups that share blockIdx % 8 (one XCD under round-robin dispatch --
+      // a speed assumption only) arrive on their group's counter, the last of a group arrives on the top counter, the last
+      // of those publishes the generation word with a write-through store; waiters poll only that word (L2-served sc1
+      // loads, no atomic traffic on its line).  Counters are monotonic within the frame (zeroed by k_track_begin).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        KfGridBarrier* gb = L.barrier;
+        const unsigned g = blockIdx.x & 7u, gsize = (gridDim.x + 7u - g) >> 3, ngroups = gridDim.x < 8u ? gridDim.x : 8u;
+        const unsigned t = __hip_atomic_fetch_add(&gb->group[g].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gsize * (unsigned)(step + 1) - 1u) {
+          const unsigned tt = __hip_atomic_fetch_add(&gb->top.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (tt == ngroups * (unsigned)(step + 1) - 1u)
+            __hip_atomic_store(&gb->gen.v, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned spins = 0;
+        while (L.exp_mode != 5 && __hip_atomic_load(&gb->gen.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(step + 1)) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > ICP_SPIN_LIMIT) { s_abort = 1; break; }                  // never spin forever: report instead
+        }
+      }
+      __syncthreads();
+      if (s_abort) { if (threadIdx.x == 0) { st->status = 3; st->tracked = 0; } return; }
+      KF_STAMP(5);
+      n_prev = grid_l;
+    }
+  }
+  if (stamp) { for (int i = 0; i < 6; ++i) st->reduced[20 + i] = seg[i]; }
+  // the last step's system, then commit _pose (ICP.cpp:84)
+  fold_partials_sc1(L.partials + (size_t)((step + 1) & 1) * KF_ICP_MAX_WG * 32, n_prev, s_tot);
+  apply_step(a, s_tot, s_cur, &s_code);
+  if (blockIdx.x != 0) return;
+  if (threadIdx.x < 27 && L.exp_mode != 7) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
+  if (s_code != STEP_APPLIED) { if (threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; } return; }
+  if (threadIdx.x < 16) st->pose[threadIdx.x] = s_cur[threadIdx.x];
+  if (threadIdx.x == 0) { st->tracked = 1; st->iterations = applied + 1; }
+}
+
 // ---- SDF tracker ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(TRK_THREADS) k_sdf_step(TrackArgs a) {
   __shared__ float s_m[7][16];                 // cur, then delta*cur for +w1,-w1,+w2,-w2,+w3,-w3 (CalSDFErrSolverParams.cu:118-133)
   __shared__ float s_linv[16];
-  __shared__ float s_wave[4 * 32], s_tot[32 * 32];
+  __shared__ float s_wave[27 * (TRK_THREADS / 16)], s_tot[32 * 32];
   __shared__ int s_code;
   if (!step_prologue(a, s_m[0], s_linv, s_tot, &s_code)) return;
   const float w_h = 0.001f;                                               // :119 `float w_h = 0.001;`
@@ -427,9 +598,10 @@ __global__ void __launch_bounds__(TRK_THREADS) k_sdf_step(TrackArgs a) {
 
 // ---- loop control ---------------------------------------------------------------------------------------------------
 // mode 0: frame 0 (no tracking, "tracked"); mode 1: start of a Gauss-Newton loop
-__global__ void k_track_begin(KfTrackState* st, int mode) {
+__global__ void k_track_begin(KfTrackState* st, int mode, KfGridBarrier* gb) {
+  if (blockIdx.x == 0 && threadIdx.x < 10 && gb) reinterpret_cast<KfPaddedCounter*>(gb)[threadIdx.x].v = 0u;   // 8 groups + top + gen
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  st->status = KF_TRACK_OK; st->iterations = 0; st->converged = 0;
+  st->status = KF_TRACK_OK; st->iterations = 0; st->converged = 0; st->arrive = 0u;
   if (mode == 0) { st->tracked = 1; return; }
   st->tracked = 0;
   for (int i = 0; i < 16; ++i) st->cur[0][i] = st->pose[i];                 // ICP.cpp:62
@@ -513,7 +685,7 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   if (!c || !icp || !cam0) return KF_ERR_ARG;
   if ((int)icp->pyramid_levels != c->levels || (int)cam0->cols != c->cols || (int)cam0->rows != c->rows) return KF_ERR_ARG;
   if (frame_id == 0) {                                       // ICP.cpp:52-55
-    hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, 0);
+    hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, 0, c->grid_barrier);
     return (int)hipGetLastError();
   }
   int iters[KF_MAX_LEVELS] = {0, 0, 0};                      // ICP.cpp:14-35
@@ -522,11 +694,29 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   kf_evt_begin(c, KF_STAGE_TRACK);
   if ((st = kf_launch_pyramids(c, false, true, true))) return st;       // ICP.cpp:57-60
   if ((st = kf_launch_pyramids(c, true, true, true))) return st;
-  hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, 1);
+  hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, 1, c->grid_barrier);
   kf_camera_params cams[KF_MAX_LEVELS]; cams[0] = *cam0;
   for (int l = 1; l < c->levels; ++l) {                      // ICP.cpp:36-48
     cams[l].cols = cams[l - 1].cols / 2; cams[l].rows = cams[l - 1].rows / 2;
     cams[l].cx = cams[l - 1].cx / 2; cams[l].cy = cams[l - 1].cy / 2; cams[l].fx = cams[l - 1].fx / 2; cams[l].fy = cams[l - 1].fy / 2;
+  }
+  const int grid0 = icp_grid(c->cols * c->rows);
+  static int persistent_env = -1;
+  if (persistent_env < 0) { const char* e = getenv("KF_ICP_PERSISTENT"); persistent_env = e ? atoi(e) : 1; }
+  if (persistent_env && grid0 <= c->num_cus && grid0 <= KF_ICP_MAX_WG && kf_live_contexts(c->cfg.device) == 1) {
+    // every workgroup must be resident at once (software grid barrier): one 1024-lane workgroup per CU, grid0 <= #CUs
+    IcpLoopArgs L; memset(&L, 0, sizeof(L));
+    for (int l = 0; l < c->levels; ++l) {
+      L.new_v[l] = c->new_v[l]; L.new_n[l] = c->new_n[l]; L.model_v[l] = c->model_v[l]; L.model_n[l] = c->model_n[l];
+      L.cam[l] = to_cam(&cams[l]); L.iters[l] = iters[l];
+    }
+    L.levels = c->levels;
+    L.dist_thres = icp->dist_thres; L.sin_thres = icp->norm_sin_thres; L.dist_shake = icp->dist_shake; L.angle_shake = icp->angle_shake;
+    L.partials = c->icp_partials; L.track = c->track; L.barrier = c->grid_barrier;
+    { static int em = -1; if (em < 0) { const char* e = getenv("KF_ICP_EXP"); em = e ? atoi(e) : 0; } L.exp_mode = em; }
+    hipLaunchKernelGGL(k_icp_loop, dim3(grid0), dim3(ICP_THREADS), 0, c->stream, L);
+    kf_evt_end(c, KF_STAGE_TRACK);
+    return (int)hipGetLastError();
   }
   TrackArgs a; memset(&a, 0, sizeof(a));
   a.use_state = 1;
@@ -553,11 +743,11 @@ extern "C" int kf_sdf_track(kf_ctx* c, uint32_t frame_id, const kf_sdf_tracker_p
   if (!c || !sp || !cam) return KF_ERR_ARG;
   if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
   if (frame_id == 0) {                                       // SDF.cpp:46-49
-    hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, 0);
+    hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, 0, c->grid_barrier);
     return (int)hipGetLastError();
   }
   kf_evt_begin(c, KF_STAGE_TRACK);
-  hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, 1);
+  hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, 1, c->grid_barrier);
   TrackArgs a; memset(&a, 0, sizeof(a));
   a.use_state = 1; a.sdf = 1;
   a.cam = to_cam(cam); a.vol = c->vol; a.depth = c->trunced_depth;

@@ -82,7 +82,7 @@ SYMBOLS = [
     "kf_icp_track", "kf_sdf_track", "kf_read_track_result", "kf_integrate_volume", "kf_raycast_volume",
     "kf_marching_cubes", "kf_clear_triangles", "kf_triangle_count", "kf_read_triangles", "kf_download_map",
     "kf_upload_map", "kf_download_volume", "kf_upload_volume", "kf_get_volume_stats", "kf_stored_z_range",
-    "kf_stage_timers", "kf_read_stage_ms", "kf_set_stream", "kf_raycast_volume_slab", "kf_set_model_maps_device",
+    "kf_stage_timers", "kf_read_stage_ms", "kf_set_stream", "kf_raycast_volume_slab", "kf_set_model_maps_device", "kf_selftest_div",
 ]
 
 
@@ -323,6 +323,11 @@ class Context:
         cnt = np.zeros(8, np.uint32)
         _chk(self.lib.kf_read_stage_ms(self.h, _p(ms), _p(cnt)), "kf_read_stage_ms")
         return ms, cnt
+
+    def selftest_div(self, n, seed, mode):
+        m = C.c_uint32(0)
+        _chk(self.lib.kf_selftest_div(self.h, n, seed, mode, C.byref(m)), "kf_selftest_div")
+        return m.value
 
     def sync(self):
         _chk(self.lib.kf_synchronize(self.h), "kf_synchronize")

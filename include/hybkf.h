@@ -172,6 +172,9 @@ int kf_upload_volume(kf_ctx* ctx, uint32_t z_begin, uint32_t z_end, const float*
 int kf_get_volume_stats(kf_ctx* ctx, kf_volume_stats* out);                /* blocking */
 int kf_stored_z_range(kf_ctx* ctx, uint32_t* z_begin, uint32_t* z_end);
 
+/* test hook: counts fp32 quotients where the kernels' split exact-division helper differs from the compiler's `/` (must be 0) */
+int kf_selftest_div(kf_ctx* ctx, unsigned n, unsigned seed, int mode, unsigned* mismatches);
+
 /* Per-stage device timers (hipEvent pairs on the context's stream).  `stage_mask` bit s enables stage s:
  * 0 depth upload/convert, 1 preprocess, 2 track, 3 integrate (all passes), 4 raycast, 5 integrate fusion kernel only,
  * 6 marching cubes, 7 raycast kernel only.  kf_stage_timers resets the accumulators; kf_read_stage_ms blocks and returns

@@ -276,3 +276,12 @@ def test_full_size_integrate_counts_512():
     t, w = ctx.download_volume(0, 256)
     assert np.array_equal(bits(t), bits(ovol.tsdf[:256])) and np.array_equal(bits(w), bits(ovol.weight[:256]))
     ctx.close()
+
+
+def test_exact_division_helper():
+    """The kernels divide through a split exact-division helper (shared reciprocal); it must agree bit for bit with the
+    compiler's IEEE `/` on the operand ranges the kernels use -- 4 x 2^24 random quotients."""
+    ctx = K.Context(K.camera(*small_cam()), 32, 3.0, levels=3)
+    for mode in range(4):
+        assert ctx.selftest_div(1 << 24, 12345 + mode, mode) == 0, mode
+    ctx.close()

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the ICP tracker alone on the C2 stream: fuse 3 frames, then track frame 3 repeatedly from the same pose."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from hybkinectfu_amd import lib as K, scene as S
+P = S.STOCK
+cam, size, res = S.vga_camera(), 4.0, 512
+ctx = K.Context(K.camera(*cam), res, size, P["volume_max_weight"], levels=3)
+ctx.set_pose(S.pose0(size))
+for k in range(4):
+    ctx.upload_depth_mm(S.render_depth_mm(S.trajectory_pose(k, size), cam, size))
+    ctx.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+    ctx.icp_track(k, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+    if k < 3:
+        ctx.integrate(None, P["integrate_sdf_trunc"], P["integrate_depth_trunc"])
+        ctx.raycast(None, 0.035, P["depth_trunc_min"], P["depth_trunc_max"])
+ok, pose, status, iters = ctx.track_result()
+print("tracked", ok, "status", status, "iters", iters)
+ctx.stage_timers(1 << 2)
+for _ in range(50):
+    ctx.icp_track(4, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+ms, cnt = ctx.read_stage_ms()
+print("track stage: %.4f ms per frame (pyramids + begin + loop)" % (ms[2] / cnt[2]))
+if os.environ.get("KF_ICP_EXP") == "7":
+    r = ctx.read_solver_params()
+    names = ["prefetch", "fold", "solve", "pixels", "wavesum+store", "barrier"]
+    print("WG0 lane0 shader ticks per frame: " + ", ".join("%s=%.0f" % (n, r[20 + i]) for i, n in enumerate(names)), "(100 MHz ticks? see s_memtime)")
