@@ -39,11 +39,13 @@ def workload(n_gpus, name="auto"):
                 desc="C4: synthetic 640x480 depth (Scene S), 1024^3 @ 6 m TSDF, z-slab per GPU, %d GPUs" % n_gpus)
 
 
-def cpu_baseline(wl, frames_mm, n_sample=3):
+def cpu_baseline(wl, frames_mm, n_sample=12):
     """The CPU oracle (oracle/, 'port') on the first n_sample frames of the same stream, all host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    cores = O.set_threads(os.cpu_count() or 1)
+    # the GPU box gives one GPU job a 16-core share of the host; more OpenMP threads than that only oversubscribe it
+    # (tools/cpu_scaling.py: integrate is fastest at 16 threads there)
+    cores = O.set_threads(min(16, len(os.sched_getaffinity(0)), os.cpu_count() or 1))
     cam = wl["cam"]
     ocam = O.Cam.make(*cam)
     vol = O.OVolume(wl["res"], wl["size"], P["volume_max_weight"])

@@ -361,18 +361,25 @@ static bool icp_row(int x, int y, const float* new_v, const float* new_n, const 
 void okf_icp_system(const float* new_v, const float* new_n, const float* model_v, const float* model_n,
                     const okf_cam* cam, const float cur[16], const float last_inv[16],
                     float dist_thres, float sin_thres, double* out27d, float* out27f, int* valid) {
-  double accd[27]; float accf[27]; int nvalid = 0;
-  for (int k = 0; k < 27; ++k) { accd[k] = 0; accf[k] = 0; }
   int cols = cam->cols, rows = cam->rows;
+  /* per-row partial sums (rows run in parallel), combined in row order: deterministic for any thread count */
+  double* rowd = (double*)calloc((size_t)rows * 27, sizeof(double));
+  float* rowf = (float*)calloc((size_t)rows * 27, sizeof(float));
+  int* rown = (int*)calloc((size_t)rows, sizeof(int));
+#pragma omp parallel for schedule(static)
   for (int y = 0; y < rows; ++y)
     for (int x = 0; x < cols; ++x) {
       float row[7];
       if (!icp_row(x, y, new_v, new_n, model_v, model_n, *cam, cur, last_inv, dist_thres, sin_thres, row)) continue;
-      ++nvalid;
+      ++rown[y];
       int s = 0;
       for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 7; ++j) { float pr = row[i] * row[j]; accd[s] += (double)pr; accf[s] += pr; ++s; }   /* :92-105 */
+        for (int j = i; j < 7; ++j) { float pr = row[i] * row[j]; rowd[y * 27 + s] += (double)pr; rowf[y * 27 + s] += pr; ++s; }   /* :92-105 */
     }
+  double accd[27]; float accf[27]; int nvalid = 0;
+  for (int k = 0; k < 27; ++k) { accd[k] = 0; accf[k] = 0; }
+  for (int y = 0; y < rows; ++y) { nvalid += rown[y]; for (int k = 0; k < 27; ++k) { accd[k] += rowd[y * 27 + k]; accf[k] += rowf[y * 27 + k]; } }
+  free(rowd); free(rowf); free(rown);
   if (out27d) memcpy(out27d, accd, sizeof(accd));
   if (out27f) memcpy(out27f, accf, sizeof(accf));
   if (valid) *valid = nvalid;
