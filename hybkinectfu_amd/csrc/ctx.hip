@@ -111,7 +111,7 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
   if (cfg->has_color) TRY(dev_alloc(&v.color, c->n_stored_vox));
   TRY(dev_alloc(&v.flags, c->n_stored_bricks + 4));      // updated with 32-bit atomics: keep the last word whole
   v.nm = (v.res + KF_MACRO - 1) / KF_MACRO;
-  TRY(dev_alloc(&v.macro, (size_t)v.nm * v.nm * v.nm));
+  TRY(dev_alloc(&v.macro, (size_t)v.nm * v.nm * v.nm + 4));   // read as 32-bit words by the raycast's LDS copy
   TRY(dev_alloc(&c->active_bricks, c->n_stored_bricks));
   TRY(dev_alloc(&c->tile_max_depth, (size_t)kf_div_up(c->cols, 16) * kf_div_up(c->rows, 16)));
   c->max_triangles = cfg->max_triangles;

@@ -59,7 +59,27 @@ __global__ void __launch_bounds__(256) k_integrate_prepare(IntegrateArgs a) {
   }
 }
 
-// pass 1: one lane per stored brick; conservative rejection, survivors appended to the queue.
+// pass 1: one WAVE per 32^3-voxel macro cell (4x4x4 bricks = 64 lanes).  The wave first tests the macro cell's bounding
+// sphere against the depth range and the frustum (uniform: a culled macro cell costs a few scalar-ish instructions for 64
+// bricks), then each lane tests its own brick, and the survivors are appended with ONE atomic per wave.  All tests are
+// conservative: a brick is dropped only when no voxel of it can pass the reference's predicate.
+__device__ __forceinline__ bool cull_sphere_visible(const IntegrateArgs& a, const float* m, float cx, float cy, float cz, float r,
+                                                    float& px, float& py, float& pz) {
+  px = m[0] * cx + m[1] * cy + m[2] * cz + m[3];
+  py = m[4] * cx + m[5] * cy + m[6] * cz + m[7];
+  pz = m[8] * cx + m[9] * cy + m[10] * cz + m[11];
+  if (pz + r <= 0.f) return false;                                     // every voxel has pf.z <= 0
+  if (pz - r >= a.max_dist + a.sdf_trunc) return false;                // needs pf.z < depth + trunc < max_dist + trunc
+  // frustum side planes through the eye, widened by one pixel
+  const float tl = (-1.f - a.dcam.cx) / a.dcam.fx, tr = ((float)a.dcam.cols - a.dcam.cx) / a.dcam.fx;
+  const float tt = (-1.f - a.dcam.cy) / a.dcam.fy, tb = ((float)a.dcam.rows - a.dcam.cy) / a.dcam.fy;
+  if ((px - tl * pz) < -r * sqrtf(1.f + tl * tl)) return false;
+  if ((tr * pz - px) < -r * sqrtf(1.f + tr * tr)) return false;
+  if ((py - tt * pz) < -r * sqrtf(1.f + tt * tt)) return false;
+  if ((tb * pz - py) < -r * sqrtf(1.f + tb * tb)) return false;
+  return true;
+}
+
 __global__ void __launch_bounds__(256) k_integrate_cull(IntegrateArgs a) {
   if (a.track && !a.track->tracked) {                        // HybKinectfu.cpp:123: integrate only when tracking succeeded
     if (blockIdx.x == 0 && threadIdx.x == 0) a.cnt->frames_lost += 1;
@@ -67,44 +87,49 @@ __global__ void __launch_bounds__(256) k_integrate_cull(IntegrateArgs a) {
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) a.cnt->frames_fused += 1;
   const KfVolume& v = a.vol;
-  const size_t nbricks = (size_t)(v.bz1 - v.bz0) * v.nb * v.nb;
-  const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (slot >= nbricks) return;
-  const int bx = (int)(slot % v.nb), by = (int)((slot / v.nb) % v.nb), bz = (int)(slot / ((size_t)v.nb * v.nb)) + v.bz0;
+  const int nmxy = (v.nb + 3) >> 2;                          // macro cells per x / y
+  const int mz0 = v.bz0 >> 2, mz1 = (v.bz1 + 3) >> 2;        // macro layers touching the stored bricks
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int n_macro = nmxy * nmxy * (mz1 - mz0);
+  if (wave >= n_macro) return;
+  const int mx = wave % nmxy, my = (wave / nmxy) % nmxy, mz = wave / (nmxy * nmxy) + mz0;
   const float* m = a.tinv;
   const float cell = v.cell;
-  // voxel centres of the brick span [(8b+0.5), (8b+7.5)] * cell per axis -> centre (8b+4)*cell, half-diagonal 3.5*sqrt(3)*cell
-  const float cx = (float)(bx * 8 + 4) * cell, cy = (float)(by * 8 + 4) * cell, cz = (float)(bz * 8 + 4) * cell;
+  float px, py, pz;
+  // macro cell: voxel centres span [(32m+0.5), (32m+31.5)] * cell -> centre (32m+16)*cell, half-diagonal 15.5*sqrt(3)*cell
+  if (!cull_sphere_visible(a, m, (float)(mx * 32 + 16) * cell, (float)(my * 32 + 16) * cell, (float)(mz * 32 + 16) * cell,
+                           27.0f * cell + 1e-4f * v.size, px, py, pz)) return;
+  const int bx = mx * 4 + (lane & 3), by = my * 4 + ((lane >> 2) & 3), bz = mz * 4 + (lane >> 4);
+  bool keep = bx < v.nb && by < v.nb && bz >= v.bz0 && bz < v.bz1;
+  // brick: voxel centres span [(8b+0.5), (8b+7.5)] * cell per axis -> centre (8b+4)*cell, half-diagonal 3.5*sqrt(3)*cell
   const float r = 6.1f * cell + 1e-4f * v.size;
-  const float px = m[0] * cx + m[1] * cy + m[2] * cz + m[3];
-  const float py = m[4] * cx + m[5] * cy + m[6] * cz + m[7];
-  const float pz = m[8] * cx + m[9] * cy + m[10] * cz + m[11];
-  if (pz + r <= 0.f) return;                                           // every voxel has pf.z <= 0
-  if (pz - r >= a.max_dist + a.sdf_trunc) return;                      // needs pf.z < depth + trunc < max_dist + trunc
-  // frustum side planes through the eye, widened by one pixel
-  const float tl = (-1.f - a.dcam.cx) / a.dcam.fx, tr = ((float)a.dcam.cols - a.dcam.cx) / a.dcam.fx;
-  const float tt = (-1.f - a.dcam.cy) / a.dcam.fy, tb = ((float)a.dcam.rows - a.dcam.cy) / a.dcam.fy;
-  if ((px - tl * pz) < -r * sqrtf(1.f + tl * tl)) return;
-  if ((tr * pz - px) < -r * sqrtf(1.f + tr * tr)) return;
-  if ((py - tt * pz) < -r * sqrtf(1.f + tt * tt)) return;
-  if ((tb * pz - py) < -r * sqrtf(1.f + tb * tb)) return;
+  if (keep) keep = cull_sphere_visible(a, m, (float)(bx * 8 + 4) * cell, (float)(by * 8 + 4) * cell, (float)(bz * 8 + 4) * cell, r, px, py, pz);
   // depth test against the tile max over the brick's pixel footprint (only when the brick is clear of the eye plane)
   const float zn = pz - r, zf = pz + r;
-  if (zn > 4.f * cell) {
+  if (keep && zn > 4.f * cell) {
     const float xl = px - r, xr = px + r, yl = py - r, yr = py + r;
     float u0 = (xl < 0.f ? xl / zn : xl / zf) * a.dcam.fx + a.dcam.cx, u1 = (xr > 0.f ? xr / zn : xr / zf) * a.dcam.fx + a.dcam.cx;
     float w0 = (yl < 0.f ? yl / zn : yl / zf) * a.dcam.fy + a.dcam.cy, w1 = (yr > 0.f ? yr / zn : yr / zf) * a.dcam.fy + a.dcam.cy;
     int ix0 = (int)floorf(u0) - 1, ix1 = (int)ceilf(u1) + 2, iy0 = (int)floorf(w0) - 1, iy1 = (int)ceilf(w1) + 2;
     ix0 = max(ix0, 0); iy0 = max(iy0, 0); ix1 = min(ix1, a.dcam.cols - 1); iy1 = min(iy1, a.dcam.rows - 1);
-    if (ix0 > ix1 || iy0 > iy1) return;
-    float dmax = 0.f;
-    for (int ty = iy0 >> 4; ty <= (iy1 >> 4); ++ty)
-      for (int tx = ix0 >> 4; tx <= (ix1 >> 4); ++tx) dmax = fmaxf(dmax, a.tile_max[ty * a.tiles_x + tx]);
-    if (dmax == 0.f) return;                                           // no pixel under the brick can integrate
-    if (zn >= dmax + a.sdf_trunc) return;                              // every voxel lies behind every surface it can see
+    if (ix0 > ix1 || iy0 > iy1) keep = false;
+    else {
+      float dmax = 0.f;
+      for (int ty = iy0 >> 4; ty <= (iy1 >> 4); ++ty)
+        for (int tx = ix0 >> 4; tx <= (ix1 >> 4); ++tx) dmax = fmaxf(dmax, a.tile_max[ty * a.tiles_x + tx]);
+      if (dmax == 0.f) keep = false;                                     // no pixel under the brick can integrate
+      else if (zn >= dmax + a.sdf_trunc) keep = false;                   // every voxel lies behind every surface it can see
+    }
   }
-  unsigned pos = atomicAdd(&a.cnt->n_active_bricks, 1u);               // wave-aggregated by the compiler
-  a.queue[pos] = (unsigned)bx | ((unsigned)by << 10) | ((unsigned)(bz - v.bz0) << 20);   // packed brick coordinates: no div/mod to decode
+  const unsigned long long mask = __ballot(keep);
+  if (mask == 0ull) return;
+  unsigned base = 0;
+  if (lane == 0) base = atomicAdd(&a.cnt->n_active_bricks, (unsigned)__popcll(mask));
+  base = __shfl(base, 0, 64);
+  if (keep) {
+    const unsigned pos = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+    a.queue[pos] = (unsigned)bx | ((unsigned)by << 10) | ((unsigned)(bz - v.bz0) << 20);   // packed brick coordinates: no div/mod to decode
+  }
 }
 
 // pass 2: one workgroup walks the queue BR bricks at a time, one lane per x-adjacent voxel pair (16 contiguous bytes) of
@@ -256,7 +281,11 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   }
   kf_evt_begin(c, KF_STAGE_INTEGRATE);
   hipLaunchKernelGGL(k_integrate_prepare, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, c->stream, a);
-  hipLaunchKernelGGL(k_integrate_cull, dim3((unsigned)((c->n_stored_bricks + 255) / 256)), dim3(256), 0, c->stream, a);
+  {
+    const int nmxy = (c->vol.nb + 3) >> 2, nmz = ((c->vol.bz1 + 3) >> 2) - (c->vol.bz0 >> 2);
+    const unsigned n_macro = (unsigned)nmxy * nmxy * nmz;                      // one wave per macro cell, four per workgroup
+    hipLaunchKernelGGL(k_integrate_cull, dim3((n_macro + 3) / 4), dim3(256), 0, c->stream, a);
+  }
   unsigned grid = (unsigned)(c->n_stored_bricks < 4096 ? c->n_stored_bricks : 4096);
   kf_evt_begin(c, KF_STAGE_INTEGRATE_KERNEL);
   if (has_color) hipLaunchKernelGGL((k_integrate_bricks<true, 1>), dim3(grid), dim3(256), 0, c->stream, a);

@@ -252,6 +252,55 @@ __device__ __forceinline__ bool kf_interpolate_sdf(const KfVolume& v, float3 pos
          q[4].x * a * ib * ic + q[5].x * a * ib * c + q[6].x * a * b * ic + q[7].x * a * b * c;
   return true;
 }
+// The same interpolation split into prepare / load / finish so that SEVERAL lookups can have their 8 voxel gathers in flight
+// together (the reference's early-outs are pure, so evaluating a batch and then testing the results in the reference's
+// order gives the same outcome).  Divisions by the volume size and the cell size go through kf_div with hoisted reciprocals.
+struct KfInterp { bool ok; int3 g; float a, b, c; };
+__device__ __forceinline__ KfInterp kf_interp_prepare(const KfVolume& v, float3 pos, const KfRecip& rS, const KfRecip& rcell) {
+  KfInterp it; it.ok = false; it.a = it.b = it.c = 0.f;
+  const float r = (float)v.res;
+  int3 g = make_int3(kf_f2i(kf_div(pos.x * r, rS)), kf_f2i(kf_div(pos.y * r, rS)), kf_f2i(kf_div(pos.z * r, rS)));   // tsdfVolume.h:50-56
+  it.g = g;
+  const int R = v.res;
+  if (g.x <= 0 || g.x >= R - 1 || g.y <= 0 || g.y >= R - 1 || g.z <= 0 || g.z >= R - 1) return it;
+  const float cell = v.cell;
+  g.x = (pos.x < ((float)g.x + 0.5f) * cell) ? (g.x - 1) : g.x;
+  g.y = (pos.y < ((float)g.y + 0.5f) * cell) ? (g.y - 1) : g.y;
+  g.z = (pos.z < ((float)g.z + 0.5f) * cell) ? (g.z - 1) : g.z;
+  it.g = g;
+  it.a = kf_div(pos.x - ((float)g.x + 0.5f) * cell, rcell);
+  it.b = kf_div(pos.y - ((float)g.y + 0.5f) * cell, rcell);
+  it.c = kf_div(pos.z - ((float)g.z + 0.5f) * cell, rcell);
+  it.ok = kf_z_stored(v, g.z) && kf_z_stored(v, g.z + 1);
+  return it;
+}
+__device__ __forceinline__ void kf_interp_load(const KfVolume& v, const KfInterp& it, float2 q[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) q[k] = make_float2(0.f, 0.f);
+  if (it.ok) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = v.tw[kf_vox_index(v, it.g.x + (k >> 2), it.g.y + ((k >> 1) & 1), it.g.z + (k & 1))];
+  }
+}
+__device__ __forceinline__ bool kf_interp_finish(const KfInterp& it, const float2 q[8], float& dist) {
+  if (!it.ok) return false;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) if (q[k].y == 0.f) return false;
+  const float a = it.a, b = it.b, c = it.c, ia = 1 - a, ib = 1 - b, ic = 1 - c;
+  dist = q[0].x * ia * ib * ic + q[1].x * ia * ib * c + q[2].x * ia * b * ic + q[3].x * ia * b * c +
+         q[4].x * a * ib * ic + q[5].x * a * ib * c + q[6].x * a * b * ic + q[7].x * a * b * c;
+  return true;
+}
+// two lookups, 16 gathers in flight
+__device__ __forceinline__ void kf_interpolate_sdf_pair(const KfVolume& v, float3 p1, float3 p2, const KfRecip& rS, const KfRecip& rcell,
+                                                        bool& ok1, float& d1, bool& ok2, float& d2) {
+  const KfInterp i1 = kf_interp_prepare(v, p1, rS, rcell), i2 = kf_interp_prepare(v, p2, rS, rcell);
+  float2 q1[8], q2[8];
+  kf_interp_load(v, i1, q1); kf_interp_load(v, i2, q2);
+  d1 = 0.f; d2 = 0.f;
+  ok1 = kf_interp_finish(i1, q1, d1); ok2 = kf_interp_finish(i2, q2, d2);
+}
+
 // tsdfVolume.h:123-148 (float -> uchar truncation)
 __device__ __forceinline__ bool kf_interpolate_color(const KfVolume& v, float3 pos, uchar4& out) {
   int3 g; float a, b, c;

@@ -12,6 +12,7 @@
 //     interpolation inputs are bit-identical to the reference march;
 //   * bricks are 4 KiB contiguous, so the trilinear taps at the hit (2 + 6 lookups x 8 voxels) touch 1-2 bricks.
 #include "kf_internal.h"
+#include <stdlib.h>
 
 struct RaycastArgs {
   KfVolume vol;
@@ -22,25 +23,29 @@ struct RaycastArgs {
   float* out_t;                  // optional: ray parameter of the first crossing this context detected (+inf: none) -- z-slab merge
   float inc, near_plane, far_plane;
   int has_color;
+  int exp_mode;                  // timing experiments only (KF_RAYCAST_EXP): 1 = stop at the crossing without evaluating it
 };
 
-// gradientForPoint raycastingVolume.cu:16-42: bounds tested on the LAST sample's voxel, taps taken around the vertex
-__device__ __forceinline__ bool gradient_for_point(const KfVolume& v, float3 samplepos, float3 vtx, float3& grad) {
-  int3 g = kf_world_to_voxel(v, samplepos);
+// gradientForPoint raycastingVolume.cu:16-42: bounds tested on the LAST sample's voxel, taps taken around the vertex.
+// The +/- taps of an axis are looked up as a pair (16 gathers in flight); the reference's early-outs are pure, so testing
+// the pair's verdicts in its order (+ then -) is equivalent.
+__device__ __forceinline__ bool gradient_for_point(const KfVolume& v, float3 samplepos, float3 vtx, const KfRecip& rS, const KfRecip& rcell, float3& grad) {
+  const float rf = (float)v.res;
+  const int3 g = make_int3(kf_f2i(kf_div(samplepos.x * rf, rS)), kf_f2i(kf_div(samplepos.y * rf, rS)), kf_f2i(kf_div(samplepos.z * rf, rS)));
   const int R = v.res;
   if (g.x <= 1 || g.x >= R - 2) return false;
   if (g.y <= 1 || g.y >= R - 2) return false;
   if (g.z <= 1 || g.z >= R - 2) return false;
   const float cell = v.cell;
-  float f1, f2; float3 n;
-  if (!kf_interpolate_sdf(v, kf3(vtx.x + cell, vtx.y, vtx.z), f1)) return false;
-  if (!kf_interpolate_sdf(v, kf3(vtx.x - cell, vtx.y, vtx.z), f2)) return false;
+  float f1, f2; bool o1, o2; float3 n;
+  kf_interpolate_sdf_pair(v, kf3(vtx.x + cell, vtx.y, vtx.z), kf3(vtx.x - cell, vtx.y, vtx.z), rS, rcell, o1, f1, o2, f2);
+  if (!o1 || !o2) return false;
   n.x = f1 - f2;
-  if (!kf_interpolate_sdf(v, kf3(vtx.x, vtx.y + cell, vtx.z), f1)) return false;
-  if (!kf_interpolate_sdf(v, kf3(vtx.x, vtx.y - cell, vtx.z), f2)) return false;
+  kf_interpolate_sdf_pair(v, kf3(vtx.x, vtx.y + cell, vtx.z), kf3(vtx.x, vtx.y - cell, vtx.z), rS, rcell, o1, f1, o2, f2);
+  if (!o1 || !o2) return false;
   n.y = f1 - f2;
-  if (!kf_interpolate_sdf(v, kf3(vtx.x, vtx.y, vtx.z + cell), f1)) return false;
-  if (!kf_interpolate_sdf(v, kf3(vtx.x, vtx.y, vtx.z - cell), f2)) return false;
+  kf_interpolate_sdf_pair(v, kf3(vtx.x, vtx.y, vtx.z + cell), kf3(vtx.x, vtx.y, vtx.z - cell), rS, rcell, o1, f1, o2, f2);
+  if (!o1 || !o2) return false;
   n.z = f1 - f2;
   float len = kf_norm(n);
   if ((double)len < 1e-8) return false;
@@ -48,15 +53,28 @@ __device__ __forceinline__ bool gradient_for_point(const KfVolume& v, float3 sam
   return true;
 }
 
+#define RAYCAST_LDS_MACRO 32768
+#define RB 1                      // ray samples per batch (4 measured 5 % slower at C2/C4: the march is VALU-bound, not latency-bound)
 __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
   const KfVolume& v = a.vol;
+  // the macro-cell table (<= 32 KiB up to 1024^3) is copied into LDS: the empty-space walk then costs an LDS read per
+  // macro cell instead of a dependent L2 round trip
+  __shared__ unsigned s_macro_words[RAYCAST_LDS_MACRO / 4];
+  const int nm3 = v.nm * v.nm * v.nm;
+  const bool macro_in_lds = nm3 <= RAYCAST_LDS_MACRO;
+  if (macro_in_lds) {
+    const unsigned* src = reinterpret_cast<const unsigned*>(v.macro);
+    for (int i = threadIdx.x; i < (nm3 + 3) / 4; i += 256) s_macro_words[i] = src[i];
+    __syncthreads();
+  }
+  const unsigned char* s_macro = reinterpret_cast<const unsigned char*>(s_macro_words);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7), y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
   if (x >= a.cam.cols || y >= a.cam.rows) return;
   const int pix = y * a.cam.cols + x;
   float4 out_v = make_float4(0.f, 0.f, 0.f, 0.f), out_n = make_float4(0.f, 0.f, 0.f, 0.f);
   uchar4 out_c = make_uchar4(0, 0, 0, 0);
-  float t_cross = __builtin_huge_valf();
+  float t_cross = __builtin_huge_valf(), t_cross_prev = 0.f;
   const float* T = a.pose ? a.pose : a.pose_val.m;
   // raycastKernel :136-150
   const float3 cam_dir = kf_normalize(kf_depth_to_skeleton((unsigned)x, (unsigned)y, 1.0f, a.cam));
@@ -76,6 +94,7 @@ __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
     const int R = v.res;
     const float rf = (float)R;
     const KfRecip rS = kf_recip(S);                                       // `worldPos.x*_resolution.x/_size.x`: shared divisor
+    const KfRecip rcell = kf_recip(v.cell);
     const int zs0 = v.bz0 * KF_BRICK, zs1 = v.bz1 * KF_BRICK;
     float t = tmin, t_prev = tmin;
     float last_sdf = 0.f; bool have_last = true;
@@ -90,7 +109,8 @@ __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
         const int mx = max(0, min((int)floorf(pos.x * inv_mcell), nm - 1));
         const int my = max(0, min((int)floorf(pos.y * inv_mcell), nm - 1));
         const int mz = max(0, min((int)floorf(pos.z * inv_mcell), nm - 1));
-        if (!v.macro[((size_t)mz * nm + my) * nm + mx]) {
+        const int mi = (mz * nm + my) * nm + mx;
+        if (!(macro_in_lds ? s_macro[mi] : v.macro[mi])) {
           const float bx = dir.x > 0.f ? (float)(mx + 1) * mcell - eps : (float)mx * mcell + eps;
           const float by = dir.y > 0.f ? (float)(my + 1) * mcell - eps : (float)my * mcell + eps;
           const float bz = dir.z > 0.f ? (float)(mz + 1) * mcell - eps : (float)mz * mcell + eps;
@@ -101,49 +121,72 @@ __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
           continue;
         }
       }
-      // tsdfvolume::getVoxel(world) tsdfVolume.h:81-97: nearest voxel, index clamped
-      int gx = kf_f2i(kf_div(pos.x * rf, rS)), gy = kf_f2i(kf_div(pos.y * rf, rS)), gz = kf_f2i(kf_div(pos.z * rf, rS));
-      gx = max(0, min(gx, R - 1)); gy = max(0, min(gy, R - 1)); gz = max(0, min(gz, R - 1));
-      // only samples whose voxel this context OWNS can be its crossing candidates (the whole volume on one GPU; with
-      // z-slabs the neighbour's layers are stored as halo and serve the previous-sample / trilinear / gradient reads only)
-      const bool owned = gz >= v.own_z0 && gz < v.own_z1;
-      size_t slot = 0; unsigned flag = 0;
-      if (owned) { slot = kf_brick_slot(v, gx >> 3, gy >> 3, gz >> 3); flag = v.flags[slot]; }
-      const size_t idx = slot * KF_BRICK_VOX + (size_t)(((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7));
-      if (!(flag & KF_FLAG_HASNEG)) {
-        // level 2: tsdf >= 0 everywhere in this 8^3 brick: not the negative side of a crossing
-        have_last = false; t_prev = t;
-        t += a.inc;
-        continue;
-      }
-      const float sdf = v.tw[idx].x;
-      float3 last_pos = kf3(0.f, 0.f, 0.f);
-      if (sdf < 0.0f) {
-        last_pos = kf_add(org, kf_scale(dir, t_prev));                     // the previous sample of the march, recomputed exactly
-        if (!have_last) {                                                  // its tsdf was never fetched: fetch it now
-          int lx = kf_f2i(kf_div(last_pos.x * rf, rS)), ly = kf_f2i(kf_div(last_pos.y * rf, rS)), lz = kf_f2i(kf_div(last_pos.z * rf, rS));
-          lx = max(0, min(lx, R - 1)); ly = max(0, min(ly, R - 1)); lz = max(0, min(lz, R - 1));
-          last_sdf = (lz >= zs0 && lz < zs1) ? v.tw[kf_vox_index(v, lx, ly, lz)].x : 0.f;
-          have_last = true;
+      // level 2: a batch of RB consecutive samples (the same repeated addition gives their parameters).  Their brick flags are
+      // fetched together, then the tsdf of the samples in has-negative bricks together: two dependent round trips per RB
+      // samples instead of up to two per sample -- rays grazing a wall stay inside flagged macro cells for dozens of steps.
+      float tb[RB]; size_t idxb[RB]; unsigned flagb[RB]; float sdfb[RB]; bool liveb[RB];
+      {
+        float tt = t;
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          tb[j] = tt; liveb[j] = tt < tmax;
+          const float3 pj = kf_add(org, kf_scale(dir, tt));
+          // tsdfvolume::getVoxel(world) tsdfVolume.h:81-97: nearest voxel, index clamped
+          int gx = kf_f2i(kf_div(pj.x * rf, rS)), gy = kf_f2i(kf_div(pj.y * rf, rS)), gz = kf_f2i(kf_div(pj.z * rf, rS));
+          gx = max(0, min(gx, R - 1)); gy = max(0, min(gy, R - 1)); gz = max(0, min(gz, R - 1));
+          // only samples whose voxel this context OWNS can be its crossing candidates (the whole volume on one GPU; with
+          // z-slabs the neighbour's layers are stored as halo and serve the previous-sample / trilinear / gradient reads only)
+          const bool owned = liveb[j] && gz >= v.own_z0 && gz < v.own_z1;
+          size_t slot = 0; flagb[j] = 0;
+          if (owned) { slot = kf_brick_slot(v, gx >> 3, gy >> 3, gz >> 3); flagb[j] = v.flags[slot]; }
+          idxb[j] = slot * KF_BRICK_VOX + (size_t)(((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7));
+          tt += a.inc;
         }
-        if (last_sdf > 0.0f) {                                             // zero crossing :83
-          t_cross = t;
-          float ftdt, ft;
-          if (!kf_interpolate_sdf(v, pos, ftdt)) break;
-          if (!kf_interpolate_sdf(v, last_pos, ft)) break;
-          const float alpha = t - a.inc * ftdt / (ftdt - ft);
-          const float3 vtx = kf_add(org, kf_scale(dir, alpha));
-          if (a.has_color) { uchar4 c = make_uchar4(0, 0, 0, 0); kf_interpolate_color(v, vtx, c); out_c = c; }
-          float3 grad;
-          if (!gradient_for_point(v, last_pos, vtx, grad)) break;
+#pragma unroll
+        for (int j = 0; j < RB; ++j) sdfb[j] = (flagb[j] & KF_FLAG_HASNEG) ? v.tw[idxb[j]].x : 0.f;
+      }
+      bool crossed = false;
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        if (crossed || !liveb[j]) continue;
+        if (!(flagb[j] & KF_FLAG_HASNEG)) {                                 // tsdf >= 0 everywhere in this 8^3 brick
+          have_last = false; t_prev = tb[j];
+          continue;
+        }
+        const float sdf = sdfb[j];
+        if (sdf < 0.0f) {
+          if (!have_last) {                                                  // the previous sample's tsdf was never fetched: fetch it now
+            const float3 last_pos = kf_add(org, kf_scale(dir, t_prev));      // recomputed exactly as the march computed it
+            int lx = kf_f2i(kf_div(last_pos.x * rf, rS)), ly = kf_f2i(kf_div(last_pos.y * rf, rS)), lz = kf_f2i(kf_div(last_pos.z * rf, rS));
+            lx = max(0, min(lx, R - 1)); ly = max(0, min(ly, R - 1)); lz = max(0, min(lz, R - 1));
+            last_sdf = (lz >= zs0 && lz < zs1) ? v.tw[kf_vox_index(v, lx, ly, lz)].x : 0.f;
+            have_last = true;
+          }
+          if (last_sdf > 0.0f) { t_cross = tb[j]; t_cross_prev = t_prev; crossed = true; continue; }   // zero crossing :83
+        }
+        last_sdf = sdf; have_last = true; t_prev = tb[j];
+      }
+      if (crossed) break;
+      t = tb[RB - 1] + a.inc;
+    }
+    // The crossing is evaluated HERE, after the march loop, not inside it: lanes of a wave meet their crossings at
+    // different iterations, and inside the loop the 64-gather evaluation would run once per distinct iteration with a
+    // handful of active lanes each time.  After the loop every lane that found a crossing evaluates together.
+    if (t_cross < __builtin_huge_valf() && a.exp_mode != 1) {
+      const float3 pos = kf_add(org, kf_scale(dir, t_cross)), last_pos = kf_add(org, kf_scale(dir, t_cross_prev));
+      float ftdt, ft; bool ok_cur, ok_last;
+      kf_interpolate_sdf_pair(v, pos, last_pos, rS, rcell, ok_cur, ftdt, ok_last, ft);
+      if (ok_cur && ok_last) {                                              // :87-88 `break` on either failure
+        const float alpha = t_cross - a.inc * ftdt / (ftdt - ft);
+        const float3 vtx = kf_add(org, kf_scale(dir, alpha));
+        if (a.has_color) { uchar4 c = make_uchar4(0, 0, 0, 0); kf_interpolate_color(v, vtx, c); out_c = c; }
+        float3 grad;
+        if (gradient_for_point(v, last_pos, vtx, rS, rcell, grad)) {
           out_v = make_float4(vtx.x, vtx.y, vtx.z, 1.0f);
           out_n = make_float4(grad.x, grad.y, grad.z, 0.f);
-          break;
         }
       }
-      last_sdf = sdf; have_last = true; t_prev = t;
-      t += a.inc;
-    }
+    } else if (t_cross < __builtin_huge_valf()) out_v = make_float4(t_cross, 0.f, 0.f, 1.f);
   }
   a.out_v[pix] = out_v; a.out_n[pix] = out_n;
   if (a.out_t) a.out_t[pix] = t_cross;
@@ -162,6 +205,7 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
   else a.pose = c->track->pose;
   a.out_v = out_v ? out_v : c->model_v[0]; a.out_n = out_n ? out_n : c->model_n[0]; a.out_rgb = c->raycast_rgb; a.out_t = out_t;
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
+  { static int em = -1; if (em < 0) { const char* e = getenv("KF_RAYCAST_EXP"); em = e ? atoi(e) : 0; } a.exp_mode = em; }
   dim3 grid(kf_div_up(c->cols, 16), kf_div_up(c->rows, 16));
   kf_evt_begin(c, KF_STAGE_RAYCAST);
   hipLaunchKernelGGL(k_raycast, grid, dim3(256), 0, c->stream, a);
