@@ -72,9 +72,10 @@ __device__ __forceinline__ float det6(float m[36]) {
       }
     const float piv = m[k * 6 + k];
     det *= piv;
+    const KfRecip rp = kf_recip(piv);                        // one reciprocal refinement per pivot, exact quotients (kf_div)
 #pragma unroll
     for (int r = k + 1; r < 6; ++r) {
-      const float f = m[r * 6 + k] / piv;
+      const float f = kf_div(m[r * 6 + k], rp);
 #pragma unroll
       for (int c = k + 1; c < 6; ++c) m[r * 6 + c] -= f * m[k * 6 + c];
     }
@@ -83,7 +84,7 @@ __device__ __forceinline__ float det6(float m[36]) {
 }
 // x = LLT(A) \ b, fp32 (ICP.cpp:143, SDF.cpp:79)
 __device__ __forceinline__ void llt_solve6(const float A[36], const float b[6], float x[6]) {
-  float L[36];
+  float L[36]; KfRecip rd[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     float s = A[j * 6 + j];
@@ -91,12 +92,13 @@ __device__ __forceinline__ void llt_solve6(const float A[36], const float b[6], 
     for (int k = 0; k < j; ++k) s -= L[j * 6 + k] * L[j * 6 + k];
     const float d = sqrtf(s);
     L[j * 6 + j] = d;
+    rd[j] = kf_recip(d);                                     // every division by L_jj (3 per column) shares this reciprocal
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       float t = A[i * 6 + j];
 #pragma unroll
       for (int k = 0; k < j; ++k) t -= L[i * 6 + k] * L[j * 6 + k];
-      L[i * 6 + j] = t / d;
+      L[i * 6 + j] = kf_div(t, rd[j]);
     }
   }
   float y[6];
@@ -105,14 +107,14 @@ __device__ __forceinline__ void llt_solve6(const float A[36], const float b[6], 
     float t = b[i];
 #pragma unroll
     for (int k = 0; k < i; ++k) t -= L[i * 6 + k] * y[k];
-    y[i] = t / L[i * 6 + i];
+    y[i] = kf_div(t, rd[i]);
   }
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
     float t = y[i];
 #pragma unroll
     for (int k = i + 1; k < 6; ++k) t -= L[k * 6 + i] * x[k];
-    x[i] = t / L[i * 6 + i];
+    x[i] = kf_div(t, rd[i]);
   }
 }
 __device__ __forceinline__ void mat3_mul(const float a[9], const float b[9], float o[9]) {
@@ -436,15 +438,16 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     const int grid_l = (npx + ICP_THREADS * ICP_PX - 1) / (ICP_THREADS * ICP_PX);
     const bool has_px = (int)blockIdx.x < grid_l;
     const int base = blockIdx.x * (ICP_THREADS * ICP_PX) + threadIdx.x;
-    for (int it = 0; it < L.iters[l]; ++it, ++step) {
-      // this lane's own vertices / normals do not depend on the running transform: request them before the fold + solve
-      float4 iv[ICP_PX], in_[ICP_PX];
+    // this lane's own vertices / normals depend neither on the running transform nor on the iteration: they are loaded once
+    // per pyramid level and stay in registers for all of its iterations (the reference re-reads them 4 / 5 / 10 times)
+    float4 iv[ICP_PX], in_[ICP_PX];
 #pragma unroll
-      for (int j = 0; j < ICP_PX; ++j) {
-        const int i = base + j * ICP_THREADS;
-        iv[j] = make_float4(0.f, 0.f, 0.f, 0.f); in_[j] = iv[j];
-        if (has_px && i < npx) { iv[j] = new_v[i]; in_[j] = new_n[i]; }
-      }
+    for (int j = 0; j < ICP_PX; ++j) {
+      const int i = base + j * ICP_THREADS;
+      iv[j] = make_float4(0.f, 0.f, 0.f, 0.f); in_[j] = iv[j];
+      if (has_px && i < npx) { iv[j] = new_v[i]; in_[j] = new_n[i]; }
+    }
+    for (int it = 0; it < L.iters[l]; ++it, ++step) {
       KF_STAMP(0);
       if (step > 0 && L.exp_mode != 6) {
         if (L.exp_mode != 3) fold_partials_sc1(L.partials + (size_t)((step + 1) & 1) * KF_ICP_MAX_WG * 32, n_prev, s_tot);
@@ -487,10 +490,16 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
 #pragma unroll
         for (int k = 0; k < 27; ++k) { const float sw = kf_row_scan_sum(acc[k]); if ((threadIdx.x & 15) == 15) s_wave[k * (ICP_THREADS / 16) + row] = sw; }
         __syncthreads();
-        if (threadIdx.x < 27) {
-          float sw = s_wave[threadIdx.x * (ICP_THREADS / 16)];
-          for (int w = 1; w < ICP_THREADS / 16; ++w) sw += s_wave[threadIdx.x * (ICP_THREADS / 16) + w];
-          __hip_atomic_store(L.partials + (size_t)(step & 1) * KF_ICP_MAX_WG * 32 + blockIdx.x * 32 + threadIdx.x, sw,
+        // 4 lanes per sum add 8 row totals each, then two DPP shifts combine the four partial chains (fixed order)
+        if (threadIdx.x < 27 * 4) {
+          const int k = threadIdx.x >> 2, part = threadIdx.x & 3;
+          float sw = s_wave[k * (ICP_THREADS / 16) + part * 8];
+#pragma unroll
+          for (int w = 1; w < 8; ++w) sw += s_wave[k * (ICP_THREADS / 16) + part * 8 + w];
+          sw += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sw), 0x111, 0xf, 0xf, true));   // row_shr:1
+          sw += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sw), 0x112, 0xf, 0xf, true));   // row_shr:2
+          if (part == 3)
+            __hip_atomic_store(L.partials + (size_t)(step & 1) * KF_ICP_MAX_WG * 32 + blockIdx.x * 32 + k, sw,
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
