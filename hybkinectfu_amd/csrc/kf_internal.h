@@ -81,6 +81,7 @@ struct kf_ctx {
   int lvl_cols[KF_MAX_LEVELS], lvl_rows[KF_MAX_LEVELS];
   // frame maps (CudaDeviceDataMan.h:56-67)
   uint16_t* depth_mm;                 // staging for host uploads
+  const uint16_t* pending_mm;         // device u16 frame whose conversion is deferred into the fused preprocess kernel
   float* raw_depth; float* trunced_depth; float* filtered_depth;
   uchar4* raw_rgb; uchar4* raycast_rgb;   // stored 4 bytes/pixel on the device
   float4* new_v[KF_MAX_LEVELS]; float4* new_n[KF_MAX_LEVELS];
@@ -367,4 +368,6 @@ __device__ __forceinline__ float kf_row_scan_sum(float v) {
 
 // entry points implemented across the .hip files (internal linkage between translation units)
 int kf_launch_pyramids(kf_ctx* ctx, bool model, bool vertices, bool normals);
+int kf_launch_pyramids_and_begin(kf_ctx* ctx, int begin_mode);
 int kf_live_contexts(int device);
+int kf_materialize_raw_depth(kf_ctx* ctx);

@@ -59,6 +59,79 @@ __global__ void __launch_bounds__(256) k_bilateral(const float* __restrict__ in,
   out[y * cols + x] = result;
 }
 
+// Fused front end of HybKinectfu::processNewFrame (src/HybKinectfu.cpp:63-110): u16 mm -> f32 m (:73), range gate
+// (DataPreprocesser.cu:17-36) and bilateral filter (:37-79) in ONE launch.  The (64+2R)x(4+2R) gated tile lives in LDS; the
+// R x R tap loop is fully unrolled and branch-free: a zero (invalid or out-of-image) tap gets weight 0 -- adding +0 leaves the
+// reference's running sums bit-identical -- and the reference's early `return` (any tap further than 5 sigma_d away keeps the
+// unfiltered value, :66-69) becomes a flag tested once at the end.
+template <int R>
+__global__ void __launch_bounds__(256) k_gate_bilateral(const uint16_t* __restrict__ mm, const float* __restrict__ raw_in,
+                                                        float* __restrict__ raw_out, float* __restrict__ trunced, float* __restrict__ filtered,
+                                                        int cols, int rows, float tmin, float tmax, float ss_inv, float sd_inv, float sigma_depth) {
+  constexpr int TW = BIL_TX + 2 * R, TH = BIL_TY + 2 * R;
+  __shared__ float tile[TW * TH];
+  const int x0 = blockIdx.x * BIL_TX - R, y0 = blockIdx.y * BIL_TY - R;
+  for (int i = threadIdx.x; i < TW * TH; i += 256) {
+    const int lx = i % TW, ly = i / TW, gx = x0 + lx, gy = y0 + ly;
+    float g = 0.f;
+    if (gx >= 0 && gx < cols && gy >= 0 && gy < rows) {
+      const float d = mm ? (float)((double)mm[gy * cols + gx] * 0.001) : raw_in[gy * cols + gx];   // HybKinectfu.cpp:73
+      g = (d < tmax && d > tmin) ? d : 0.f;                                                        // DataPreprocesser.cu:25-33
+      const bool interior = lx >= R && lx < R + BIL_TX && ly >= R && ly < R + BIL_TY;              // written exactly once
+      if (interior) { if (mm) raw_out[gy * cols + gx] = d; trunced[gy * cols + gx] = g; }
+    }
+    tile[i] = g;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const int x = blockIdx.x * BIL_TX + lx, y = blockIdx.y * BIL_TY + ly;
+  if (x >= cols || y >= rows) return;
+  const float value = tile[(ly + R) * TW + lx + R];
+  float result = value;
+  if (value != 0.f) {
+    float sum1 = 0.f, sum2 = 0.f;
+    bool aborted = false;
+    const float thr = 5 * sigma_depth;
+#pragma unroll
+    for (int dy = -R; dy <= R; ++dy) {
+#pragma unroll
+      for (int dx = -R; dx <= R; ++dx) {
+        const float tmp = tile[(ly + R + dy) * TW + lx + R + dx];
+        const bool valid = tmp != 0.f;
+        aborted |= valid && (fabsf(tmp - value) > thr);
+        const float space2 = (float)(dx * dx + dy * dy);
+        const float data2 = (value - tmp) * (value - tmp);
+        const float w = valid ? __expf(-(space2 * ss_inv + data2 * sd_inv)) : 0.f;
+        sum1 += tmp * w; sum2 += w;
+      }
+    }
+    if (!aborted && sum2 > 0.f) result = sum1 / sum2;
+  }
+  filtered[y * cols + x] = result;
+}
+
+// depthToVerticesKernel + verticesToNormalsKernel (VerticesNormalsCalculater.cu:15-66) in one launch: the four neighbour
+// vertices a normal needs are recomputed from the filtered depth with the same arithmetic instead of being re-read.
+__global__ void __launch_bounds__(256) k_vertices_normals(const float* __restrict__ depth, float4* __restrict__ out_v, float4* __restrict__ out_n, KfCam cam) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= cam.cols || y >= cam.rows) return;
+  const int i = y * cam.cols + x;
+  const float d0 = depth[i];
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f), n = v;
+  float3 v0 = kf3(0.f, 0.f, 0.f);
+  if (d0 != 0.f) { v0 = kf_depth_to_skeleton((unsigned)x, (unsigned)y, d0, cam); v = make_float4(v0.x, v0.y, v0.z, 1.0f); }
+  if (d0 != 0.f && !(x == cam.cols - 1 || y == cam.rows - 1 || x == 0 || y == 0)) {
+    const float dr = depth[i + 1], du = depth[i + cam.cols], dl = depth[i - 1], dd = depth[i - cam.cols];
+    if (dr != 0.f && du != 0.f && dl != 0.f && dd != 0.f) {                       // a vertex's z is its depth: z == 0 <=> depth == 0
+      const float3 vr = kf_depth_to_skeleton((unsigned)(x + 1), (unsigned)y, dr, cam), vu = kf_depth_to_skeleton((unsigned)x, (unsigned)(y + 1), du, cam);
+      const float3 vl = kf_depth_to_skeleton((unsigned)(x - 1), (unsigned)y, dl, cam), vd = kf_depth_to_skeleton((unsigned)x, (unsigned)(y - 1), dd, cam);
+      const float3 c = kf_normalize(kf_cross(kf_sub(vu, vd), kf_sub(vr, vl)));
+      n = make_float4(c.x, c.y, c.z, 0.f);
+    }
+  }
+  out_v[i] = v; out_n[i] = n;
+}
+
 // VerticesNormalsCalculater.cu:15-33
 __global__ void __launch_bounds__(256) k_depth_to_vertices(const float* __restrict__ depth, float4* __restrict__ out, KfCam cam) {
   int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -101,8 +174,23 @@ __device__ __forceinline__ float4 pyr_normal(float4 p00, float4 p01, float4 p10,
 
 // One thread per 2x2 block of level-1 pixels (= one level-2 pixel): reads 16 level-0 texels, writes 4 level-1 and 1 level-2.
 // blockIdx.z: 0 = vertices, 1 = normals.
-struct PyrMaps { const float4* in[2]; float4* l1[2]; float4* l2[2]; };
-__global__ void __launch_bounds__(256) k_pyramid(PyrMaps m, int cols0, int rows0, int levels, int kind_base) {
+// slots 0/1 = new vertices/normals, 2/3 = model vertices/normals (odd slot = normal averaging rule)
+struct PyrMaps { const float4* in[4]; float4* l1[4]; float4* l2[4]; };
+// begin_mode >= 0: block (0,0,0) also runs the start-of-tracking bookkeeping (k_track_begin) so a frame needs no extra launch
+__global__ void __launch_bounds__(256) k_pyramid(PyrMaps m, int cols0, int rows0, int levels, int kind_base,
+                                                 KfTrackState* st, KfGridBarrier* gb, int begin_mode) {
+  if (begin_mode >= 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    if (threadIdx.x < 10 && gb) reinterpret_cast<KfPaddedCounter*>(gb)[threadIdx.x].v = 0u;      // 8 groups + top + gen
+    if (threadIdx.x == 0) {
+      st->status = KF_TRACK_OK; st->iterations = 0; st->converged = 0; st->arrive = 0u;
+      if (begin_mode == 0) st->tracked = 1;
+      else {
+        st->tracked = 0;
+        for (int i = 0; i < 16; ++i) st->cur[0][i] = st->pose[i];            // ICP.cpp:62
+        kf_mat44_inverse(st->pose, st->last_inv);                           // ICP.cpp:63
+      }
+    }
+  }
   const int kind = kind_base + blockIdx.z;
   const float4* __restrict__ in = m.in[kind];
   float4* __restrict__ o1 = m.l1[kind];
@@ -119,30 +207,42 @@ __global__ void __launch_bounds__(256) k_pyramid(PyrMaps m, int cols0, int rows0
       if (x1 < c1 && y1 < r1) {
         const float4* p = in + (size_t)(2 * y1) * cols0 + 2 * x1;
         float4 p00 = p[0], p01 = p[1], p10 = p[cols0], p11 = p[cols0 + 1];
-        q[j][i] = kind ? pyr_normal(p00, p01, p10, p11) : pyr_vertex(p00, p01, p10, p11);
+        q[j][i] = (kind & 1) ? pyr_normal(p00, p01, p10, p11) : pyr_vertex(p00, p01, p10, p11);
         o1[(size_t)y1 * c1 + x1] = q[j][i];
       }
     }
   if (levels > 2 && bx < c2 && by < r2)
-    o2[(size_t)by * c2 + bx] = kind ? pyr_normal(q[0][0], q[0][1], q[1][0], q[1][1]) : pyr_vertex(q[0][0], q[0][1], q[1][0], q[1][1]);
+    o2[(size_t)by * c2 + bx] = (kind & 1) ? pyr_normal(q[0][0], q[0][1], q[1][0], q[1][1]) : pyr_vertex(q[0][0], q[0][1], q[1][0], q[1][1]);
 }
 
+static void pyr_maps(kf_ctx* c, PyrMaps& m) {
+  float4** src[4] = {c->new_v, c->new_n, c->model_v, c->model_n};
+  for (int k = 0; k < 4; ++k) { m.in[k] = src[k][0]; m.l1[k] = src[k][1]; m.l2[k] = c->levels > 2 ? src[k][2] : nullptr; }
+}
 int kf_launch_pyramids(kf_ctx* c, bool model, bool vertices, bool normals) {
   if (c->levels < 2 || (!vertices && !normals)) return 0;
-  PyrMaps m;
-  float4** v = model ? c->model_v : c->new_v;
-  float4** n = model ? c->model_n : c->new_n;
-  m.in[0] = v[0]; m.l1[0] = v[1]; m.l2[0] = c->levels > 2 ? v[2] : nullptr;
-  m.in[1] = n[0]; m.l1[1] = n[1]; m.l2[1] = c->levels > 2 ? n[2] : nullptr;
+  PyrMaps m; pyr_maps(c, m);
   int c1 = c->cols >> 1, r1 = c->rows >> 1;
   dim3 grid(kf_div_up(kf_div_up(c1, 2), 32), kf_div_up(kf_div_up(r1, 2), 8), (vertices && normals) ? 2 : 1);
-  hipLaunchKernelGGL(k_pyramid, grid, dim3(256), 0, c->stream, m, c->cols, c->rows, c->levels, vertices ? 0 : 1);
+  hipLaunchKernelGGL(k_pyramid, grid, dim3(256), 0, c->stream, m, c->cols, c->rows, c->levels, (model ? 2 : 0) + (vertices ? 0 : 1),
+                     (KfTrackState*)nullptr, (KfGridBarrier*)nullptr, -1);
+  return (int)hipGetLastError();
+}
+// all four pyramids (ICP.cpp:57-60) plus the start-of-tracking bookkeeping in ONE launch
+int kf_launch_pyramids_and_begin(kf_ctx* c, int begin_mode) {
+  PyrMaps m; pyr_maps(c, m);
+  int c1 = c->cols >> 1, r1 = c->rows >> 1;
+  dim3 grid(c->levels < 2 ? 1 : kf_div_up(kf_div_up(c1, 2), 32), c->levels < 2 ? 1 : kf_div_up(kf_div_up(r1, 2), 8), c->levels < 2 ? 1 : 4);
+  hipLaunchKernelGGL(k_pyramid, grid, dim3(256), 0, c->stream, m, c->levels < 2 ? 0 : c->cols, c->levels < 2 ? 0 : c->rows, c->levels, 0,
+                     c->track, c->grid_barrier, begin_mode);
   return (int)hipGetLastError();
 }
 
 // ---- C ABI ---------------------------------------------------------------------------------------------------------
 extern "C" int kf_trunc_depth(kf_ctx* c, float tmin, float tmax) {
   if (!c) return KF_ERR_ARG;
+  int st = kf_materialize_raw_depth(c);
+  if (st) return st;
   int n = c->cols * c->rows;
   hipLaunchKernelGGL(k_trunc_depth, dim3(kf_div_up(n, 256)), dim3(256), 0, c->stream, c->raw_depth, c->trunced_depth, n, tmin, tmax);
   return (int)hipGetLastError();
@@ -176,13 +276,26 @@ extern "C" int kf_calculate_new_normals(kf_ctx* c) {
 }
 
 extern "C" int kf_preprocess(kf_ctx* c, float tmin, float tmax, float sigma_pixel, float sigma_depth, const kf_camera_params* cam) {
-  if (!c) return KF_ERR_ARG;
+  if (!c || !cam || (int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
   int st;
   kf_evt_begin(c, KF_STAGE_PREPROCESS);
-  if ((st = kf_trunc_depth(c, tmin, tmax))) return st;
-  if ((st = kf_bilateral_filter_depth(c, sigma_pixel, sigma_depth))) return st;
-  if ((st = kf_calculate_new_vertices(c, cam))) return st;
-  st = kf_calculate_new_normals(c);
+  const int radius = (int)ceil(2.0 * (double)sigma_pixel);
+  if (radius == 4) {                                           // stock sigma_pixel = 2: two fused launches instead of five
+    const float sd_inv = (float)(0.5 / (double)(sigma_depth * sigma_depth));
+    const float ss_inv = (float)(0.5 / (double)(sigma_pixel * sigma_pixel));
+    dim3 grid(kf_div_up(c->cols, BIL_TX), kf_div_up(c->rows, BIL_TY));
+    hipLaunchKernelGGL(k_gate_bilateral<4>, grid, dim3(256), 0, c->stream, c->pending_mm, c->raw_depth, c->raw_depth, c->trunced_depth,
+                       c->filtered_depth, c->cols, c->rows, tmin, tmax, ss_inv, sd_inv, sigma_depth);
+    c->pending_mm = nullptr;
+    dim3 grid2(kf_div_up(c->cols, 64), kf_div_up(c->rows, 4));
+    hipLaunchKernelGGL(k_vertices_normals, grid2, dim3(256), 0, c->stream, c->filtered_depth, c->new_v[0], c->new_n[0], to_cam(cam));
+    st = (int)hipGetLastError();
+  } else {
+    if ((st = kf_trunc_depth(c, tmin, tmax))) return st;
+    if ((st = kf_bilateral_filter_depth(c, sigma_pixel, sigma_depth))) return st;
+    if ((st = kf_calculate_new_vertices(c, cam))) return st;
+    st = kf_calculate_new_normals(c);
+  }
   kf_evt_end(c, KF_STAGE_PREPROCESS);
   return st;
 }

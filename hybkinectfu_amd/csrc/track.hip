@@ -701,9 +701,7 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   if (c->levels == 1) iters[0] = 3; else if (c->levels == 2) { iters[0] = 10; iters[1] = 5; } else { iters[0] = 10; iters[1] = 5; iters[2] = 4; }
   int st;
   kf_evt_begin(c, KF_STAGE_TRACK);
-  if ((st = kf_launch_pyramids(c, false, true, true))) return st;       // ICP.cpp:57-60
-  if ((st = kf_launch_pyramids(c, true, true, true))) return st;
-  hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, 1, c->grid_barrier);
+  if ((st = kf_launch_pyramids_and_begin(c, 1))) return st;             // ICP.cpp:57-63: four pyramids + loop set-up, one launch
   kf_camera_params cams[KF_MAX_LEVELS]; cams[0] = *cam0;
   for (int l = 1; l < c->levels; ++l) {                      // ICP.cpp:36-48
     cams[l].cols = cams[l - 1].cols / 2; cams[l].rows = cams[l - 1].rows / 2;
