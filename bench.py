@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--stages", action="store_true", help="extra instrumented pass: per-stage milliseconds to stderr")
     ap.add_argument("--config", default="auto", choices=["auto", "c2", "c4"],
                     help="auto: C2 (512^3 @ 4 m) on 1 GPU, C4 (1024^3 @ 6 m, z-slabs) on N > 1, as BASELINE.json's metric states")
+    ap.add_argument("--icp-mode", default="replicated", choices=["replicated", "allreduce"],
+                    help="multi-GPU tracking: every rank runs the whole ICP (default) or pixels are split and the 27-float system all-reduced")
     ap.add_argument("--force-slab", action="store_true", help="run the z-slab pipeline (and its collectives) even with one rank")
     args = ap.parse_args()
 
@@ -112,7 +114,7 @@ def main():
         pipe = Pipe(kcam, res, size, wl, device=local_rank)
     else:
         from hybkinectfu_amd.pipeline import SlabPipeline as Pipe
-        pipe = Pipe(kcam, res, size, wl, rank=rank, world=world, device=local_rank)
+        pipe = Pipe(kcam, res, size, wl, rank=rank, world=world, device=local_rank, icp_mode=args.icp_mode)
 
     def run(first, count):
         for k in range(first, first + count):

@@ -38,6 +38,11 @@ struct TrackArgs {
   int consume;                                   // 1: first fold + apply the previous step's system
   int n_prev_wg;                                 // workgroups that wrote the previous step's partials
   int sdf;                                       // consume with the SDF tracker's update rule (exp map, convergence test)
+  // pixel-partitioned ICP (multi-GPU): this context sums only pixels [px_begin, px_end) (0,0 = all); the previous step's
+  // system arrives all-reduced in ext_prev (27 floats) instead of workgroup partials; fold_out receives this step's 27 sums
+  int px_begin, px_end;
+  const float* ext_prev;
+  float* fold_out;
   // SDF tracker only
   KfVolume vol; const float* depth;
 };
@@ -264,7 +269,8 @@ __device__ __forceinline__ bool step_prologue(const TrackArgs& a, float* s_cur, 
     if (a.use_state && blockIdx.x == 0 && threadIdx.x < 16) st->cur[(a.step + 1) & 1][threadIdx.x] = s_cur[threadIdx.x];
     return true;
   }
-  fold_partials(a.partials + (size_t)((a.step + 1) & 1) * KF_ICP_MAX_WG * 32, a.n_prev_wg, s_tot);
+  if (a.ext_prev) fold_partials(a.ext_prev, 1, s_tot);
+  else fold_partials(a.partials + (size_t)((a.step + 1) & 1) * KF_ICP_MAX_WG * 32, a.n_prev_wg, s_tot);
   apply_step(a, s_tot, s_cur, s_code);
   const int code = *s_code;
   if (blockIdx.x == 0) {
@@ -331,8 +337,8 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_step(TrackArgs a) {
   __shared__ float s_wave[27 * (ICP_THREADS / 16)], s_tot[(ICP_THREADS / 32) * 32];
   __shared__ int s_code;
   // the lane's own vertices / normals do not depend on the running transform: request them before the fold + solve
-  const int npx = a.cam.cols * a.cam.rows;
-  const int base = blockIdx.x * (ICP_THREADS * ICP_PX) + threadIdx.x;
+  const int npx = a.px_end > 0 ? a.px_end : a.cam.cols * a.cam.rows;
+  const int base = a.px_begin + blockIdx.x * (ICP_THREADS * ICP_PX) + threadIdx.x;
   float4 iv[ICP_PX], in_[ICP_PX];
 #pragma unroll
   for (int j = 0; j < ICP_PX; ++j) {
@@ -623,9 +629,12 @@ __global__ void __launch_bounds__(ICP_THREADS) k_track_finish(TrackArgs a) {
   __shared__ float s_cur[16], s_linv[16], s_tot[32 * 32];
   __shared__ int s_code;
   KfTrackState* st = a.track;
-  if (!a.use_state) {
+  if (!a.use_state || a.fold_out) {                                       // fold only: per-call wrappers, pixel-partitioned ICP
     fold_partials(a.partials + (size_t)((a.step + 1) & 1) * KF_ICP_MAX_WG * 32, a.n_prev_wg, s_tot);
-    if (threadIdx.x < 27) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
+    if (threadIdx.x < 32) {
+      if (a.fold_out) a.fold_out[threadIdx.x] = threadIdx.x < 27 ? s_tot[threadIdx.x] : 0.f;
+      else if (threadIdx.x < 27) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
+    }
     return;
   }
   if (!step_prologue(a, s_cur, s_linv, s_tot, &s_code)) return;            // lost or converged: already recorded
@@ -743,6 +752,58 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   a.step = step; a.consume = 1; a.n_prev_wg = prev_grid;
   hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, a);
   kf_evt_end(c, KF_STAGE_TRACK);
+  return (int)hipGetLastError();
+}
+
+// ---- pixel-partitioned ICP for z-slab / multi-GPU runs (all-reduce of the 27-float system) -------------
+// The caller owns a 32-float device buffer `dev_sums`.  Per Gauss-Newton step: kf_icp_partition_step sums this rank's pixel
+// range and leaves the 27 sums in dev_sums; the caller all-reduces dev_sums (SUM) over the ranks; the next step (or
+// kf_icp_partition_finish) consumes it.  Every rank applies the identical all-reduced system, so the poses agree bitwise.
+extern "C" int kf_icp_partition_begin(kf_ctx* c, uint32_t frame_id) {
+  if (!c) return KF_ERR_ARG;
+  return kf_launch_pyramids_and_begin(c, frame_id == 0 ? 0 : 1);
+}
+static int icp_iters(int levels, int iters[KF_MAX_LEVELS]) {                // ICP.cpp:14-35
+  iters[0] = iters[1] = iters[2] = 0;
+  if (levels == 1) iters[0] = 3; else if (levels == 2) { iters[0] = 10; iters[1] = 5; } else if (levels == 3) { iters[0] = 10; iters[1] = 5; iters[2] = 4; } else return 0;
+  return iters[0] + iters[1] + iters[2];
+}
+extern "C" int kf_icp_partition_steps(kf_ctx* c) { int it[KF_MAX_LEVELS]; return c ? icp_iters(c->levels, it) : 0; }
+extern "C" int kf_icp_partition_step(kf_ctx* c, uint32_t step, const kf_icp_params* icp, const kf_camera_params* cam0,
+                                     uint32_t part, uint32_t parts, float* dev_sums) {
+  if (!c || !icp || !cam0 || !dev_sums || parts == 0 || part >= parts) return KF_ERR_ARG;
+  int iters[KF_MAX_LEVELS];
+  const int total = icp_iters(c->levels, iters);
+  if ((int)step >= total) return KF_ERR_ARG;
+  int l = c->levels - 1, s = (int)step;                                     // coarse -> fine
+  while (s >= iters[l]) { s -= iters[l]; --l; }
+  kf_camera_params cam = *cam0;
+  for (int k = 0; k < l; ++k) { cam.cols /= 2; cam.rows /= 2; cam.cx /= 2; cam.cy /= 2; cam.fx /= 2; cam.fy /= 2; }
+  TrackArgs a; memset(&a, 0, sizeof(a));
+  a.use_state = 1;
+  a.new_v = c->new_v[l]; a.new_n = c->new_n[l]; a.model_v = c->model_v[l]; a.model_n = c->model_n[l];
+  a.cam = to_cam(&cam);
+  a.dist_thres = icp->dist_thres; a.sin_thres = icp->norm_sin_thres; a.dist_shake = icp->dist_shake; a.angle_shake = icp->angle_shake;
+  a.partials = c->icp_partials; a.track = c->track;
+  a.step = (int)step; a.consume = step > 0; a.ext_prev = step > 0 ? dev_sums : nullptr;
+  const int rows_per = kf_div_up(a.cam.rows, (int)parts);                    // whole image rows per rank
+  const int y0 = (int)part * rows_per, y1 = (y0 + rows_per < a.cam.rows) ? y0 + rows_per : a.cam.rows;
+  a.px_begin = y0 * a.cam.cols; a.px_end = (y1 > y0 ? y1 : y0) * a.cam.cols;
+  const int grid = (a.px_end > a.px_begin) ? icp_grid(a.px_end - a.px_begin) : 1;
+  if (grid > KF_ICP_MAX_WG) return KF_ERR_ARG;
+  if (a.px_end <= a.px_begin) { a.px_begin = 1; a.px_end = 1; }              // empty range: the kernel's bound check skips every pixel
+  hipLaunchKernelGGL(k_icp_step, dim3(grid), dim3(ICP_THREADS), 0, c->stream, a);
+  TrackArgs f = a; f.step = (int)step + 1; f.n_prev_wg = grid; f.fold_out = dev_sums; f.ext_prev = nullptr;
+  hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, f);
+  return (int)hipGetLastError();
+}
+extern "C" int kf_icp_partition_finish(kf_ctx* c, const kf_icp_params* icp, const float* dev_sums) {
+  if (!c || !icp || !dev_sums) return KF_ERR_ARG;
+  int iters[KF_MAX_LEVELS];
+  TrackArgs a; memset(&a, 0, sizeof(a));
+  a.use_state = 1; a.consume = 1; a.step = icp_iters(c->levels, iters); a.ext_prev = dev_sums;
+  a.dist_shake = icp->dist_shake; a.angle_shake = icp->angle_shake; a.partials = c->icp_partials; a.track = c->track;
+  hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, a);
   return (int)hipGetLastError();
 }
 

@@ -83,6 +83,7 @@ SYMBOLS = [
     "kf_marching_cubes", "kf_clear_triangles", "kf_triangle_count", "kf_read_triangles", "kf_download_map",
     "kf_upload_map", "kf_download_volume", "kf_upload_volume", "kf_get_volume_stats", "kf_stored_z_range",
     "kf_stage_timers", "kf_read_stage_ms", "kf_set_stream", "kf_raycast_volume_slab", "kf_set_model_maps_device", "kf_selftest_div",
+    "kf_icp_partition_begin", "kf_icp_partition_steps", "kf_icp_partition_step", "kf_icp_partition_finish",
 ]
 
 
@@ -241,6 +242,18 @@ class Context:
     def icp_track(self, frame_id, dist, sin, dist_shake, angle_shake):
         p = IcpParams(self.levels, sin, dist, dist_shake, angle_shake)
         _chk(self.lib.kf_icp_track(self.h, frame_id, C.byref(p), C.byref(self.cam)), "kf_icp_track")
+
+    def icp_partition_track(self, frame_id, dist, sin, dist_shake, angle_shake, part, parts, dev_sums_ptr, all_reduce):
+        """ICP with the pixels split over `parts` ranks; `all_reduce()` must sum the 32-float buffer at dev_sums_ptr over the ranks."""
+        p = IcpParams(self.levels, sin, dist, dist_shake, angle_shake)
+        _chk(self.lib.kf_icp_partition_begin(self.h, frame_id), "kf_icp_partition_begin")
+        if frame_id == 0:
+            return
+        for step in range(self.lib.kf_icp_partition_steps(self.h)):
+            _chk(self.lib.kf_icp_partition_step(self.h, step, C.byref(p), C.byref(self.cam), part, parts, C.c_void_p(dev_sums_ptr)),
+                 "kf_icp_partition_step")
+            all_reduce()
+        _chk(self.lib.kf_icp_partition_finish(self.h, C.byref(p), C.c_void_p(dev_sums_ptr)), "kf_icp_partition_finish")
 
     def sdf_track(self, frame_id, max_iter, dist_shake, angle_shake):
         p = SdfTrackerParams(max_iter, dist_shake, angle_shake)

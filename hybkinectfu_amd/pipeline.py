@@ -92,9 +92,10 @@ class SlabPipeline:
     MIN all-reduce of the crossing parameter and one integer SUM all-reduce of the winning vertex/normal maps.
     """
 
-    def __init__(self, kcam, res, size, wl=None, rank=0, world=1, device=0, max_triangles=0):
+    def __init__(self, kcam, res, size, wl=None, rank=0, world=1, device=0, max_triangles=0, icp_mode="replicated"):
         import torch
         import torch.distributed as dist
+        self.icp_mode = icp_mode            # "replicated" (default, faster at VGA) or "allreduce" (pixels split over the ranks)
         wl = wl or {}
         self.dist, self.torch = dist, torch
         self.rank, self.world = rank, world
@@ -110,12 +111,17 @@ class SlabPipeline:
         self.t = torch.empty((kcam.rows, kcam.cols), dtype=torch.float32, device=dev)
         self.v = torch.empty((kcam.rows, kcam.cols, 4), dtype=torch.float32, device=dev)
         self.n = torch.empty((kcam.rows, kcam.cols, 4), dtype=torch.float32, device=dev)
+        self.sums = torch.zeros(32, dtype=torch.float32, device=dev)
 
     def process_frame_device(self, dev_mm_ptr, frame_id):
         c, dist = self.ctx, self.dist
         c.set_depth_mm_device(dev_mm_ptr)
         c.preprocess(P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
-        c.icp_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+        if self.icp_mode == "allreduce":
+            c.icp_partition_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"],
+                                  self.rank, self.world, self.sums.data_ptr(), lambda: dist.all_reduce(self.sums, op=dist.ReduceOp.SUM))
+        else:
+            c.icp_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
         c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist)
         c.raycast_slab(None, self.inc, P["depth_trunc_min"], self.trunc_max, self.t.data_ptr(), self.v.data_ptr(), self.n.data_ptr())
         v, n = merge_candidates(self.t, self.v, self.n,

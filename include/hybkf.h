@@ -155,6 +155,17 @@ int kf_raycast_volume_slab(kf_ctx* ctx, int has_color, const kf_mat44* transform
                            float* dev_t, float* dev_v, float* dev_n);
 int kf_set_model_maps_device(kf_ctx* ctx, const float* dev_v, const float* dev_n);   /* model_{vertices,normals}_pyramid[0] <- device buffers */
 
+/* Pixel-partitioned ICP ("partition pixels across GPUs, all-reduce the 27-float system").  `dev_sums` is a
+ * caller-owned 32-float device buffer.  kf_icp_partition_begin builds the pyramids and arms the loop; for step = 0 ..
+ * kf_icp_partition_steps()-1, kf_icp_partition_step consumes the all-reduced system of the previous step from dev_sums,
+ * sums this rank's share (image rows part/parts) of the pixels and leaves its 27 sums in dev_sums for the caller to
+ * all-reduce (SUM); kf_icp_partition_finish applies the last system and commits the pose.  Asynchronous. */
+int kf_icp_partition_begin(kf_ctx* ctx, uint32_t frame_id);
+int kf_icp_partition_steps(kf_ctx* ctx);
+int kf_icp_partition_step(kf_ctx* ctx, uint32_t step, const kf_icp_params* icp, const kf_camera_params* depth_camera,
+                          uint32_t part, uint32_t parts, float* dev_sums);
+int kf_icp_partition_finish(kf_ctx* ctx, const kf_icp_params* icp, const float* dev_sums);
+
 /* cudaMarchingcube  src/cuda/marchingcube.cu:154-164.  Triangles are appended after those already stored
  * (the reference never clears its counter, src/cuda/MarchingcubeData.h:56,99) in the canonical order (z, y, x, k). */
 int kf_marching_cubes(kf_ctx* ctx, int has_color, float threshold_marchingcube);

@@ -80,3 +80,50 @@ def test_slabs_equal_whole_volume(world):
     assert len(wt) > 1000 and len(cat) == len(wt) and np.array_equal(cat.view(np.uint32), wt.view(np.uint32))
     for c in [whole] + slabs:
         c.close()
+
+
+def test_pixel_partitioned_icp_matches_replicated():
+    """Two contexts play two ranks: each sums half of the image rows per Gauss-Newton step, the 27-float systems are added
+    (the all-reduce) and both apply the same update.  Result: same verdict, pose within 1e-4 of the replicated tracker."""
+    cam = S.vga_camera()
+    kcam = K.camera(*cam)
+    size, res = 3.0, 128
+    trunc = 5 * size / res
+    ref = K.Context(kcam, res, size, P["volume_max_weight"], levels=3)
+    ranks = [K.Context(kcam, res, size, P["volume_max_weight"], levels=3) for _ in range(2)]
+    dev = torch.device("cuda", 0)
+    sums = [torch.zeros(32, dtype=torch.float32, device=dev) for _ in ranks]
+    for c in [ref] + ranks:
+        c.set_pose(S.pose0(size))
+    for k in range(3):
+        mm = S.render_depth_mm(S.trajectory_pose(k, size), cam, size)
+        for c in [ref] + ranks:
+            c.upload_depth_mm(mm)
+            c.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+        ref.icp_track(k, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+        icp = K.IcpParams(3, P["icp_thre_sin_angle"], P["icp_thre_dist"], P["camera_shake_dist"], P["camera_shake_angle"])
+        lib = K.load()
+        for r, c in enumerate(ranks):
+            assert lib.kf_icp_partition_begin(c.h, k) == 0
+        if k > 0:
+            import ctypes as C
+            for step in range(lib.kf_icp_partition_steps(ranks[0].h)):
+                for r, c in enumerate(ranks):
+                    assert lib.kf_icp_partition_step(c.h, step, C.byref(icp), C.byref(c.cam), r, 2, C.c_void_p(sums[r].data_ptr())) == 0
+                    c.sync()
+                total = sums[0] + sums[1]                               # the all-reduce
+                for s_ in sums:
+                    s_.copy_(total)
+                torch.cuda.synchronize()
+            for r, c in enumerate(ranks):
+                assert lib.kf_icp_partition_finish(c.h, C.byref(icp), C.c_void_p(sums[r].data_ptr())) == 0
+        ok_ref, pose_ref, _, it_ref = ref.track_result()
+        res_r = [c.track_result() for c in ranks]
+        assert ok_ref and all(r[0] for r in res_r)
+        assert np.array_equal(res_r[0][1].view(np.uint32), res_r[1][1].view(np.uint32))        # ranks agree bitwise
+        assert np.max(np.abs(res_r[0][1] - pose_ref)) < 1e-4 and res_r[0][3] == it_ref
+        for c in [ref] + ranks:
+            c.integrate(None, trunc, 2.5)
+            c.raycast(None, 0.7 * trunc, P["depth_trunc_min"], P["depth_trunc_max"])
+    for c in [ref] + ranks:
+        c.close()
