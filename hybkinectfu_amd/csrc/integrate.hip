@@ -30,6 +30,7 @@ struct IntegrateArgs {
   float sdf_trunc, max_dist;
   int has_color, color_angled;
   int tiles_x, tiles_y;
+  float fr_slope[4], fr_norm[4]; // frustum side planes through the eye (left, right, top, bottom), widened by one pixel: slope and sqrt(1+slope^2)
   int exp_mode;                  // timing experiments only (KF_INTEGRATE_EXP): 1 = no store, 2 = no load/store
 };
 
@@ -70,37 +71,38 @@ __device__ __forceinline__ bool cull_sphere_visible(const IntegrateArgs& a, cons
   pz = m[8] * cx + m[9] * cy + m[10] * cz + m[11];
   if (pz + r <= 0.f) return false;                                     // every voxel has pf.z <= 0
   if (pz - r >= a.max_dist + a.sdf_trunc) return false;                // needs pf.z < depth + trunc < max_dist + trunc
-  // frustum side planes through the eye, widened by one pixel
-  const float tl = (-1.f - a.dcam.cx) / a.dcam.fx, tr = ((float)a.dcam.cols - a.dcam.cx) / a.dcam.fx;
-  const float tt = (-1.f - a.dcam.cy) / a.dcam.fy, tb = ((float)a.dcam.rows - a.dcam.cy) / a.dcam.fy;
-  if ((px - tl * pz) < -r * sqrtf(1.f + tl * tl)) return false;
-  if ((tr * pz - px) < -r * sqrtf(1.f + tr * tr)) return false;
-  if ((py - tt * pz) < -r * sqrtf(1.f + tt * tt)) return false;
-  if ((tb * pz - py) < -r * sqrtf(1.f + tb * tb)) return false;
+  if ((px - a.fr_slope[0] * pz) < -r * a.fr_norm[0]) return false;
+  if ((a.fr_slope[1] * pz - px) < -r * a.fr_norm[1]) return false;
+  if ((py - a.fr_slope[2] * pz) < -r * a.fr_norm[2]) return false;
+  if ((a.fr_slope[3] * pz - py) < -r * a.fr_norm[3]) return false;
   return true;
 }
 
-__global__ void __launch_bounds__(256) k_integrate_cull(IntegrateArgs a) {
+#define CULL_WAVES 16
+__global__ void __launch_bounds__(CULL_WAVES * 64) k_integrate_cull(IntegrateArgs a) {
   if (a.track && !a.track->tracked) {                        // HybKinectfu.cpp:123: integrate only when tracking succeeded
     if (blockIdx.x == 0 && threadIdx.x == 0) a.cnt->frames_lost += 1;
     return;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) a.cnt->frames_fused += 1;
+  __shared__ unsigned s_cnt[CULL_WAVES];
+  __shared__ unsigned s_base;
   const KfVolume& v = a.vol;
   const int nmxy = (v.nb + 3) >> 2;                          // macro cells per x / y
   const int mz0 = v.bz0 >> 2, mz1 = (v.bz1 + 3) >> 2;        // macro layers touching the stored bricks
-  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * CULL_WAVES + wid;
   const int n_macro = nmxy * nmxy * (mz1 - mz0);
-  if (wave >= n_macro) return;
   const int mx = wave % nmxy, my = (wave / nmxy) % nmxy, mz = wave / (nmxy * nmxy) + mz0;
   const float* m = a.tinv;
   const float cell = v.cell;
   float px, py, pz;
-  // macro cell: voxel centres span [(32m+0.5), (32m+31.5)] * cell -> centre (32m+16)*cell, half-diagonal 15.5*sqrt(3)*cell
-  if (!cull_sphere_visible(a, m, (float)(mx * 32 + 16) * cell, (float)(my * 32 + 16) * cell, (float)(mz * 32 + 16) * cell,
-                           27.0f * cell + 1e-4f * v.size, px, py, pz)) return;
   const int bx = mx * 4 + (lane & 3), by = my * 4 + ((lane >> 2) & 3), bz = mz * 4 + (lane >> 4);
-  bool keep = bx < v.nb && by < v.nb && bz >= v.bz0 && bz < v.bz1;
+  // macro cell: voxel centres span [(32m+0.5), (32m+31.5)] * cell -> centre (32m+16)*cell, half-diagonal 15.5*sqrt(3)*cell
+  bool keep = wave < n_macro &&
+              cull_sphere_visible(a, m, (float)(mx * 32 + 16) * cell, (float)(my * 32 + 16) * cell, (float)(mz * 32 + 16) * cell,
+                                  27.0f * cell + 1e-4f * v.size, px, py, pz);
+  keep = keep && bx < v.nb && by < v.nb && bz >= v.bz0 && bz < v.bz1;
   // brick: voxel centres span [(8b+0.5), (8b+7.5)] * cell per axis -> centre (8b+4)*cell, half-diagonal 3.5*sqrt(3)*cell
   const float r = 6.1f * cell + 1e-4f * v.size;
   if (keep) keep = cull_sphere_visible(a, m, (float)(bx * 8 + 4) * cell, (float)(by * 8 + 4) * cell, (float)(bz * 8 + 4) * cell, r, px, py, pz);
@@ -114,20 +116,33 @@ __global__ void __launch_bounds__(256) k_integrate_cull(IntegrateArgs a) {
     ix0 = max(ix0, 0); iy0 = max(iy0, 0); ix1 = min(ix1, a.dcam.cols - 1); iy1 = min(iy1, a.dcam.rows - 1);
     if (ix0 > ix1 || iy0 > iy1) keep = false;
     else {
-      float dmax = 0.f;
-      for (int ty = iy0 >> 4; ty <= (iy1 >> 4); ++ty)
-        for (int tx = ix0 >> 4; tx <= (ix1 >> 4); ++tx) dmax = fmaxf(dmax, a.tile_max[ty * a.tiles_x + tx]);
-      if (dmax == 0.f) keep = false;                                     // no pixel under the brick can integrate
-      else if (zn >= dmax + a.sdf_trunc) keep = false;                   // every voxel lies behind every surface it can see
+      const int tx0 = ix0 >> 4, tx1 = ix1 >> 4, ty0 = iy0 >> 4, ty1 = iy1 >> 4;
+      if (tx1 - tx0 < 4 && ty1 - ty0 < 4) {
+        // the usual case (footprint within 4x4 tiles): sixteen independent clamped loads instead of a dependent loop
+        float dmax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dmax = fmaxf(dmax, a.tile_max[min(ty0 + j, ty1) * a.tiles_x + min(tx0 + i, tx1)]);
+        if (dmax == 0.f) keep = false;                                     // no pixel under the brick can integrate
+        else if (zn >= dmax + a.sdf_trunc) keep = false;                   // every voxel lies behind every surface it can see
+      }                                                                    // larger footprints (bricks close to the eye) are kept
     }
   }
+  // compaction: ONE atomic per 16 macro cells (an address takes ~11 ns per atomic; per-wave atomics made this pass
+  // cost more than the fusion itself at 1024^3)
   const unsigned long long mask = __ballot(keep);
-  if (mask == 0ull) return;
-  unsigned base = 0;
-  if (lane == 0) base = atomicAdd(&a.cnt->n_active_bricks, (unsigned)__popcll(mask));
-  base = __shfl(base, 0, 64);
+  if (lane == 0) s_cnt[wid] = (unsigned)__popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned total = 0;
+#pragma unroll
+    for (int w = 0; w < CULL_WAVES; ++w) { const unsigned n = s_cnt[w]; s_cnt[w] = total; total += n; }
+    s_base = total ? atomicAdd(&a.cnt->n_active_bricks, total) : 0u;
+  }
+  __syncthreads();
   if (keep) {
-    const unsigned pos = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+    const unsigned pos = s_base + s_cnt[wid] + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
     a.queue[pos] = (unsigned)bx | ((unsigned)by << 10) | ((unsigned)(bz - v.bz0) << 20);   // packed brick coordinates: no div/mod to decode
   }
 }
@@ -272,6 +287,9 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   a.sdf_trunc = ip->sdf_truncation; a.max_dist = ip->max_integrate_dist;
   a.has_color = has_color; a.color_angled = use_angle_weight_color;
   a.tiles_x = kf_div_up(c->cols, 16); a.tiles_y = kf_div_up(c->rows, 16);
+  a.fr_slope[0] = (-1.f - a.dcam.cx) / a.dcam.fx; a.fr_slope[1] = ((float)a.dcam.cols - a.dcam.cx) / a.dcam.fx;
+  a.fr_slope[2] = (-1.f - a.dcam.cy) / a.dcam.fy; a.fr_slope[3] = ((float)a.dcam.rows - a.dcam.cy) / a.dcam.fy;
+  for (int i = 0; i < 4; ++i) a.fr_norm[i] = sqrtf(1.f + a.fr_slope[i] * a.fr_slope[i]);
   { static int em = -1; if (em < 0) { const char* e = getenv("KF_INTEGRATE_EXP"); em = e ? atoi(e) : 0; } a.exp_mode = em; }
   if (transform) {
     for (int i = 0; i < 16; ++i) a.pose_val.m[i] = transform->m[i];
@@ -283,8 +301,8 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   hipLaunchKernelGGL(k_integrate_prepare, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, c->stream, a);
   {
     const int nmxy = (c->vol.nb + 3) >> 2, nmz = ((c->vol.bz1 + 3) >> 2) - (c->vol.bz0 >> 2);
-    const unsigned n_macro = (unsigned)nmxy * nmxy * nmz;                      // one wave per macro cell, four per workgroup
-    hipLaunchKernelGGL(k_integrate_cull, dim3((n_macro + 3) / 4), dim3(256), 0, c->stream, a);
+    const unsigned n_macro = (unsigned)nmxy * nmxy * nmz;                      // one wave per macro cell, sixteen per workgroup
+    hipLaunchKernelGGL(k_integrate_cull, dim3((n_macro + CULL_WAVES - 1) / CULL_WAVES), dim3(CULL_WAVES * 64), 0, c->stream, a);
   }
   unsigned grid = (unsigned)(c->n_stored_bricks < 4096 ? c->n_stored_bricks : 4096);
   kf_evt_begin(c, KF_STAGE_INTEGRATE_KERNEL);

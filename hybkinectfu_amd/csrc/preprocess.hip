@@ -90,22 +90,26 @@ __global__ void __launch_bounds__(256) k_gate_bilateral(const uint16_t* __restri
   float result = value;
   if (value != 0.f) {
     float sum1 = 0.f, sum2 = 0.f;
-    bool aborted = false;
+    float max_diff = 0.f;                                  // largest |tap - centre| over the valid taps: the 5-sigma test, once
     const float thr = 5 * sigma_depth;
 #pragma unroll
     for (int dy = -R; dy <= R; ++dy) {
+      float row[2 * R + 1];
+#pragma unroll
+      for (int dx = -R; dx <= R; ++dx) row[dx + R] = tile[(ly + R + dy) * TW + lx + R + dx];
 #pragma unroll
       for (int dx = -R; dx <= R; ++dx) {
-        const float tmp = tile[(ly + R + dy) * TW + lx + R + dx];
+        const float tmp = row[dx + R];
         const bool valid = tmp != 0.f;
-        aborted |= valid && (fabsf(tmp - value) > thr);
+        const float diff = value - tmp;
+        max_diff = fmaxf(max_diff, valid ? fabsf(diff) : 0.f);
         const float space2 = (float)(dx * dx + dy * dy);
-        const float data2 = (value - tmp) * (value - tmp);
-        const float w = valid ? __expf(-(space2 * ss_inv + data2 * sd_inv)) : 0.f;
+        const float arg = -(space2 * ss_inv + diff * diff * sd_inv);
+        const float w = __expf(valid ? arg : -INFINITY);    // exp(-inf) = +0: selecting the argument keeps the tap loop straight-line
         sum1 += tmp * w; sum2 += w;
       }
     }
-    if (!aborted && sum2 > 0.f) result = sum1 / sum2;
+    if (!(max_diff > thr) && sum2 > 0.f) result = sum1 / sum2;
   }
   filtered[y * cols + x] = result;
 }

@@ -4,7 +4,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 i = len(rows) // 2
-while "k_depth_mm_to_m" not in rows[i]["Kernel_Name"]:
+while "k_gate_bilateral" not in rows[i]["Kernel_Name"]:
     i += 1
 t0 = int(rows[i]["Start_Timestamp"]); prev_end = t0
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 36
