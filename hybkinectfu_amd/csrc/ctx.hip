@@ -35,7 +35,7 @@ extern "C" int kf_destroy(kf_ctx* c) {
   hipSetDevice(c->cfg.device);
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->own_stream) hipStreamSynchronize(c->own_stream);
-  void* ptrs[] = {c->depth_mm, c->raw_depth, c->trunced_depth, c->filtered_depth, c->raw_rgb, c->raycast_rgb, c->icp_partials,
+  void* ptrs[] = {c->depth_mm, c->raw_depth, c->trunced_depth, c->filtered_depth, c->raw_rgb, c->raycast_rgb, c->icp_partials, c->icp_loop_slots,
                   c->track, c->counters, c->grid_barrier, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macro, c->active_bricks,
                   c->tile_max_depth, c->triangles, c->mc_block_counts};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -92,6 +92,8 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
     lc >>= 1; lr >>= 1;
   }
   TRY(dev_alloc(&c->icp_partials, (size_t)2 * KF_ICP_MAX_WG * 32));      // double-buffered by Gauss-Newton step parity
+  TRY(dev_alloc(&c->icp_loop_slots, (size_t)KF_ICP_LOOP_STEPS * KF_ICP_MAX_WG * 32));
+  TRY((int)hipMemsetAsync(c->icp_loop_slots, 0, (size_t)KF_ICP_LOOP_STEPS * KF_ICP_MAX_WG * 32 * sizeof(unsigned long long), c->stream));
   TRY(dev_alloc(&c->track, 1)); TRY(dev_alloc(&c->counters, 1)); TRY(dev_alloc(&c->grid_barrier, 1));
   TRY((int)hipMemsetAsync(c->grid_barrier, 0, sizeof(KfGridBarrier), c->stream)); TRY(dev_alloc(&c->scratch_mats, 8 * 16));
   TRY((int)hipMemsetAsync(c->track, 0, sizeof(KfTrackState), c->stream));

@@ -139,8 +139,8 @@ __device__ __forceinline__ void mat44_mul(const float* a, const float* b, float*
   for (int i = 0; i < 16; ++i) out[i] = r[i];
 }
 // vector6ToTransformMatrix (ICP.cpp:95-111, SDF.cpp:25-43): R = Rx Ry Rz, shake test on the rotation angle and |t|
-__device__ __forceinline__ bool vector6_to_transform(const float x[6], float dist_shake, float angle_shake, float t[16]) {
-  const float c0 = cosf(x[0]), s0 = sinf(x[0]), c1 = cosf(x[1]), s1 = sinf(x[1]), c2 = cosf(x[2]), s2 = sinf(x[2]);
+__device__ __forceinline__ bool transform_from_sincos(const float x[6], float c0, float s0, float c1, float s1, float c2, float s2,
+                                                      float dist_shake, float angle_shake, float t[16]) {
   const float Rx[9] = {1, 0, 0, 0, c0, -s0, 0, s0, c0};
   const float Ry[9] = {c1, 0, s1, 0, 1, 0, -s1, 0, c1};
   const float Rz[9] = {c2, -s2, 0, s2, c2, 0, 0, 0, 1};
@@ -155,6 +155,10 @@ __device__ __forceinline__ bool vector6_to_transform(const float x[6], float dis
 #pragma unroll
   for (int i = 0; i < 16; ++i) t[i] = o[i];
   return true;
+}
+__device__ __forceinline__ bool vector6_to_transform(const float x[6], float dist_shake, float angle_shake, float t[16]) {
+  const float c0 = cosf(x[0]), s0 = sinf(x[0]), c1 = cosf(x[1]), s1 = sinf(x[1]), c2 = cosf(x[2]), s2 = sinf(x[2]);
+  return transform_from_sincos(x, c0, s0, c1, s1, c2, s2, dist_shake, angle_shake, t);
 }
 
 // ---- fold the previous step's partial sums: identical order in every workgroup ------------------------------------------
@@ -225,27 +229,64 @@ enum { STEP_APPLIED = 0, STEP_LOST_DET = 1, STEP_LOST_SHAKE = 2, STEP_CONVERGED 
 //   ICP: minimizePointToPlaneErrFunc (ICP.cpp:117-143) + loop body of estimateCameraPose (:71-82)
 //   SDF: loop body of CameraPoseFinderSDF::estimateCameraPose (SDF.cpp:62-101)
 __device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_tot, float* s_cur, int* s_code) {
+  if (!a.sdf) {
+    // ICP: the determinant test (ICP.cpp:138) and the solve + increment (:143, :71-82) do not depend on each other, so two
+    // lanes of DIFFERENT waves run them side by side and lane 0 keeps the solve's result only if the determinant passed.
+    // LDS scratch behind the 27 totals (s_tot + 32): [0..15] candidate transform, [16] solve verdict, [17] det verdict,
+    // [20..25] the increment x, [26..28] cosines and [29..31] sines of its three angles.
+    float* scratch = const_cast<float*>(s_tot) + 32;
+    const unsigned det_lane = blockDim.x > 64u ? 64u : 1u;
+    if (threadIdx.x == det_lane) {
+      float A[36], b[6];
+      unpack27(s_tot, A, b);
+      scratch[17] = ((double)det6(A) < 1E-10) ? 1.f : 0.f;
+    }
+    if (threadIdx.x == 0) {
+      float A[36], b[6], x[6];
+      unpack27(s_tot, A, b);
+      llt_solve6(A, b, x);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) scratch[20 + i] = x[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {                                                 // the three Euler angles: one lane each, one pass of the trig code
+      const float ang = scratch[20 + threadIdx.x];
+      scratch[26 + threadIdx.x] = cosf(ang); scratch[29 + threadIdx.x] = sinf(ang);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float x[6], T[16], ncur[16];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) x[i] = scratch[20 + i];
+      const bool still = transform_from_sincos(x, scratch[26], scratch[29], scratch[27], scratch[30], scratch[28], scratch[31],
+                                               a.dist_shake, a.angle_shake, T);
+      scratch[16] = still ? 0.f : 1.f;
+      if (still) {
+        mat44_mul(T, s_cur, ncur);                                         // ICP.cpp:81 cur = T * cur
+        for (int i = 0; i < 16; ++i) scratch[i] = ncur[i];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int code = STEP_APPLIED;
+      if (scratch[17] != 0.f) code = STEP_LOST_DET;
+      else if (scratch[16] != 0.f) code = STEP_LOST_SHAKE;
+      else for (int i = 0; i < 16; ++i) s_cur[i] = scratch[i];
+      *s_code = code;
+    }
+    __syncthreads();
+    return;
+  }
   if (threadIdx.x == 0) {
     float A[36], b[6], x[6], T[16], ncur[16];
     unpack27(s_tot, A, b);
     int code = STEP_APPLIED;
-    if (!a.sdf) {
-      float m[36];
-#pragma unroll
-      for (int i = 0; i < 36; ++i) m[i] = A[i];
-      if ((double)det6(m) < 1E-10) code = STEP_LOST_DET;                 // ICP.cpp:138
-    }
-    if (code == STEP_APPLIED) {
-      llt_solve6(A, b, x);
-      if (!vector6_to_transform(x, a.dist_shake, a.angle_shake, T)) code = STEP_LOST_SHAKE;
-      else if (a.sdf) {
-        const float nx = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
-        if (nx < 0.001f) code = STEP_CONVERGED;                            // SDF.cpp:87-90: stop before applying x
-        else { sdf_apply_increment(x, s_cur, ncur); for (int i = 0; i < 16; ++i) s_cur[i] = ncur[i]; }
-      } else {
-        mat44_mul(T, s_cur, ncur);                                         // ICP.cpp:81 cur = T * cur
-        for (int i = 0; i < 16; ++i) s_cur[i] = ncur[i];
-      }
+    llt_solve6(A, b, x);
+    if (!vector6_to_transform(x, a.dist_shake, a.angle_shake, T)) code = STEP_LOST_SHAKE;
+    else {
+      const float nx = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
+      if (nx < 0.001f) code = STEP_CONVERGED;                              // SDF.cpp:87-90: stop before applying x
+      else { sdf_apply_increment(x, s_cur, ncur); for (int i = 0; i < 16; ++i) s_cur[i] = ncur[i]; }
     }
     *s_code = code;
   }
@@ -373,36 +414,56 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_step(TrackArgs a) {
 }
 
 // ---- persistent ICP: the whole 19-step loop in ONE launch ---------------------------------------------------------------------
-// One 1024-lane workgroup per CU (124 VGPRs -> exactly one per CU), at most 75 of them at VGA, all co-resident.  Between two
-// Gauss-Newton steps the workgroups meet at a software grid barrier built as the guide's hand-off recipe prescribes
-// (MI355X_MICROARCH.md "Valid forms", table row 1): every partial sum is stored write-through (sc1), each storing wave drains
-// its stores, the workgroup meets, ONE lane adds to an agent-scope arrival counter and polls it with sc1 loads, the rest of
-// the workgroup waits at a workgroup barrier, and every later load of the partials is an sc1 load.  No fence, no kernel
-// boundary: a step costs the barrier (~1-2 us) instead of a dependent dispatch (~5 us measured here) plus a cold start of the
-// 30 KB straight-line step code, which is what bounded the one-launch-per-step form at ~22 us per step.
+// One 512-lane workgroup per CU (no scratch at <= 256 VGPRs), 150 of them at VGA, all co-resident.  Between two Gauss-Newton
+// steps nothing but the 27 partial sums of each workgroup has to cross CUs, so there is no grid barrier: a workgroup
+// publishes its sums as tagged 64-bit words (one write-through store each) and every workgroup folds all of them, polling
+// until the tags are current (fold_partials_tagged below; MI355X_MICROARCH.md "Valid forms": sc1 store -> sc1 load hand-off).
+// A step then costs one store->load propagation (~1 us) instead of a dependent dispatch (~5 us measured here) plus a cold
+// start of the 30 KB straight-line step code, which is what bounded the one-launch-per-step form at ~22 us per step; the
+// two-level counter barrier this replaces cost three dependent atomic round trips (~4 us) per step.
 struct IcpLoopArgs {
   const float4* new_v[KF_MAX_LEVELS]; const float4* new_n[KF_MAX_LEVELS];
   const float4* model_v[KF_MAX_LEVELS]; const float4* model_n[KF_MAX_LEVELS];
   KfCam cam[KF_MAX_LEVELS];
   int iters[KF_MAX_LEVELS]; int levels;
   float dist_thres, sin_thres, dist_shake, angle_shake;
-  float* partials;                               // 2 x KF_ICP_MAX_WG x 32, by step parity
+  unsigned long long* slots;                     // KF_ICP_LOOP_STEPS x KF_ICP_MAX_WG x 32 tagged partial sums, one array per step
+  unsigned tag_base;                             // this launch's sequence number (host counter x 64); tag = tag_base + step
   KfTrackState* track;
-  KfGridBarrier* barrier;
   int exp_mode;                                  // timing experiments only (KF_ICP_EXP)
 };
 
-__device__ __forceinline__ void fold_partials_sc1(const float* partials, int n_wg, float* s_tot) {
+#define ICP_SPIN_LIMIT 4000000u
+#define ICP_FOLD_BATCH 10
+// Partial sums of the persistent loop travel as 64-bit (value, tag) words: the tag is the launch's sequence number plus the
+// Gauss-Newton step, every step has its own slot array, and a word is published by ONE 8-byte write-through store -- so a
+// reader needs no barrier and no flag: it polls the words it is about to add until their tags are current.  The adds run
+// in the order of fold_partials (workgroup-major within a part, then the parts), so both launch forms give the same bits.
+__device__ __forceinline__ void fold_partials_tagged(const unsigned long long* slots, int n_wg, unsigned tag, float* s_tot, int* s_abort) {
   const int k = threadIdx.x & 31, part = threadIdx.x >> 5, parts = blockDim.x >> 5;
   float s = 0.f;
   if (k < 27) {
-    for (int w = part; w < n_wg; w += 4 * parts) {
-      const int w1 = w + parts, w2 = w + 2 * parts, w3 = w + 3 * parts;
-      const float v0 = __hip_atomic_load(&partials[w * 32 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float v1 = (w1 < n_wg) ? __hip_atomic_load(&partials[w1 * 32 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-      const float v2 = (w2 < n_wg) ? __hip_atomic_load(&partials[w2 * 32 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-      const float v3 = (w3 < n_wg) ? __hip_atomic_load(&partials[w3 * 32 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-      s += v0; s += v1; s += v2; s += v3;
+    for (int w0 = part; w0 < n_wg; w0 += ICP_FOLD_BATCH * parts) {
+      float v[ICP_FOLD_BATCH];
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < ICP_FOLD_BATCH; ++j) {
+          const int w = w0 + j * parts;
+          v[j] = 0.f;
+          if (w < n_wg) {
+            const unsigned long long u = __hip_atomic_load(&slots[w * 32 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[j] = __uint_as_float((unsigned)u);
+            ok = ok && (unsigned)(u >> 32) == tag;
+          }
+        }
+        if (ok) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > ICP_SPIN_LIMIT) { *s_abort = 1; break; }                   // never spin forever: report instead
+      }
+#pragma unroll
+      for (int j = 0; j < ICP_FOLD_BATCH; ++j) s += v[j];
     }
   }
   s_tot[part * 32 + k] = s;
@@ -417,7 +478,6 @@ __device__ __forceinline__ void fold_partials_sc1(const float* partials, int n_w
   __syncthreads();
 }
 
-#define ICP_SPIN_LIMIT 4000000u
 __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   __shared__ float s_cur[16], s_linv[16];
   __shared__ float s_wave[27 * (ICP_THREADS / 16)], s_tot[(ICP_THREADS / 32) * 32];
@@ -456,7 +516,8 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     for (int it = 0; it < L.iters[l]; ++it, ++step) {
       KF_STAMP(0);
       if (step > 0 && L.exp_mode != 6) {
-        if (L.exp_mode != 3) fold_partials_sc1(L.partials + (size_t)((step + 1) & 1) * KF_ICP_MAX_WG * 32, n_prev, s_tot);
+        fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort);
+        if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = 3; st->tracked = 0; } return; }
         KF_STAMP(1);
         if (L.exp_mode == 1 || L.exp_mode == 3) { if (threadIdx.x == 0) s_code = STEP_APPLIED; __syncthreads(); } else
         apply_step(a, s_tot, s_cur, &s_code);
@@ -505,42 +566,20 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
           sw += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sw), 0x111, 0xf, 0xf, true));   // row_shr:1
           sw += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sw), 0x112, 0xf, 0xf, true));   // row_shr:2
           if (part == 3)
-            __hip_atomic_store(L.partials + (size_t)(step & 1) * KF_ICP_MAX_WG * 32 + blockIdx.x * 32 + k, sw,
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(L.slots + (size_t)step * KF_ICP_MAX_WG * 32 + blockIdx.x * 32 + k,
+                               ((unsigned long long)(L.tag_base + (unsigned)step) << 32) | (unsigned long long)__float_as_uint(sw),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       KF_STAMP(4);
-      // grid barrier: drain, meet, one lane arrives; everyone else waits at the workgroup barrier behind it.
-      // Two levels so that no word is hammered: workgroups that share blockIdx % 8 (one XCD under round-robin dispatch --
-      // a speed assumption only) arrive on their group's counter, the last of a group arrives on the top counter, the last
-      // of those publishes the generation word with a write-through store; waiters poll only that word (L2-served sc1
-      // loads, no atomic traffic on its line).  Counters are monotonic within the frame (zeroed by k_track_begin).
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        KfGridBarrier* gb = L.barrier;
-        const unsigned g = blockIdx.x & 7u, gsize = (gridDim.x + 7u - g) >> 3, ngroups = gridDim.x < 8u ? gridDim.x : 8u;
-        const unsigned t = __hip_atomic_fetch_add(&gb->group[g].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == gsize * (unsigned)(step + 1) - 1u) {
-          const unsigned tt = __hip_atomic_fetch_add(&gb->top.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (tt == ngroups * (unsigned)(step + 1) - 1u)
-            __hip_atomic_store(&gb->gen.v, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        unsigned spins = 0;
-        while (L.exp_mode != 5 && __hip_atomic_load(&gb->gen.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(step + 1)) {
-          __builtin_amdgcn_s_sleep(4);
-          if (++spins > ICP_SPIN_LIMIT) { s_abort = 1; break; }                  // never spin forever: report instead
-        }
-      }
-      __syncthreads();
-      if (s_abort) { if (threadIdx.x == 0) { st->status = 3; st->tracked = 0; } return; }
       KF_STAMP(5);
       n_prev = grid_l;
     }
   }
   if (stamp) { for (int i = 0; i < 6; ++i) st->reduced[20 + i] = seg[i]; }
   // the last step's system, then commit _pose (ICP.cpp:84)
-  fold_partials_sc1(L.partials + (size_t)((step + 1) & 1) * KF_ICP_MAX_WG * 32, n_prev, s_tot);
+  fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort);
+  if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = 3; st->tracked = 0; } return; }
   apply_step(a, s_tot, s_cur, &s_code);
   if (blockIdx.x != 0) return;
   if (threadIdx.x < 27 && L.exp_mode != 7) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
@@ -719,7 +758,8 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   const int grid0 = icp_grid(c->cols * c->rows);
   static int persistent_env = -1;
   if (persistent_env < 0) { const char* e = getenv("KF_ICP_PERSISTENT"); persistent_env = e ? atoi(e) : 1; }
-  if (persistent_env && grid0 <= c->num_cus && grid0 <= KF_ICP_MAX_WG && kf_live_contexts(c->cfg.device) == 1) {
+  if (persistent_env && grid0 <= c->num_cus && grid0 <= KF_ICP_MAX_WG && iters[0] + iters[1] + iters[2] <= KF_ICP_LOOP_STEPS &&
+      kf_live_contexts(c->cfg.device) == 1) {
     // every workgroup must be resident at once (software grid barrier): one 1024-lane workgroup per CU, grid0 <= #CUs
     IcpLoopArgs L; memset(&L, 0, sizeof(L));
     for (int l = 0; l < c->levels; ++l) {
@@ -728,7 +768,8 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
     }
     L.levels = c->levels;
     L.dist_thres = icp->dist_thres; L.sin_thres = icp->norm_sin_thres; L.dist_shake = icp->dist_shake; L.angle_shake = icp->angle_shake;
-    L.partials = c->icp_partials; L.track = c->track; L.barrier = c->grid_barrier;
+    c->icp_loop_seq += 64u;                                  // tags of one launch never collide with an earlier launch's slots
+    L.slots = c->icp_loop_slots; L.tag_base = c->icp_loop_seq; L.track = c->track;
     { static int em = -1; if (em < 0) { const char* e = getenv("KF_ICP_EXP"); em = e ? atoi(e) : 0; } L.exp_mode = em; }
     hipLaunchKernelGGL(k_icp_loop, dim3(grid0), dim3(ICP_THREADS), 0, c->stream, L);
     kf_evt_end(c, KF_STAGE_TRACK);
