@@ -36,7 +36,7 @@ extern "C" int kf_destroy(kf_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->own_stream) hipStreamSynchronize(c->own_stream);
   void* ptrs[] = {c->depth_mm, c->raw_depth, c->trunced_depth, c->filtered_depth, c->raw_rgb, c->raycast_rgb, c->icp_partials, c->icp_loop_slots,
-                  c->track, c->counters, c->grid_barrier, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macro, c->active_bricks,
+                  c->track, c->counters, c->grid_barrier, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macro, c->vol.negbits, c->active_bricks,
                   c->tile_max_depth, c->triangles, c->mc_block_counts};
   for (void* p : ptrs) if (p) hipFree(p);
   for (int l = 0; l < KF_MAX_LEVELS; ++l) {
@@ -114,6 +114,7 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
   TRY(dev_alloc(&v.flags, c->n_stored_bricks + 4));      // updated with 32-bit atomics: keep the last word whole
   v.nm = (v.res + KF_MACRO - 1) / KF_MACRO;
   TRY(dev_alloc(&v.macro, (size_t)v.nm * v.nm * v.nm + 4));   // read as 32-bit words by the raycast's LDS copy
+  TRY(dev_alloc(&v.negbits, kf_negbit_words(c->n_stored_bricks)));
   TRY(dev_alloc(&c->active_bricks, c->n_stored_bricks));
   TRY(dev_alloc(&c->tile_max_depth, (size_t)kf_div_up(c->cols, 16) * kf_div_up(c->rows, 16)));
   c->max_triangles = cfg->max_triangles;
@@ -136,6 +137,7 @@ extern "C" int kf_reset_volume(kf_ctx* c) {
   if (c->vol.color) KF_CHECK(hipMemsetAsync(c->vol.color, 0, c->n_stored_vox * sizeof(uchar4), c->stream));
   KF_CHECK(hipMemsetAsync(c->vol.flags, 0, c->n_stored_bricks, c->stream));
   KF_CHECK(hipMemsetAsync(c->vol.macro, 0, (size_t)c->vol.nm * c->vol.nm * c->vol.nm, c->stream));
+  KF_CHECK(hipMemsetAsync(c->vol.negbits, 0, kf_negbit_words(c->n_stored_bricks) * sizeof(unsigned), c->stream));
   KF_CHECK(hipMemsetAsync(c->counters, 0, sizeof(KfCounters), c->stream));
   return 0;
 }
@@ -313,6 +315,7 @@ __global__ void __launch_bounds__(256) k_rebuild_flags(KfVolume v, size_t n_bric
     __syncthreads();
     if (threadIdx.x == 0) {
       v.flags[b] = (uint8_t)s_flag;
+      if (s_flag & KF_FLAG_HASNEG) atomicOr(&v.negbits[b >> 5], 1u << (b & 31)); else atomicAnd(&v.negbits[b >> 5], ~(1u << (b & 31)));
       if (s_flag & KF_FLAG_HASNEG) {
         const int bx = (int)(b % v.nb), by = (int)((b / v.nb) % v.nb), bz = (int)(b / ((size_t)v.nb * v.nb)) + v.bz0;
         v.macro[((size_t)(bz >> 2) * v.nm + (by >> 2)) * v.nm + (bx >> 2)] = 1;

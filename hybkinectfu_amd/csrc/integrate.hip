@@ -260,7 +260,10 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
       const unsigned wflags = ((__ballot(flags & KF_FLAG_OBSERVED) ? KF_FLAG_OBSERVED : 0u) | (__ballot(flags & KF_FLAG_HASNEG) ? KF_FLAG_HASNEG : 0u)) & ~fold[b];
       if (wflags && (threadIdx.x & 63) == 0) {
         atomicOr(reinterpret_cast<unsigned*>(v.flags) + (slot[b] >> 2), wflags << (8u * (slot[b] & 3u)));
-        if (wflags & KF_FLAG_HASNEG) v.macro[((size_t)(bz[b] >> 2) * v.nm + (by[b] >> 2)) * v.nm + (bx[b] >> 2)] = 1;   // 4 bricks per macro edge
+        if (wflags & KF_FLAG_HASNEG) {
+          v.macro[((size_t)(bz[b] >> 2) * v.nm + (by[b] >> 2)) * v.nm + (bx[b] >> 2)] = 1;   // 4 bricks per macro edge
+          atomicOr(&v.negbits[slot[b] >> 5], 1u << (slot[b] & 31u));
+        }
       }
     }
   }

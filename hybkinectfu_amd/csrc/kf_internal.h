@@ -27,6 +27,7 @@ struct KfVolume {
   uchar4* color;         // (c0, c1, c2, unused) per voxel; null when the context has no colour
   uint8_t* flags;        // per brick KF_FLAG_*
   uint8_t* macro;        // per 32^3-voxel macro cell of the WHOLE volume: 1 = some voxel in it has (had) tsdf < 0
+  unsigned* negbits;     // one bit per STORED brick slot: the brick's KF_FLAG_HASNEG, packed so the raycast can keep the table in LDS
   int nm;                // macro cells per axis = ceil(res / 32)
   int res;               // voxels per axis
   int nb;                // bricks per axis
@@ -116,6 +117,8 @@ void kf_evt_end(kf_ctx* c, int stage);
 #define KF_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 static inline int kf_div_up(int a, int b) { return (a + b - 1) / b; }
+// words of KfVolume::negbits, padded to whole 16-byte vectors (the raycast copies the table with uint4 loads)
+static inline size_t kf_negbit_words(size_t n_bricks) { return ((n_bricks + 127) / 128) * 4; }
 
 // ------------------------------------------------------------------------------------------------------------------
 // device arithmetic

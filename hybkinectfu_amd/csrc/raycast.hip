@@ -23,6 +23,7 @@ struct RaycastArgs {
   float* out_t;                  // optional: ray parameter of the first crossing this context detected (+inf: none) -- z-slab merge
   float inc, near_plane, far_plane;
   int has_color;
+  int neg_words;                 // words of vol.negbits to keep in LDS (0: the table does not fit -> brick flags are read from global memory)
   int exp_mode;                  // timing experiments only (KF_RAYCAST_EXP): 1 = stop at the crossing without evaluating it
 };
 
@@ -53,24 +54,61 @@ __device__ __forceinline__ bool gradient_for_point(const KfVolume& v, float3 sam
   return true;
 }
 
-#define RAYCAST_LDS_MACRO 32768
-#define RB 1                      // ray samples per batch (4 measured 5 % slower at C2/C4: the march is VALU-bound, not latency-bound)
-__global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
+#define RAYCAST_THREADS 512
+#define RAYCAST_LDS_BYTES 49152   // budget for the two bit tables: 3 workgroups x 8 waves stay resident per CU (160 KiB LDS)
+
+// bit `i` of a packed table
+__device__ __forceinline__ bool rc_bit(const unsigned* words, unsigned i) { return (words[i >> 5] >> (i & 31u)) & 1u; }
+
+// Advance t by the reference's own repeated addition (no memory traffic) until the ray is about to leave the axis-aligned
+// cell [c, c + edge) that contains pos; the exit bound is shrunk by eps so rounding can never skip a sample of a neighbour.
+__device__ __forceinline__ void rc_skip_cell(float3 pos, float3 dir, float3 inv_dir, float cx, float cy, float cz, float edge, float eps,
+                                             float inc, float tmax, float& t, float& t_prev) {
+  const float bx = dir.x > 0.f ? cx + edge - eps : cx + eps;
+  const float by = dir.y > 0.f ? cy + edge - eps : cy + eps;
+  const float bz = dir.z > 0.f ? cz + edge - eps : cz + eps;
+  // the exit parameter only has to be conservative (eps and the 1e-6 t margin absorb a few ulps): reciprocals, no divisions
+  const float dt = fminf(fminf((bx - pos.x) * inv_dir.x, (by - pos.y) * inv_dir.y), (bz - pos.z) * inv_dir.z);
+  const float t_exit = fminf(t + dt - 1e-6f * t, tmax);
+  do { t_prev = t; t += inc; } while (t < t_exit);      // the reference's own repeated addition: identical sample parameters
+}
+
+__global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
   const KfVolume& v = a.vol;
-  // the macro-cell table (<= 32 KiB up to 1024^3) is copied into LDS: the empty-space walk then costs an LDS read per
-  // macro cell instead of a dependent L2 round trip
-  __shared__ unsigned s_macro_words[RAYCAST_LDS_MACRO / 4];
+  // Two packed tables live in LDS so that the empty-space walk costs LDS reads instead of dependent L2 round trips (the
+  // march is latency-bound: halving the rays does not shorten it): one bit per 32^3 macro cell of the whole volume
+  // (packed here from the byte table), and -- when it fits -- one bit per stored 8^3 brick (KfVolume::negbits).
+  extern __shared__ unsigned s_tables[];
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime();
   const int nm3 = v.nm * v.nm * v.nm;
-  const bool macro_in_lds = nm3 <= RAYCAST_LDS_MACRO;
-  if (macro_in_lds) {
-    const unsigned* src = reinterpret_cast<const unsigned*>(v.macro);
-    for (int i = threadIdx.x; i < (nm3 + 3) / 4; i += 256) s_macro_words[i] = src[i];
+  const int macro_words = (nm3 + 31) >> 5;
+  unsigned* s_macro = s_tables;
+  const unsigned* s_neg = s_tables + macro_words;
+  {
+    const unsigned* src = reinterpret_cast<const unsigned*>(v.macro);            // 4 cells per word, bytes are 0 / 1
+    const int src_words = (nm3 + 3) >> 2;
+    for (int i = threadIdx.x; i < macro_words; i += RAYCAST_THREADS) {
+      unsigned bits = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned w = (i * 8 + j < src_words) ? src[i * 8 + j] : 0u;
+        bits |= ((w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u)) << (4 * j);
+      }
+      s_macro[i] = bits;
+    }
+    if (a.neg_words) {
+      const uint4* nsrc = reinterpret_cast<const uint4*>(v.negbits);
+      uint4* ndst = reinterpret_cast<uint4*>(s_tables + macro_words);
+      for (int i = threadIdx.x; i < a.neg_words / 4; i += RAYCAST_THREADS) ndst[i] = nsrc[i];
+    }
     __syncthreads();
   }
-  const unsigned char* s_macro = reinterpret_cast<const unsigned char*>(s_macro_words);
+  const bool neg_in_lds = a.neg_words != 0;
+  // a workgroup is a 32x16 pixel tile, a wave an 8x8 patch of it
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7), y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  const int x = blockIdx.x * 32 + (wave & 3) * 8 + (lane & 7), y = blockIdx.y * 16 + (wave >> 2) * 8 + (lane >> 3);
   if (x >= a.cam.cols || y >= a.cam.rows) return;
+  if (a.exp_mode == 2 && ((blockIdx.x + blockIdx.y) & 1)) return;      // timing experiment: half the rays (latency- or throughput-bound?)
   const int pix = y * a.cam.cols + x;
   float4 out_v = make_float4(0.f, 0.f, 0.f, 0.f), out_n = make_float4(0.f, 0.f, 0.f, 0.f);
   uchar4 out_c = make_uchar4(0, 0, 0, 0);
@@ -89,6 +127,7 @@ __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
   float tmax = fminf(fminf(((dir.x > 0 ? S : 0.f) - org.x) / dir.x, ((dir.y > 0 ? S : 0.f) - org.y) / dir.y), ((dir.z > 0 ? S : 0.f) - org.z) / dir.z);
   tmin = fmaxf(tmin, a.near_plane / cam_dir.z);
   tmax = fminf(tmax, a.far_plane / cam_dir.z);
+  unsigned long long st1 = __builtin_amdgcn_s_memtime(), st2 = st1; int n_iter = 0, n_samp = 0;
   if (tmin < tmax) {
     // raySample :65-119
     const int R = v.res;
@@ -98,77 +137,61 @@ __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
     const int zs0 = v.bz0 * KF_BRICK, zs1 = v.bz1 * KF_BRICK;
     float t = tmin, t_prev = tmin;
     float last_sdf = 0.f; bool have_last = true;
-    const float mcell = (float)KF_MACRO * v.cell, inv_mcell = 1.f / mcell, eps = 1e-4f * mcell;
+    const float mcell = (float)KF_MACRO * v.cell, inv_mcell = 1.f / mcell, meps = 1e-4f * mcell;
+    const float bcell = (float)KF_BRICK * v.cell, beps = 1e-3f * bcell;
+    const float3 inv_dir = kf3(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
     const int nm = v.nm;
     while (t < tmax) {
+      ++n_iter;
       const float3 pos = kf_add(org, kf_scale(dir, t));
-      // level 1: 32^3-voxel macro cell without any negative voxel -> none of the samples inside it can be the negative
-      // side of a crossing.  Advance t by the reference's own repeated addition (no memory traffic) until the ray is
-      // about to leave the cell; the exit bound is shrunk by eps so rounding can never skip a sample of a neighbour.
+      // level 1: a 32^3-voxel macro cell without any negative voxel -> none of the samples inside it can be the negative
+      // side of a crossing: walk to its far side.
       {
         const int mx = max(0, min((int)floorf(pos.x * inv_mcell), nm - 1));
         const int my = max(0, min((int)floorf(pos.y * inv_mcell), nm - 1));
         const int mz = max(0, min((int)floorf(pos.z * inv_mcell), nm - 1));
-        const int mi = (mz * nm + my) * nm + mx;
-        if (!(macro_in_lds ? s_macro[mi] : v.macro[mi])) {
-          const float bx = dir.x > 0.f ? (float)(mx + 1) * mcell - eps : (float)mx * mcell + eps;
-          const float by = dir.y > 0.f ? (float)(my + 1) * mcell - eps : (float)my * mcell + eps;
-          const float bz = dir.z > 0.f ? (float)(mz + 1) * mcell - eps : (float)mz * mcell + eps;
-          const float dt = fminf(fminf((bx - pos.x) / dir.x, (by - pos.y) / dir.y), (bz - pos.z) / dir.z);
-          const float t_exit = fminf(t + dt - 1e-6f * t, tmax);
-          do { t_prev = t; t += a.inc; } while (t < t_exit);
+        if (!rc_bit(s_macro, (unsigned)((mz * nm + my) * nm + mx))) {
+          rc_skip_cell(pos, dir, inv_dir, (float)mx * mcell, (float)my * mcell, (float)mz * mcell, mcell, meps, a.inc, tmax, t, t_prev);
           have_last = false;
           continue;
         }
       }
-      // level 2: a batch of RB consecutive samples (the same repeated addition gives their parameters).  Their brick flags are
-      // fetched together, then the tsdf of the samples in has-negative bricks together: two dependent round trips per RB
-      // samples instead of up to two per sample -- rays grazing a wall stay inside flagged macro cells for dozens of steps.
-      float tb[RB]; size_t idxb[RB]; unsigned flagb[RB]; float sdfb[RB]; bool liveb[RB];
-      {
-        float tt = t;
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-          tb[j] = tt; liveb[j] = tt < tmax;
-          const float3 pj = kf_add(org, kf_scale(dir, tt));
-          // tsdfvolume::getVoxel(world) tsdfVolume.h:81-97: nearest voxel, index clamped
-          int gx = kf_f2i(kf_div(pj.x * rf, rS)), gy = kf_f2i(kf_div(pj.y * rf, rS)), gz = kf_f2i(kf_div(pj.z * rf, rS));
-          gx = max(0, min(gx, R - 1)); gy = max(0, min(gy, R - 1)); gz = max(0, min(gz, R - 1));
-          // only samples whose voxel this context OWNS can be its crossing candidates (the whole volume on one GPU; with
-          // z-slabs the neighbour's layers are stored as halo and serve the previous-sample / trilinear / gradient reads only)
-          const bool owned = liveb[j] && gz >= v.own_z0 && gz < v.own_z1;
-          size_t slot = 0; flagb[j] = 0;
-          if (owned) { slot = kf_brick_slot(v, gx >> 3, gy >> 3, gz >> 3); flagb[j] = v.flags[slot]; }
-          idxb[j] = slot * KF_BRICK_VOX + (size_t)(((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7));
-          tt += a.inc;
-        }
-#pragma unroll
-        for (int j = 0; j < RB; ++j) sdfb[j] = (flagb[j] & KF_FLAG_HASNEG) ? v.tw[idxb[j]].x : 0.f;
+      // level 2: the sample's own voxel -- tsdfvolume::getVoxel(world) tsdfVolume.h:81-97: nearest voxel, index clamped
+      int gx = kf_f2i(kf_div(pos.x * rf, rS)), gy = kf_f2i(kf_div(pos.y * rf, rS)), gz = kf_f2i(kf_div(pos.z * rf, rS));
+      gx = max(0, min(gx, R - 1)); gy = max(0, min(gy, R - 1)); gz = max(0, min(gz, R - 1));
+      // only samples whose voxel this context OWNS can be its crossing candidates (the whole volume on one GPU; with
+      // z-slabs the neighbour's layers are stored as halo and serve the previous-sample / trilinear / gradient reads only)
+      const bool owned = gz >= v.own_z0 && gz < v.own_z1;
+      size_t slot = 0; bool has_neg = false;
+      if (owned) {
+        slot = kf_brick_slot(v, gx >> 3, gy >> 3, gz >> 3);
+        has_neg = neg_in_lds ? rc_bit(s_neg, (unsigned)slot) : (v.flags[slot] & KF_FLAG_HASNEG) != 0;
       }
-      bool crossed = false;
-#pragma unroll
-      for (int j = 0; j < RB; ++j) {
-        if (crossed || !liveb[j]) continue;
-        if (!(flagb[j] & KF_FLAG_HASNEG)) {                                 // tsdf >= 0 everywhere in this 8^3 brick
-          have_last = false; t_prev = tb[j];
-          continue;
-        }
-        const float sdf = sdfb[j];
-        if (sdf < 0.0f) {
-          if (!have_last) {                                                  // the previous sample's tsdf was never fetched: fetch it now
-            const float3 last_pos = kf_add(org, kf_scale(dir, t_prev));      // recomputed exactly as the march computed it
-            int lx = kf_f2i(kf_div(last_pos.x * rf, rS)), ly = kf_f2i(kf_div(last_pos.y * rf, rS)), lz = kf_f2i(kf_div(last_pos.z * rf, rS));
-            lx = max(0, min(lx, R - 1)); ly = max(0, min(ly, R - 1)); lz = max(0, min(lz, R - 1));
-            last_sdf = (lz >= zs0 && lz < zs1) ? v.tw[kf_vox_index(v, lx, ly, lz)].x : 0.f;
-            have_last = true;
-          }
-          if (last_sdf > 0.0f) { t_cross = tb[j]; t_cross_prev = t_prev; crossed = true; continue; }   // zero crossing :83
-        }
-        last_sdf = sdf; have_last = true; t_prev = tb[j];
+      if (!has_neg) {                                                       // tsdf >= 0 everywhere in this 8^3 brick (or not ours)
+        if (owned && neg_in_lds) {
+          // the table is an LDS read away, so walking brick by brick is cheaper than sample by sample.  The cell is the
+          // VOXEL's brick: if rounding put pos a hair outside it, the walk is merely shorter (never past the far face).
+          rc_skip_cell(pos, dir, inv_dir, (float)(gx >> 3) * bcell, (float)(gy >> 3) * bcell, (float)(gz >> 3) * bcell, bcell, beps, a.inc, tmax, t, t_prev);
+        } else { t_prev = t; t += a.inc; }
+        have_last = false;
+        continue;
       }
-      if (crossed) break;
-      t = tb[RB - 1] + a.inc;
+      ++n_samp;
+      const float sdf = v.tw[slot * KF_BRICK_VOX + (size_t)(((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7))].x;
+      if (sdf < 0.0f) {
+        if (!have_last) {                                                    // the previous sample's tsdf was never fetched: fetch it now
+          const float3 last_pos = kf_add(org, kf_scale(dir, t_prev));        // recomputed exactly as the march computed it
+          int lx = kf_f2i(kf_div(last_pos.x * rf, rS)), ly = kf_f2i(kf_div(last_pos.y * rf, rS)), lz = kf_f2i(kf_div(last_pos.z * rf, rS));
+          lx = max(0, min(lx, R - 1)); ly = max(0, min(ly, R - 1)); lz = max(0, min(lz, R - 1));
+          last_sdf = (lz >= zs0 && lz < zs1) ? v.tw[kf_vox_index(v, lx, ly, lz)].x : 0.f;
+          have_last = true;
+        }
+        if (last_sdf > 0.0f) { t_cross = t; t_cross_prev = t_prev; break; }  // zero crossing :83
+      }
+      last_sdf = sdf; have_last = true; t_prev = t;
+      t += a.inc;
     }
+    st2 = __builtin_amdgcn_s_memtime();
     // The crossing is evaluated HERE, after the march loop, not inside it: lanes of a wave meet their crossings at
     // different iterations, and inside the loop the 64-gather evaluation would run once per distinct iteration with a
     // handful of active lanes each time.  After the loop every lane that found a crossing evaluates together.
@@ -188,6 +211,11 @@ __global__ void __launch_bounds__(256) k_raycast(RaycastArgs a) {
       }
     } else if (t_cross < __builtin_huge_valf()) out_v = make_float4(t_cross, 0.f, 0.f, 1.f);
   }
+  if (a.exp_mode == 3) {                                                // diagnostics: shader-clock ticks of the three phases, loop trips
+    const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+    out_v = make_float4((float)(st1 - st0), (float)(st2 - st1), (float)(st3 - st2), (float)n_iter);
+    out_n = make_float4((float)n_samp, 0.f, 0.f, 0.f);
+  }
   a.out_v[pix] = out_v; a.out_n[pix] = out_n;
   if (a.out_t) a.out_t[pix] = t_cross;
   if (a.has_color) a.out_rgb[pix] = out_c;
@@ -206,9 +234,12 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
   a.out_v = out_v ? out_v : c->model_v[0]; a.out_n = out_n ? out_n : c->model_n[0]; a.out_rgb = c->raycast_rgb; a.out_t = out_t;
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
   { static int em = -1; if (em < 0) { const char* e = getenv("KF_RAYCAST_EXP"); em = e ? atoi(e) : 0; } a.exp_mode = em; }
-  dim3 grid(kf_div_up(c->cols, 16), kf_div_up(c->rows, 16));
+  const size_t macro_bytes = (((size_t)c->vol.nm * c->vol.nm * c->vol.nm + 31) / 32) * 4, neg_bytes = kf_negbit_words(c->n_stored_bricks) * 4;
+  a.neg_words = (macro_bytes + neg_bytes <= RAYCAST_LDS_BYTES) ? (int)(neg_bytes / 4) : 0;
+  if (macro_bytes > RAYCAST_LDS_BYTES) return KF_ERR_STATE;
+  dim3 grid(kf_div_up(c->cols, 32), kf_div_up(c->rows, 16));
   kf_evt_begin(c, KF_STAGE_RAYCAST);
-  hipLaunchKernelGGL(k_raycast, grid, dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_raycast, grid, dim3(RAYCAST_THREADS), macro_bytes + (size_t)a.neg_words * 4, c->stream, a);
   kf_evt_end(c, KF_STAGE_RAYCAST);
   return (int)hipGetLastError();
 }
