@@ -403,21 +403,26 @@ static void evt_fold(kf_ctx* c, int s) {
 }
 void kf_evt_begin(kf_ctx* c, int s) {
   if (!(c->timers_enabled & (1 << s))) return;
+  c->ev_open[s] = (c->ev_seen[s]++ % c->timers_period) == 0;          // sampling: every timers_period-th interval is timed
+  if (!c->ev_open[s]) return;
   if (c->ev_n[s] == 64) evt_fold(c, s);
   if (!c->ev[s][0][c->ev_n[s]]) { (void)hipEventCreate(&c->ev[s][0][c->ev_n[s]]); (void)hipEventCreate(&c->ev[s][1][c->ev_n[s]]); }
   (void)hipEventRecord(c->ev[s][0][c->ev_n[s]], c->stream);
 }
 void kf_evt_end(kf_ctx* c, int s) {
-  if (!(c->timers_enabled & (1 << s))) return;
+  if (!(c->timers_enabled & (1 << s)) || !c->ev_open[s]) return;
+  c->ev_open[s] = 0;
   (void)hipEventRecord(c->ev[s][1][c->ev_n[s]], c->stream);
   c->ev_n[s] += 1;
 }
 
-// enable: bit mask of KF_STAGE_* to time (0 = off).  Resets the accumulators.
+// enable: bits 0-7 = mask of KF_STAGE_* to time (0 = off), bits 8-15 = sampling period N (0 or 1: every interval; N: every
+// N-th interval of a stage, so the event records perturb a benchmark N times less).  Resets the accumulators.
 extern "C" int kf_stage_timers(kf_ctx* c, int enable) {
   if (!c) return KF_ERR_ARG;
-  for (int s = 0; s < 8; ++s) { evt_fold(c, s); c->ev_ms[s] = 0.0; c->ev_count[s] = 0; }
-  c->timers_enabled = enable;
+  for (int s = 0; s < 8; ++s) { evt_fold(c, s); c->ev_ms[s] = 0.0; c->ev_count[s] = 0; c->ev_seen[s] = 0; c->ev_open[s] = 0; }
+  c->timers_enabled = enable & 0xFF;
+  c->timers_period = ((enable >> 8) & 0xFF) > 1 ? (unsigned)((enable >> 8) & 0xFF) : 1u;
   return 0;
 }
 // out_ms[s] = accumulated milliseconds of stage s; counts[s] (may be null) = number of timed intervals.  Blocking.

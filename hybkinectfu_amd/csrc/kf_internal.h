@@ -104,6 +104,8 @@ struct kf_ctx {
   void* host_pinned;                  // small pinned staging buffer
   // per-stage hipEvent timers (KF_STAGE_*): bit s of timers_enabled turns stage s on
   int timers_enabled;
+  unsigned timers_period;             // time every timers_period-th interval of a stage (>= 1)
+  unsigned ev_seen[8]; int ev_open[8];
   hipEvent_t ev[8][2][64];            // [stage][begin/end][ring]
   int ev_n[8];                        // pairs recorded and not yet folded
   double ev_ms[8]; unsigned ev_count[8];

@@ -503,13 +503,15 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     const int npx = a.cam.cols * a.cam.rows;
     const int grid_l = (npx + ICP_THREADS * ICP_PX - 1) / (ICP_THREADS * ICP_PX);
     const bool has_px = (int)blockIdx.x < grid_l;
-    const int base = blockIdx.x * (ICP_THREADS * ICP_PX) + threadIdx.x;
+    // pixels are dealt to the workgroups in 64-pixel chunks, round robin: every workgroup sees the same mix of surface and
+    // background, so they all reach the exchange of partial sums at about the same time (contiguous blocks did not)
+    const int chunk0 = (int)(threadIdx.x >> 6) * grid_l + (int)blockIdx.x, chunk_step = (ICP_THREADS / 64) * grid_l;
     // this lane's own vertices / normals depend neither on the running transform nor on the iteration: they are loaded once
     // per pyramid level and stay in registers for all of its iterations (the reference re-reads them 4 / 5 / 10 times)
     float4 iv[ICP_PX], in_[ICP_PX];
 #pragma unroll
     for (int j = 0; j < ICP_PX; ++j) {
-      const int i = base + j * ICP_THREADS;
+      const int i = (chunk0 + j * chunk_step) * 64 + (int)(threadIdx.x & 63);
       iv[j] = make_float4(0.f, 0.f, 0.f, 0.f); in_[j] = iv[j];
       if (has_px && i < npx) { iv[j] = new_v[i]; in_[j] = new_n[i]; }
     }
@@ -555,7 +557,11 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
         // 16-lane row totals by DPP, one LDS word per (sum, row), then 27 lanes add the 32 row totals in a fixed order
         const int row = threadIdx.x >> 4;
 #pragma unroll
-        for (int k = 0; k < 27; ++k) { const float sw = kf_row_scan_sum(acc[k]); if ((threadIdx.x & 15) == 15) s_wave[k * (ICP_THREADS / 16) + row] = sw; }
+        for (int k = 0; k < 27; ++k) acc[k] = kf_row_scan_sum(acc[k]);      // 27 independent DPP chains, free to interleave
+        if ((threadIdx.x & 15) == 15) {
+#pragma unroll
+          for (int k = 0; k < 27; ++k) s_wave[k * (ICP_THREADS / 16) + row] = acc[k];
+        }
         __syncthreads();
         // 4 lanes per sum add 8 row totals each, then two DPP shifts combine the four partial chains (fixed order)
         if (threadIdx.x < 27 * 4) {

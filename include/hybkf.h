@@ -188,7 +188,8 @@ int kf_selftest_div(kf_ctx* ctx, unsigned n, unsigned seed, int mode, unsigned* 
 
 /* Per-stage device timers (hipEvent pairs on the context's stream).  `stage_mask` bit s enables stage s:
  * 0 depth upload/convert, 1 preprocess, 2 track, 3 integrate (all passes), 4 raycast, 5 integrate fusion kernel only,
- * 6 marching cubes, 7 raycast kernel only.  kf_stage_timers resets the accumulators; kf_read_stage_ms blocks and returns
+ * 6 marching cubes, 7 raycast kernel only.  Bits 8-15 of `stage_mask`, when > 1, are a sampling period N: only every N-th
+ * interval of a stage is timed (fewer event records in a benchmark's timed region).  kf_stage_timers resets the accumulators; kf_read_stage_ms blocks and returns
  * accumulated milliseconds and the number of timed intervals per stage. */
 int kf_stage_timers(kf_ctx* ctx, int stage_mask);
 int kf_read_stage_ms(kf_ctx* ctx, float out_ms[8], uint32_t counts[8]);
