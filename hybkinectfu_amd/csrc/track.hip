@@ -699,8 +699,12 @@ static inline int icp_grid(int npx) { return kf_div_up(npx, ICP_THREADS * ICP_PX
 extern "C" int kf_set_pose(kf_ctx* c, const kf_mat44* pose) {
   if (!c || !pose) return KF_ERR_ARG;
   memcpy(c->host_pinned, pose->m, 64);
+  const int one = 1;
+  memcpy((char*)c->host_pinned + 64, &one, sizeof(one));
   KF_CHECK(hipMemcpyAsync(c->track->pose, c->host_pinned, 64, hipMemcpyHostToDevice, c->stream));
-  KF_CHECK(hipStreamSynchronize(c->stream));     // the pinned staging word is reused
+  // a pose supplied by the caller counts as a successful localisation: the device-predicated integrate (transform == NULL) fuses with it
+  KF_CHECK(hipMemcpyAsync(&c->track->tracked, (char*)c->host_pinned + 64, sizeof(one), hipMemcpyHostToDevice, c->stream));
+  KF_CHECK(hipStreamSynchronize(c->stream));     // the pinned staging words are reused
   return 0;
 }
 

@@ -263,13 +263,16 @@ bool CameraPoseFinderSDF::estimateCameraPose(const DepthFrameData& depth_frame, 
 
 // ---- HybKinectfu (src/HybKinectfu.cpp) ---------------------------------------------------------------------------------------------
 HybKinectfu::HybKinectfu() : _camera_pose_finder(nullptr), _inited(false) {}
-HybKinectfu::~HybKinectfu() { delete _camera_pose_finder; _camera_pose_finder = nullptr; }
+HybKinectfu::~HybKinectfu() { delete _camera_pose_recorder; _camera_pose_recorder = nullptr; delete _camera_pose_finder; _camera_pose_finder = nullptr; }
 
 bool HybKinectfu::init() {                                     // :28-61
   if (_inited) return false;
   if (!CudaDeviceDataMan::instance()->ctx() && !CudaDeviceDataMan::instance()->init()) return false;
-  if (AppParams::instance()->_switch_params.useSdfTracker) _camera_pose_finder = new CameraPoseFinderSDF();
+  if (AppParams::instance()->_switch_params.useTrajFromFile) _camera_pose_finder = new CameraPoseFinderFromFile();
+  else if (AppParams::instance()->_switch_params.useSdfTracker) _camera_pose_finder = new CameraPoseFinderSDF();
   else _camera_pose_finder = new CameraPoseFinderICP();
+  if (AppParams::instance()->_switch_params.recordTrajectory)
+    _camera_pose_recorder = new TrajectoryRecorder(AppParams::instance()->_io_params.trajWriteFilename);
   Mat44 camera_pose0 = Mat44::getIdentity();
   camera_pose0.setTranslation((float)(AppParams::instance()->_volume_params.fVolumeMeterSize / 2.0),
                               (float)(AppParams::instance()->_volume_params.fVolumeMeterSize / 2.0),
@@ -318,6 +321,7 @@ bool HybKinectfu::processNewFrame(const DepthFrameData& depth_frame, const Color
   Mat44 cur_camera_pose = _camera_pose_finder->getCameraPose();
   kf_mat44 kp = to_kf(cur_camera_pose);
   if (camera_tracking_success) {
+    if (_camera_pose_recorder) _camera_pose_recorder->recordCameraPose(cur_camera_pose, depth_frame.timeStamp());     // :129-132
     kf_integrate_params ip = {p->_integrate_params.fSdfTruncation, p->_integrate_params.fMaxIntegrateDist};
     if (dm->check(kf_integrate_volume(ctx, p->_switch_params.useRGBData, p->_switch_params.colorAngleWeight, &kp, &ip,
                                       &p->_depth_camera_params, &p->_rgb_camera_params))) return false;

@@ -6,6 +6,7 @@
 // Paths cited are relative to /root/reference.
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
 #include <string>
 #include <vector>
 #include "../../include/hybkf.h"
@@ -124,6 +125,78 @@ protected:
   bool vector6ToTransformMatrix(const float x[6], Mat44& output);
 };
 
+// ---- src/CameraPoseFinderFromFile.{h,cpp}: poses from a TUM trajectory file (timestamp tx ty tz qx qy qz qw), the entry nearest in
+// time to the depth frame, re-based so that frame 0 keeps the initial pose ---------------------------------------------------------------------
+struct TimedRow { double stamp = 0; std::string text; float v[7] = {0, 0, 0, 0, 0, 0, 0}; };
+// The reference walks its list files with getline / tellg / seekg; the same association rule on an in-memory table: rows are
+// consumed in order, the first row at or after the target is compared with the row read just before it IN THE SAME QUERY, and
+// when the earlier one is nearer the later row is pushed back for the next query (CameraPoseFinderFromFile.cpp:34-65,
+// DataSourceProducerRGBDDataset.cpp:67-99).
+class TimedTable {
+public:
+  bool load(const std::string& filename, int header_lines, bool numeric_fields);
+  bool nearest(double target, TimedRow& out);                // false: ran off the end before reaching the target
+  bool next(TimedRow& out);                                  // plain sequential read (depth list)
+  size_t size() const { return _rows.size(); }
+private:
+  std::vector<TimedRow> _rows; size_t _cursor = 0;
+};
+
+class CameraPoseFinderFromFile : public CameraPoseFinder {
+public:
+  static Mat44 transformFromQuaternion(const float t[3], const float q_xyzw[4]);   // Eigen's Quaternion -> Matrix3f, in fp32
+protected:
+  bool initPoseFinder() override;
+  bool estimateCameraPose(const DepthFrameData& depth_frame, const ColorFrameData& color_frame) override;
+  bool enqueueEstimate(const DepthFrameData& depth_frame) override;
+private:
+  TimedTable _trajectory;
+  Mat44 _refer_transform;
+};
+
+// ---- src/TrajectoryRecorder.{h,cpp}: TUM-format trajectory writer ---------------------------------------------------------------------------------
+class TrajectoryRecorder {
+public:
+  explicit TrajectoryRecorder(const std::string& record_filename);
+  virtual ~TrajectoryRecorder();
+  bool recordCameraPose(const Mat44& mat, double timestamp);
+  static void quaternionFromRotation(const Mat44& mat, float q_xyzw[4]);           // Eigen's Matrix3f -> Quaternion, in fp32
+protected:
+  FILE* _record_file;
+};
+
+// ---- src/DataSourceProducer.h, src/DataSourceProducerRGBDDataset.{h,cpp}: TUM RGB-D dataset reader ------------------------------------------------
+class DataSourceProducer {
+public:
+  DataSourceProducer() : _capture_color(false), _inited(false) {}
+  virtual ~DataSourceProducer() {}
+  bool init();                                               // source directory and colour switch from AppParams
+  bool readNewFrame(DepthFrameData& depth_data, ColorFrameData& rgb_data);
+protected:
+  virtual bool initDataSource() = 0;
+  virtual bool readDataFromSource(DepthFrameData& depth_data, ColorFrameData& rgb_data) = 0;
+  std::string _sourcefilename;
+  bool _capture_color;
+private:
+  bool _inited;
+};
+
+class DataSourceProducerRGBDDataset : public DataSourceProducer {
+public:
+  DataSourceProducerRGBDDataset() : _depth_factor(5) {}
+  // (cols+1)/2 x (rows+1)/2 Gaussian pyramid step of a 16-bit image, cv::pyrDown's integer arithmetic (5-tap 1 4 6 4 1 both
+  // ways, reflect-101 border, (sum + 128) >> 8)
+  static void pyrDown16(const uint16_t* src, int cols, int rows, std::vector<uint16_t>& dst);
+protected:
+  bool initDataSource() override;
+  bool readDataFromSource(DepthFrameData& depth_data, ColorFrameData& rgb_data) override;
+private:
+  const float _depth_factor;                                 // TUM depth PNGs hold 1/5000 m; /5 -> millimetres
+  TimedTable _depth_list, _rgb_list;
+  std::vector<uint16_t> _depth_store;                        // the views handed out point into these until the next read
+  std::vector<uint8_t> _bgr_store;
+};
+
 // ---- src/HybKinectfu.h / .cpp ------------------------------------------------------------------------------------------------
 class HybKinectfu {
 public:
@@ -140,6 +213,7 @@ public:
 private:
   void copyFrameToGPU(const DepthFrameData& depth_frame, const ColorFrameData& color_frame);
   CameraPoseFinder* _camera_pose_finder;
+  TrajectoryRecorder* _camera_pose_recorder = nullptr;       // switch recordTrajectory (HybKinectfu.cpp:47-50,129-132)
   bool _inited;
   bool _last_tracked = true;      // verdict of the last processNewFrame
   bool _pending = false;          // frames enqueued whose verdict still lives on the device

@@ -24,8 +24,11 @@ def load():
 
 class App:
     def __init__(self, res, size, cam, sdf_tracker=False, host_loop=False, max_triangles=0, sdf_trunc=0.0, integrate_dist=0.0,
-                 trunc_max=0.0, device=0, slab=(0, 0), halo=0):
+                 trunc_max=0.0, device=0, slab=(0, 0), halo=0, dataset_dir="", traj_read="", traj_write="", use_rgb=False):
+        """dataset_dir: TUM RGB-D directory (with trailing slash) read by process_dataset_frame; traj_read: trajectory file used
+        INSTEAD of a tracker (CameraPoseFinderFromFile); traj_write: record the tracked poses there (TrajectoryRecorder)."""
         self.h = load()
+        self.h.hkf_app_configure_io(dataset_dir.encode(), traj_read.encode(), traj_write.encode(), int(use_rgb))
         st = self.h.hkf_app_init(res, C.c_float(size), cam[0], cam[1], C.c_float(cam[2]), C.c_float(cam[3]), C.c_float(cam[4]), C.c_float(cam[5]),
                                  int(sdf_tracker), int(host_loop), max_triangles, C.c_float(sdf_trunc), C.c_float(integrate_dist),
                                  C.c_float(trunc_max), device, slab[0], slab[1], halo)
@@ -39,6 +42,16 @@ class App:
         if r < 0:
             raise K.KfError("processNewFrame failed: %d" % r)
         return bool(r)
+
+    def process_dataset_frame(self, frame_id):
+        """Next frame of the dataset directory through processNewFrame.  Returns (tracked, depth time stamp) or None at the end."""
+        stamp = C.c_double(0.0)
+        r = self.h.hkf_app_process_dataset_frame(frame_id, C.byref(stamp))
+        if r == -3:
+            return None
+        if r < 0:
+            raise K.KfError("dataset frame failed: %d" % r)
+        return bool(r), stamp.value
 
     def enqueue_frame_device(self, dev_ptr, frame_id):
         r = self.h.hkf_app_enqueue_frame(C.c_void_p(dev_ptr), 1, frame_id)
@@ -63,3 +76,66 @@ class App:
 
     def close(self):
         self.h.hkf_app_shutdown()
+
+
+# ---- GPU-free helpers of the dataset / trajectory code -------------------------------------------------------------------------
+def dataset_read(directory, cols, rows, n, with_color=False):
+    h = load()
+    depth = np.zeros((n, rows, cols), np.uint16)
+    bgr = np.zeros((n, rows, cols, 3), np.uint8) if with_color else None
+    ds, cs = np.zeros(n, np.float64), np.zeros(n, np.float64)
+    got = h.hkf_dataset_read(directory.encode(), cols, rows, int(with_color), n, depth.ctypes.data_as(C.c_void_p),
+                             bgr.ctypes.data_as(C.c_void_p) if with_color else None, ds.ctypes.data_as(C.c_void_p), cs.ctypes.data_as(C.c_void_p))
+    if got < 0:
+        raise K.KfError("hkf_dataset_read failed: %d" % got)
+    return depth[:got], (bgr[:got] if with_color else None), ds[:got], cs[:got]
+
+
+def png_read(path):
+    h = load()
+    h.hkf_png_read.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    w, hh, ch, bits = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    if not h.hkf_png_read(path.encode(), C.byref(w), C.byref(hh), C.byref(ch), C.byref(bits), None, 0):
+        return None
+    out = np.zeros((hh.value, w.value, ch.value), np.uint16 if bits.value == 16 else np.uint8)
+    h.hkf_png_read(path.encode(), C.byref(w), C.byref(hh), C.byref(ch), C.byref(bits), out.ctypes.data_as(C.c_void_p), out.nbytes)
+    return out
+
+
+def pyrdown16(img):
+    h = load()
+    img = np.ascontiguousarray(img, np.uint16)
+    out = np.zeros(((img.shape[0] + 1) // 2, (img.shape[1] + 1) // 2), np.uint16)
+    h.hkf_pyrdown16(img.ctypes.data_as(C.c_void_p), img.shape[1], img.shape[0], out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def quat_from_pose(pose):
+    h = load()
+    p = np.ascontiguousarray(pose, np.float32).reshape(16)
+    q = np.zeros(4, np.float32)
+    h.hkf_quat_from_pose(p.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p))
+    return q
+
+
+def pose_from_quat(t, q_xyzw):
+    h = load()
+    t = np.ascontiguousarray(t, np.float32); q = np.ascontiguousarray(q_xyzw, np.float32)
+    out = np.zeros(16, np.float32)
+    h.hkf_pose_from_quat(t.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out.reshape(4, 4)
+
+
+def trajectory_write(path, poses, stamps):
+    h = load()
+    p = np.ascontiguousarray(poses, np.float32).reshape(-1, 16); s = np.ascontiguousarray(stamps, np.float64)
+    return h.hkf_trajectory_write(path.encode(), p.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), len(s))
+
+
+def table_nearest(path, header_lines, targets):
+    h = load()
+    t = np.ascontiguousarray(targets, np.float64); out = np.zeros(len(t), np.float64)
+    n = h.hkf_table_nearest(path.encode(), header_lines, t.ctypes.data_as(C.c_void_p), len(t), out.ctypes.data_as(C.c_void_p))
+    if n < 0:
+        raise K.KfError("cannot read " + path)
+    return out

@@ -155,9 +155,25 @@ class Context:
         self.stored = (z0s.value, z1s.value)
         self.owned = (z0, z1)
 
+    @classmethod
+    def borrow(cls, handle, depth_cam, volume_res, volume_size, levels=3):
+        """Wrap a kf_ctx owned by someone else (the C++ host application): same methods, close() leaves it alone."""
+        self = cls.__new__(cls)
+        self.lib = load()
+        self.cam = self.rgb_cam = depth_cam
+        self.res, self.size, self.levels = int(volume_res), float(volume_size), int(levels)
+        self.h = handle if isinstance(handle, C.c_void_p) else C.c_void_p(handle)
+        self.borrowed = True
+        z0s, z1s = C.c_uint32(), C.c_uint32()
+        _chk(self.lib.kf_stored_z_range(self.h, C.byref(z0s), C.byref(z1s)), "kf_stored_z_range")
+        self.stored = (z0s.value, z1s.value)
+        self.owned = self.stored
+        return self
+
     def close(self):
         if self.h:
-            self.lib.kf_destroy(self.h)
+            if not getattr(self, "borrowed", False):
+                self.lib.kf_destroy(self.h)
             self.h = None
 
     def __del__(self):
