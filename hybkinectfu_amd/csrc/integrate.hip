@@ -274,6 +274,132 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
   if (threadIdx.x == 0 && s_upd) atomicAdd(&a.cnt->upd_shard[(blockIdx.x & 63) * 16], (unsigned long long)s_upd);
 }
 
+// ---- the same fusion pass with the lane's two x-adjacent voxels carried as one 2-vector ------------------------------------------
+// The pass is VALU-bound, not HBM-bound (~240 vector instructions per lane and brick at 8 waves per SIMD; tools/bench_integrate.py
+// gives the same time for 1, 2 or 4 bricks in flight and for 2048..8192 workgroups), so the instruction count is what the kernel's
+// distance to the HBM roofline is made of.  gfx950 issues v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 on two fp32 values at the cost
+// of one: every multiply, add and fused step of the reference's per-voxel arithmetic -- still one rounded operation per source
+// operation, so the bits do not change -- runs once for the pair.  The code is straight-line (no per-voxel branches: a voxel behind
+// the camera gets a harmless divisor and is masked at the end), and the pixel rounding uses floor(p + 0.5f), which equals the
+// reference's (int)(p + 0.5) in double for every p the bounds test can accept (exact sum below 2^23; tests/test_oracle_golden.py).
+typedef float kf_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ kf_f2 f2_splat(float a) { kf_f2 r = {a, a}; return r; }
+__device__ __forceinline__ kf_f2 f2_fma(kf_f2 a, kf_f2 b, kf_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+struct KfRecip2 { kf_f2 den, r; };
+__device__ __forceinline__ KfRecip2 kf_recip2(kf_f2 b) {                   // kf_recip on both halves
+  kf_f2 r0 = {__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+  const kf_f2 e0 = f2_fma(-b, r0, f2_splat(1.0f));
+  KfRecip2 k; k.den = b; k.r = f2_fma(e0, r0, r0);
+  return k;
+}
+__device__ __forceinline__ kf_f2 kf_div2(kf_f2 a, const KfRecip2& k) {     // kf_div on both halves
+  const kf_f2 q0 = a * k.r;
+  const kf_f2 e1 = f2_fma(-k.den, q0, a);
+  const kf_f2 q1 = f2_fma(e1, k.r, q0);
+  const kf_f2 e2 = f2_fma(-k.den, q1, a);
+  return f2_fma(e2, k.r, q1);
+}
+
+template <int BR>
+__global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
+  const KfVolume& v = a.vol;
+  const unsigned n_active = a.cnt->n_active_bricks >> (a.exp_mode >= 8 ? a.exp_mode - 7 : 0);     // exp_mode 8 / 9: half / quarter of the queue (timing only)
+  const float* m = a.tinv;
+  const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8], m9 = m[9], m10 = m[10], m11 = m[11];
+  const float cell = v.cell;
+  const int lx = (threadIdx.x & 3) * 2, ly = (threadIdx.x >> 2) & 7, lz = threadIdx.x >> 5;
+  const KfRecip rt = kf_recip(a.sdf_trunc);
+  KfRecip2 rtrunc; rtrunc.den = f2_splat(rt.den); rtrunc.r = f2_splat(rt.r);
+  const unsigned xlim = (unsigned)(a.dcam.cols - 2), ylim = (unsigned)(a.dcam.rows - 2);
+  __shared__ unsigned s_upd;
+  unsigned upd_total = 0;
+  if (threadIdx.x == 0) s_upd = 0;
+  __syncthreads();
+  for (unsigned q0 = blockIdx.x * BR; q0 < n_active; q0 += gridDim.x * BR) {
+    unsigned slot[BR], fold[BR]; int bx[BR], by[BR], bz[BR];
+    kf_f2 pfz[BR], d[BR]; int pix0[BR], pix1[BR]; bool ok0[BR], ok1[BR];
+    // Phase A: project both voxels (tsdfVolume.h:38-49 voxel centre; Mat.h:230-238 row * vector summed left to right)
+#pragma unroll
+    for (int b = 0; b < BR; ++b) {
+      const bool live = q0 + b < n_active;
+      const unsigned packed = live ? a.queue[q0 + b] : 0u;
+      bx[b] = (int)(packed & 1023u); by[b] = (int)((packed >> 10) & 1023u); bz[b] = (int)(packed >> 20) + v.bz0;
+      slot[b] = ((unsigned)(bz[b] - v.bz0) * (unsigned)v.nb + (unsigned)by[b]) * (unsigned)v.nb + (unsigned)bx[b];
+      fold[b] = v.flags[slot[b]];                           // current flags: the atomic below is only issued when a bit is new
+      const float x0 = (float)(bx[b] * 8 + lx);
+      kf_f2 xi = {x0, x0 + 1.0f};                           // (float)(x + 1) == (float)x + 1 for these small integers
+      const kf_f2 wx = (xi + f2_splat(0.5f)) * f2_splat(cell);
+      const float wy = ((float)(by[b] * 8 + ly) + 0.5f) * cell, wz = ((float)(bz[b] * 8 + lz) + 0.5f) * cell;
+      const kf_f2 pfx = ((f2_splat(m0) * wx + f2_splat(m1 * wy)) + f2_splat(m2 * wz)) + f2_splat(m3 * 1.0f);
+      const kf_f2 pfy = ((f2_splat(m4) * wx + f2_splat(m5 * wy)) + f2_splat(m6 * wz)) + f2_splat(m7 * 1.0f);
+      pfz[b] = ((f2_splat(m8) * wx + f2_splat(m9 * wy)) + f2_splat(m10 * wz)) + f2_splat(m11 * 1.0f);
+      const bool z0 = live && pfz[b].x > 0.f, z1 = live && pfz[b].y > 0.f;                   // :39 `if (pf.z <= 0) continue`
+      kf_f2 zs = {z0 ? pfz[b].x : 1.0f, z1 ? pfz[b].y : 1.0f};                               // masked voxels: any finite divisor
+      const KfRecip2 rz = kf_recip2(zs);
+      // DepthCamera.h:30-43 `v.x*fx/v.z + cx`, `(int)(p + 0.5)`: both quotients share the divisor pf.z
+      const kf_f2 px = kf_div2(pfx * f2_splat(a.dcam.fx), rz) + f2_splat(a.dcam.cx) + f2_splat(0.5f);
+      const kf_f2 py = kf_div2(pfy * f2_splat(a.dcam.fy), rz) + f2_splat(a.dcam.cy) + f2_splat(0.5f);
+      const int sx0 = (int)floorf(px.x), sx1 = (int)floorf(px.y), sy0 = (int)floorf(py.x), sy1 = (int)floorf(py.y);
+      // :43 `sp.x >= cols-1 || sp.y >= rows-1 || sp.x < 1 || sp.y < 1` rejects: one unsigned compare per coordinate
+      ok0[b] = z0 && (unsigned)(sx0 - 1) < xlim && (unsigned)(sy0 - 1) < ylim;
+      ok1[b] = z1 && (unsigned)(sx1 - 1) < xlim && (unsigned)(sy1 - 1) < ylim;
+      pix0[b] = ok0[b] ? sy0 * a.dcam.cols + sx0 : 0;
+      pix1[b] = ok1[b] ? sy1 * a.dcam.cols + sx1 : 0;
+    }
+    // depth gathers of all BR x 2 voxels back to back (L2-resident image)
+#pragma unroll
+    for (int b = 0; b < BR; ++b) { d[b].x = ok0[b] ? a.depth[pix0[b]] : 0.f; d[b].y = ok1[b] ? a.depth[pix1[b]] : 0.f; }
+    // Phase B: the reference's remaining predicates (:50, :64, :67)
+    bool upd0[BR], upd1[BR]; kf_f2 sdf[BR];
+#pragma unroll
+    for (int b = 0; b < BR; ++b) {
+      sdf[b] = d[b] - pfz[b];
+      upd0[b] = ok0[b] && d[b].x != 0.f && d[b].x < a.max_dist && sdf[b].x > -a.sdf_trunc;
+      upd1[b] = ok1[b] && d[b].y != 0.f && d[b].y < a.max_dist && sdf[b].y > -a.sdf_trunc;
+    }
+    // one 16-byte read-modify-write per lane and brick, only where a voxel of the pair passed; the loads go out together
+    float4* p[BR]; float4 q[BR];
+#pragma unroll
+    for (int b = 0; b < BR; ++b) {
+      p[b] = reinterpret_cast<float4*>(v.tw + (size_t)slot[b] * KF_BRICK_VOX) + threadIdx.x;
+      q[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (upd0[b] || upd1[b]) q[b] = *p[b];
+    }
+#pragma unroll
+    for (int b = 0; b < BR; ++b) {
+      // tsdfVolume.h:63-66 on both voxels; a voxel that failed the predicate keeps its stored value
+      kf_f2 tsdf = kf_div2(sdf[b], rtrunc);
+      tsdf.x = fminf(1.0f, tsdf.x); tsdf.y = fminf(1.0f, tsdf.y);
+      const kf_f2 ot = {q[b].x, q[b].z}, ow = {q[b].y, q[b].w};
+      const kf_f2 ow1 = ow + f2_splat(1.f);
+      const kf_f2 nt = kf_div2(ot * ow + tsdf, kf_recip2(ow1));               // `tsdf * 1.f` is the identity, bit for bit
+      const float nw0 = fminf(ow1.x, v.max_weight), nw1 = fminf(ow1.y, v.max_weight);
+      unsigned flags = 0;
+      if (upd0[b] || upd1[b]) {
+        float4 r = q[b];
+        if (upd0[b]) { r.x = nt.x; r.y = nw0; }
+        if (upd1[b]) { r.z = nt.y; r.w = nw1; }
+        *p[b] = r;
+        upd_total += (upd0[b] ? 1u : 0u) + (upd1[b] ? 1u : 0u);
+        flags = KF_FLAG_OBSERVED | (((upd0[b] && nt.x < 0.f) || (upd1[b] && nt.y < 0.f)) ? KF_FLAG_HASNEG : 0u);
+      }
+      // brick flags: see k_integrate_bricks
+      const unsigned wflags = ((__ballot(flags & KF_FLAG_OBSERVED) ? KF_FLAG_OBSERVED : 0u) | (__ballot(flags & KF_FLAG_HASNEG) ? KF_FLAG_HASNEG : 0u)) & ~fold[b];
+      if (wflags && (threadIdx.x & 63) == 0) {
+        atomicOr(reinterpret_cast<unsigned*>(v.flags) + (slot[b] >> 2), wflags << (8u * (slot[b] & 3u)));
+        if (wflags & KF_FLAG_HASNEG) {
+          v.macro[((size_t)(bz[b] >> 2) * v.nm + (by[b] >> 2)) * v.nm + (bx[b] >> 2)] = 1;
+          atomicOr(&v.negbits[slot[b] >> 5], 1u << (slot[b] & 31u));
+        }
+      }
+    }
+  }
+  float s = kf_wave_sum((float)upd_total);          // < 2^24 per wave: exact
+  if ((threadIdx.x & 63) == 0 && s > 0.f) atomicAdd(&s_upd, (unsigned)s);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_upd) atomicAdd(&a.cnt->upd_shard[(blockIdx.x & 63) * 16], (unsigned long long)s_upd);
+}
+
 static inline KfCam to_cam(const kf_camera_params* p) {
   KfCam c; c.cols = (int)p->cols; c.rows = (int)p->rows; c.cx = p->cx; c.cy = p->cy; c.fx = p->fx; c.fy = p->fy; return c;
 }
@@ -307,13 +433,24 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
     const unsigned n_macro = (unsigned)nmxy * nmxy * nmz;                      // one wave per macro cell, sixteen per workgroup
     hipLaunchKernelGGL(k_integrate_cull, dim3((n_macro + CULL_WAVES - 1) / CULL_WAVES), dim3(CULL_WAVES * 64), 0, c->stream, a);
   }
-  unsigned grid = (unsigned)(c->n_stored_bricks < 4096 ? c->n_stored_bricks : 4096);
+  static unsigned grid_cap = 0;                          // workgroups walking the queue: tuning knob
+  if (!grid_cap) { const char* e = getenv("KF_INTEGRATE_GRID"); grid_cap = e ? (unsigned)atoi(e) : 8192u; if (grid_cap < 64u || grid_cap > 65536u) grid_cap = 8192u; }
+  unsigned grid = (unsigned)(c->n_stored_bricks < grid_cap ? c->n_stored_bricks : grid_cap);
   kf_evt_begin(c, KF_STAGE_INTEGRATE_KERNEL);
   if (has_color) hipLaunchKernelGGL((k_integrate_bricks<true, 1>), dim3(grid), dim3(256), 0, c->stream, a);
   else {
-    static int br = 0;                                   // bricks in flight per workgroup: tuning knob, default 2
-    if (!br) { const char* e = getenv("KF_INTEGRATE_BR"); br = e ? atoi(e) : 2; if (br != 1 && br != 2 && br != 4) br = 2; }
-    if (br == 1) hipLaunchKernelGGL((k_integrate_bricks<false, 1>), dim3(grid), dim3(256), 0, c->stream, a);
+    // bricks in flight per workgroup: 2, or 4 when the stored volume is large enough for the queue to hold >~100k bricks
+    // (measured: 512^3 24 us with 2 vs 25 us with 4; 1024^3 378 us with 2 vs 358 us with 4).  KF_INTEGRATE_BR overrides.
+    static int br_env = -1;
+    if (br_env < 0) { const char* e = getenv("KF_INTEGRATE_BR"); br_env = e ? atoi(e) : 0; if (br_env != 1 && br_env != 2 && br_env != 4) br_env = 0; }
+    const int br = br_env ? br_env : (c->n_stored_bricks >= ((size_t)1 << 20) ? 4 : 2);
+    static int pairs = -1;                               // 1 (default): the packed-pair kernel; 0: the scalar one (A/B and colour path)
+    if (pairs < 0) { const char* e = getenv("KF_INTEGRATE_PAIRS"); pairs = e ? atoi(e) : 1; }
+    if (pairs) {
+      if (br == 1) hipLaunchKernelGGL((k_integrate_pairs<1>), dim3(grid), dim3(256), 0, c->stream, a);
+      else if (br == 2) hipLaunchKernelGGL((k_integrate_pairs<2>), dim3(grid), dim3(256), 0, c->stream, a);
+      else hipLaunchKernelGGL((k_integrate_pairs<4>), dim3(grid), dim3(256), 0, c->stream, a);
+    } else if (br == 1) hipLaunchKernelGGL((k_integrate_bricks<false, 1>), dim3(grid), dim3(256), 0, c->stream, a);
     else if (br == 2) hipLaunchKernelGGL((k_integrate_bricks<false, 2>), dim3(grid), dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL((k_integrate_bricks<false, 4>), dim3(grid), dim3(256), 0, c->stream, a);
   }
