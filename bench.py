@@ -39,8 +39,9 @@ def workload(n_gpus, name="auto"):
                 desc="C4: synthetic 640x480 depth (Scene S), 1024^3 @ 6 m TSDF, z-slab per GPU, %d GPUs" % n_gpus)
 
 
-def cpu_baseline(wl, frames_mm, n_sample=12):
-    """The CPU oracle (oracle/, 'port') on the first n_sample frames of the same stream, all host cores."""
+def cpu_baseline(wl, frames_mm, n_sample=150):
+    """The CPU oracle (oracle/, 'port') on the first n_sample frames of the same stream (about 10-15 s of CPU work on the
+    GPU box's 16-core share), OpenMP over the box's cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     # the GPU box gives one GPU job a 16-core share of the host; more OpenMP threads than that only oversubscribe it
@@ -53,7 +54,7 @@ def cpu_baseline(wl, frames_mm, n_sample=12):
     mv = mn = None
     t0 = time.perf_counter()
     for k in range(n_sample):
-        tr = O.trunc_depth(O.depth_mm_to_m(frames_mm[k]), P["depth_trunc_min"], wl["trunc_max"])
+        tr = O.trunc_depth(O.depth_mm_to_m(frames_mm[k % len(frames_mm)]), P["depth_trunc_min"], wl["trunc_max"])
         fl = O.bilateral(tr, P["filter_sigma_pixel"], P["filter_sigma_depth"])
         v = O.depth_to_vertices(fl, ocam)
         n = O.vertices_to_normals(v)
@@ -151,7 +152,7 @@ def main():
         n_upd_all = n_upd
     fps = args.steps / dt
 
-    # roofline of the dominant HBM kernel (k_integrate_bricks): algorithmic bytes per launch / measured duration
+    # roofline of the dominant HBM kernel (k_integrate_pairs, the fusion pass): algorithmic bytes per launch / measured duration
     launches = max(int(cnt[5]), 1)
     kern_ms = float(ms[5]) / launches
     alg_bytes = (n_upd / max(args.steps, 1)) * 16.0 + cam[0] * cam[1] * 4.0       # N_upd x 2 x 8 B + depth map
@@ -164,7 +165,7 @@ def main():
         except Exception:
             traffic = None
     roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                    traffic=traffic, kernel="k_integrate_bricks", kernel_ms=round(kern_ms, 5), launches_timed=int(cnt[5]),
+                    traffic=traffic, kernel="k_integrate_pairs", kernel_ms=round(kern_ms, 5), launches_timed=int(cnt[5]),
                     algorithmic_bytes_per_launch=int(alg_bytes), n_upd_per_frame=int(n_upd / max(args.steps, 1)))
 
     if args.stages and rank == 0:

@@ -136,3 +136,23 @@ def test_solver_closed_form():
     tw[:3, 3] = v[3:]
     E = expm(tw)
     assert np.allclose(R, E[:3, :3], atol=1e-12) and np.allclose(t, E[:3, 3], atol=1e-12)
+
+
+def test_pixel_rounding_floor_form_equals_reference_double_form():
+    """The packed fusion kernel rounds a projected pixel with floor(p + 0.5f) in fp32 (integrate.hip, k_integrate_pairs); the
+    reference computes (int)(p + 0.5) with a double literal (src/cuda/DepthCamera.h:42).  For every p >= 0.5 below 2^23 the fp32
+    sum is exact unless it crosses into the next binade, and there it can only lose a bit that does not reach the integer part."""
+    rng = np.random.default_rng(0)
+    parts = [rng.uniform(0.5, 2048, 2_000_000).astype(np.float32)]
+    for top in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048):
+        for centre in (np.float32(top), np.float32(top - 0.5)):
+            bits = int(centre.view(np.uint32))
+            parts.append((np.arange(-40000, 40000, dtype=np.int64) + bits).astype(np.uint32).view(np.float32))
+    p = np.concatenate(parts)
+    p = p[p >= 0.5]
+    want = (p.astype(np.float64) + 0.5).astype(np.int64)
+    got = np.floor((p + np.float32(0.5)).astype(np.float32)).astype(np.int64)
+    assert np.array_equal(want, got)
+    # below 0.5 both forms give a value < 1, which the bounds test rejects either way
+    q = rng.uniform(-50, 0.5, 100000).astype(np.float32)
+    assert np.all((q.astype(np.float64) + 0.5).astype(np.int64) < 1) and np.all(np.floor(q + np.float32(0.5)) < 1)

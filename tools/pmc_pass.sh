@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/pmc_pass.sh <tag> <config> "<counters>" [kernel-substring]   (GPU box) -> per-kernel average of each counter
-TAG=$1; CFG=$2; CTRS=$3; KSUB=${4:-k_integrate_bricks}
+TAG=$1; CFG=$2; CTRS=$3; KSUB=${4:-k_integrate_pairs}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc $CTRS -d $OUT --output-format csv -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --config $CFG > $OUT/bench.log 2>&1 || { tail -5 $OUT/bench.log; exit 1; }

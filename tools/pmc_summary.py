@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise a tools/profile_round.sh output directory: kernel stats tables + HBM traffic of k_integrate_bricks per launch.
+"""Summarise a tools/profile_round.sh output directory: kernel stats tables + HBM traffic of the fusion kernel per launch.
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  Per /opt/skills/guides/MI355X_MICROARCH.md (section HBM) FETCH_SIZE
 on gfx950 counts a wide coalesced 16-B-per-lane read stream at exactly half its bytes, so the read side is doubled; the
@@ -17,14 +17,14 @@ for cfg in ("c2", "c4"):
             continue
         tot, n = 0.0, 0
         for r in csv.DictReader(open(files[0])):
-            if "k_integrate_bricks" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            if ("k_integrate_pairs" in r["Kernel_Name"] or "k_integrate_bricks" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
                 tot += float(r["Counter_Value"]); n += 1
         if n:
             vals[kind] = tot / n * 1024.0
     if "fetch" in vals and "write" in vals:
         hbm = 2.0 * vals["fetch"] + vals["write"]
         res[cfg.upper()] = int(hbm)
-        lines.append("%s k_integrate_bricks per launch: FETCH_SIZE %.1f MB (x2 gfx950 correction -> %.1f MB), WRITE_SIZE %.1f MB, HBM traffic %.1f MB"
+        lines.append("%s fusion kernel (k_integrate_pairs) per launch: FETCH_SIZE %.1f MB (x2 gfx950 correction -> %.1f MB), WRITE_SIZE %.1f MB, HBM traffic %.1f MB"
                      % (cfg.upper(), vals["fetch"] / 1e6, 2 * vals["fetch"] / 1e6, vals["write"] / 1e6, hbm / 1e6))
     st = glob.glob(os.path.join(out, "trace_%s" % cfg, "*", "*kernel_stats.csv"))
     if st:
