@@ -79,6 +79,7 @@ def main():
                     help="auto: C2 (512^3 @ 4 m) on 1 GPU, C4 (1024^3 @ 6 m, z-slabs) on N > 1, as BASELINE.json's metric states")
     ap.add_argument("--icp-mode", default="replicated", choices=["replicated", "allreduce"],
                     help="multi-GPU tracking: every rank runs the whole ICP (default) or pixels are split and the 27-float system all-reduced")
+    ap.add_argument("--prefetch", action="store_true", help="preprocess frame k+1 on a side stream while frame k is tracked (measured neutral at VGA)")
     ap.add_argument("--force-slab", action="store_true", help="run the z-slab pipeline (and its collectives) even with one rank")
     args = ap.parse_args()
 
@@ -118,8 +119,10 @@ def main():
         pipe = Pipe(kcam, res, size, wl, rank=rank, world=world, device=local_rank, icp_mode=args.icp_mode)
 
     def run(first, count):
+        # --prefetch: frame k+1 is preprocessed on the context's side stream while frame k is tracked (kf_prefetch_frame)
         for k in range(first, first + count):
-            pipe.process_frame_device(dev_frames.data_ptr() + (k % n_unique) * frame_bytes, k)
+            nxt = dev_frames.data_ptr() + ((k + 1) % n_unique) * frame_bytes if args.prefetch else None
+            pipe.process_frame_device(dev_frames.data_ptr() + (k % n_unique) * frame_bytes, k, nxt)
 
     def barrier():
         pipe.sync()

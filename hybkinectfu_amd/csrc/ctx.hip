@@ -39,6 +39,11 @@ extern "C" int kf_destroy(kf_ctx* c) {
                   c->track, c->counters, c->grid_barrier, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macro, c->vol.negbits, c->active_bricks,
                   c->tile_max_depth, c->triangles, c->mc_block_counts};
   for (void* p : ptrs) if (p) hipFree(p);
+  void* alts[] = {c->alt_raw, c->alt_trunced, c->alt_filtered, c->alt_v0, c->alt_n0};
+  for (void* p : alts) if (p) hipFree(p);
+  if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
+  if (c->ev_preprocessed) hipEventDestroy(c->ev_preprocessed);
+  if (c->ev_prefetched) hipEventDestroy(c->ev_prefetched);
   for (int l = 0; l < KF_MAX_LEVELS; ++l) {
     if (c->new_v[l]) hipFree(c->new_v[l]);
     if (c->new_n[l]) hipFree(c->new_n[l]);

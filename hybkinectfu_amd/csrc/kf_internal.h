@@ -86,6 +86,12 @@ struct kf_ctx {
   const uint16_t* pending_mm;         // device u16 frame whose conversion is deferred into the fused preprocess kernel
   float* raw_depth; float* trunced_depth; float* filtered_depth;
   uchar4* raw_rgb; uchar4* raycast_rgb;   // stored 4 bytes/pixel on the device
+  // next-frame prefetch (kf_prefetch_frame): a second set of the per-frame preprocess outputs, filled on a side stream while the
+  // current frame is tracked (the persistent ICP loop leaves ~100 CUs idle); kf_preprocess swaps the sets when it is asked for
+  // exactly that frame with exactly those parameters.  Allocated on first use.
+  float* alt_raw; float* alt_trunced; float* alt_filtered; float4* alt_v0; float4* alt_n0;
+  hipStream_t side_stream; hipEvent_t ev_preprocessed, ev_prefetched;
+  const uint16_t* prefetch_src; float prefetch_params[4]; int prefetch_valid, prefetch_in_use;
   float4* new_v[KF_MAX_LEVELS]; float4* new_n[KF_MAX_LEVELS];
   float4* model_v[KF_MAX_LEVELS]; float4* model_n[KF_MAX_LEVELS];
   float* icp_partials;                // KF_ICP_MAX_WG x 32 floats

@@ -76,7 +76,7 @@ MAP_RAW_RGB, MAP_RAYCAST_RGB = 7, 8
 SYMBOLS = [
     "kf_error_string", "kf_version", "kf_create", "kf_destroy", "kf_synchronize", "kf_stream", "kf_reset_volume",
     "kf_upload_depth_mm", "kf_set_depth_mm_device", "kf_upload_rgb", "kf_trunc_depth", "kf_bilateral_filter_depth",
-    "kf_calculate_new_vertices", "kf_calculate_new_normals", "kf_preprocess", "kf_downsample_new_vertices",
+    "kf_calculate_new_vertices", "kf_calculate_new_normals", "kf_preprocess", "kf_prefetch_frame", "kf_downsample_new_vertices",
     "kf_downsample_new_normals", "kf_downsample_model_vertices", "kf_downsample_model_normals",
     "kf_cal_point_to_plane_solver_params", "kf_cal_sdf_solver_params", "kf_read_solver_params", "kf_set_pose",
     "kf_icp_track", "kf_sdf_track", "kf_read_track_result", "kf_integrate_volume", "kf_raycast_volume",
@@ -228,6 +228,10 @@ class Context:
     def preprocess(self, tmin, tmax, sigma_pixel, sigma_depth):
         _chk(self.lib.kf_preprocess(self.h, C.c_float(tmin), C.c_float(tmax), C.c_float(sigma_pixel), C.c_float(sigma_depth),
                                     C.byref(self.cam)), "kf_preprocess")
+
+    def prefetch_frame(self, dev_ptr, tmin, tmax, sigma_pixel, sigma_depth):
+        _chk(self.lib.kf_prefetch_frame(self.h, C.c_void_p(dev_ptr), self.cam.cols, self.cam.rows, C.c_float(tmin), C.c_float(tmax),
+                                        C.c_float(sigma_pixel), C.c_float(sigma_depth), C.byref(self.cam)), "kf_prefetch_frame")
 
     def downsample(self, model):
         if model:

@@ -20,11 +20,15 @@ class SingleGpuPipeline:
         self.ctx.set_pose(S.pose0(size))                       # HybKinectfu::init  src/HybKinectfu.cpp:51-57
         self.inc = P["raycast_increment_factor"] * P["integrate_sdf_trunc"]     # AppParamsProducer.cpp:113-117
 
-    def process_frame_device(self, dev_mm_ptr, frame_id):
+    def process_frame_device(self, dev_mm_ptr, frame_id, next_mm_ptr=None):
+        """next_mm_ptr: where the NEXT frame already lies in HBM (streaming input): its preprocess is enqueued on the context's
+        side stream right behind the tracking loop and overlaps with it."""
         c = self.ctx
         c.set_depth_mm_device(dev_mm_ptr)                                                                    # copyFrameToGPU
         c.preprocess(P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])  # :106-110
         c.icp_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])  # :116
+        if next_mm_ptr is not None:
+            c.prefetch_frame(next_mm_ptr, P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
         c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist)                                         # :125-140
         c.raycast(None, self.inc, P["depth_trunc_min"], self.trunc_max)                                      # :149-154
 
@@ -113,7 +117,7 @@ class SlabPipeline:
         self.n = torch.empty((kcam.rows, kcam.cols, 4), dtype=torch.float32, device=dev)
         self.sums = torch.zeros(32, dtype=torch.float32, device=dev)
 
-    def process_frame_device(self, dev_mm_ptr, frame_id):
+    def process_frame_device(self, dev_mm_ptr, frame_id, next_mm_ptr=None):
         c, dist = self.ctx, self.dist
         c.set_depth_mm_device(dev_mm_ptr)
         c.preprocess(P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
@@ -122,6 +126,8 @@ class SlabPipeline:
                                   self.rank, self.world, self.sums.data_ptr(), lambda: dist.all_reduce(self.sums, op=dist.ReduceOp.SUM))
         else:
             c.icp_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+        if next_mm_ptr is not None:
+            c.prefetch_frame(next_mm_ptr, P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
         c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist)
         c.raycast_slab(None, self.inc, P["depth_trunc_min"], self.trunc_max, self.t.data_ptr(), self.v.data_ptr(), self.n.data_ptr())
         v, n = merge_candidates(self.t, self.v, self.n,

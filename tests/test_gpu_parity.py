@@ -285,3 +285,43 @@ def test_exact_division_helper():
     for mode in range(4):
         assert ctx.selftest_div(1 << 24, 12345 + mode, mode) == 0, mode
     ctx.close()
+
+
+def test_prefetched_preprocess_is_bit_identical():
+    """kf_prefetch_frame (next frame preprocessed on a side stream while the current one is tracked) must change nothing:
+    same maps, same poses, same volume as the plain call sequence -- including when the prefetched frame is NOT the one that
+    comes next (the prefetch is then ignored)."""
+    import torch
+    from hybkinectfu_amd.pipeline import SingleGpuPipeline
+    res, size, cam = 384, 3.0, S.vga_camera()                    # stock truncation (0.05 m) = 6.4 voxels, as at C2
+    wl = dict(trunc_max=P["depth_trunc_max"], integ_dist=P["integrate_depth_trunc"])
+    n = 6
+    frames = np.stack([S.render_depth_mm(S.trajectory_pose(k, size), cam, size) for k in range(n)])
+    dev = torch.from_numpy(frames.astype(np.int16)).cuda()
+    fb = cam[0] * cam[1] * 2
+    outs = []
+    for mode in ("plain", "prefetch", "wrong-prefetch"):
+        pipe = SingleGpuPipeline(K.camera(*cam), res, size, wl)
+        poses = []
+        for k in range(n):
+            nxt = None
+            if mode == "prefetch" and k + 1 < n:
+                nxt = dev.data_ptr() + (k + 1) * fb
+            if mode == "wrong-prefetch":
+                nxt = dev.data_ptr() + ((k + 3) % n) * fb
+            pipe.process_frame_device(dev.data_ptr() + k * fb, k, nxt)
+            ok, pose, status, iters = pipe.track_result()
+            assert ok
+            poses.append(pose.copy())
+        pipe.sync()
+        maps = [pipe.ctx.download_map(m) for m in (K.MAP_RAW_DEPTH, K.MAP_TRUNCED_DEPTH, K.MAP_FILTERED_DEPTH, K.MAP_NEW_VERTICES,
+                                                   K.MAP_NEW_NORMALS, K.MAP_MODEL_VERTICES, K.MAP_MODEL_NORMALS)]
+        vol = pipe.ctx.download_volume()
+        outs.append((poses, maps, vol))
+        pipe.close()
+    for other in outs[1:]:
+        for a, b in zip(outs[0][0], other[0]):
+            assert np.array_equal(a, b)
+        for a, b in zip(outs[0][1], other[1]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert np.array_equal(outs[0][2][0], other[2][0]) and np.array_equal(outs[0][2][1], other[2][1])
