@@ -27,6 +27,15 @@ def mid_cam():
     return (160, 120, 79.5, 59.5, 131.25, 131.25)
 
 
+def ragged_cam():
+    """Not a multiple of any tile the kernels use (64x4 bilateral, 32x16 raycast, 16x16 depth tiles, 64-pixel ICP chunks at level 1)."""
+    return (200, 152, 99.5, 75.5, 164.0, 164.0)
+
+
+def odd_cam():
+    return (101, 77, 50.0, 38.0, 82.0, 82.0)
+
+
 def oracle_preprocess(mm, ocam):
     d = O.depth_mm_to_m(mm)
     tr = O.trunc_depth(d, P["depth_trunc_min"], P["depth_trunc_max"])
@@ -36,7 +45,7 @@ def oracle_preprocess(mm, ocam):
     return d, tr, fl, v, n
 
 
-@pytest.mark.parametrize("cam", [small_cam(), mid_cam(), S.vga_camera()])
+@pytest.mark.parametrize("cam", [small_cam(), mid_cam(), S.vga_camera(), ragged_cam(), odd_cam()])
 def test_preprocess_chain(cam):
     size = 3.0
     ocam, kcam = O.Cam.make(*cam), K.camera(*cam)
@@ -106,7 +115,8 @@ def _fuse_sequence(res, size, cam, n_frames, sdf_trunc, max_dist, color=False):
     return ctx, ovol, pose, ocam
 
 
-@pytest.mark.parametrize("res,size,cam,trunc", [(32, 3.0, small_cam(), 0.2), (64, 3.0, mid_cam(), 0.1), (128, 3.0, S.vga_camera(), 0.05)])
+@pytest.mark.parametrize("res,size,cam,trunc", [(32, 3.0, small_cam(), 0.2), (64, 3.0, mid_cam(), 0.1), (128, 3.0, S.vga_camera(), 0.05),
+                                                (96, 3.0, ragged_cam(), 0.12), (40, 2.5, odd_cam(), 0.2)])
 def test_integrate_raycast_mc_bit_exact(res, size, cam, trunc):
     ctx, ovol, pose, ocam = _fuse_sequence(res, size, cam, 3, trunc, 2.5)
     t, w = ctx.download_volume()
@@ -187,7 +197,7 @@ def _tracking_case(res, size, cam, trunc, n_warm=2):
 
 # truncation = 5 voxels: thinner bands leave the raycast gradient taps at grazing walls unobserved (no model normals there),
 # the 6x6 system then loses rank and the fp32 solve of the reference is meaningless on either side
-@pytest.mark.parametrize("res,cam,trunc", [(64, mid_cam(), 5 * 3.0 / 64), (128, S.vga_camera(), 5 * 3.0 / 128)])
+@pytest.mark.parametrize("res,cam,trunc", [(64, mid_cam(), 5 * 3.0 / 64), (128, S.vga_camera(), 5 * 3.0 / 128), (96, ragged_cam(), 5 * 3.0 / 96)])
 def test_icp_system_and_track(res, cam, trunc):
     size = 3.0
     ctx, ovol, pose, nxt, ocam, (v, n, ov, on, tr) = _tracking_case(res, size, cam, trunc)
