@@ -372,7 +372,7 @@ __device__ __forceinline__ bool icp_finish(const TrackArgs& a, float4 vg, float4
 
 // 512 lanes x 4 pixels per workgroup: 150 / 38 / 10 workgroups at VGA level 0 / 1 / 2 (few partials to fold, no register spills).
 #define ICP_THREADS 512
-#define ICP_PX 4
+#define ICP_PX 3
 __global__ void __launch_bounds__(ICP_THREADS) k_icp_step(TrackArgs a) {
   __shared__ float s_cur[16], s_linv[16];
   __shared__ float s_wave[27 * (ICP_THREADS / 16)], s_tot[(ICP_THREADS / 32) * 32];
@@ -434,7 +434,7 @@ struct IcpLoopArgs {
 };
 
 #define ICP_SPIN_LIMIT 4000000u
-#define ICP_FOLD_BATCH 10
+#define ICP_FOLD_BATCH 13
 // Partial sums of the persistent loop travel as 64-bit (value, tag) words: the tag is the launch's sequence number plus the
 // Gauss-Newton step, every step has its own slot array, and a word is published by ONE 8-byte write-through store -- so a
 // reader needs no barrier and no flag: it polls the words it is about to add until their tags are current.  The adds run
