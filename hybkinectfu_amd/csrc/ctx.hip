@@ -9,7 +9,6 @@
 // contexts alive per device: the persistent ICP loop needs its workgroups co-resident, which only one context per GPU guarantees
 static int g_live_ctx[64];
 int kf_live_contexts(int device) { return (device >= 0 && device < 64) ? g_live_ctx[device] : 2; }
-extern "C" int kf_debug_live_contexts(int device) { return kf_live_contexts(device); }
 
 extern "C" const char* kf_version(void) { return "hybkf-gfx950 0.1"; }
 

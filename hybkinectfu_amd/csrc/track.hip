@@ -430,7 +430,7 @@ struct IcpLoopArgs {
   unsigned long long* slots;                     // KF_ICP_LOOP_STEPS x KF_ICP_MAX_WG x 32 tagged partial sums, one array per step
   unsigned tag_base;                             // this launch's sequence number (host counter x 64); tag = tag_base + step
   KfTrackState* track;
-  int exp_mode;                                  // timing experiments only (KF_ICP_EXP)
+  int exp_mode;                                  // diagnostics only (KF_ICP_EXP): 1 = skip the solve (timing), 7 = shader-clock stamps per phase
 };
 
 #define ICP_SPIN_LIMIT 4000000u
@@ -517,11 +517,11 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     }
     for (int it = 0; it < L.iters[l]; ++it, ++step) {
       KF_STAMP(0);
-      if (step > 0 && L.exp_mode != 6) {
+      if (step > 0) {
         fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort);
         if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = 3; st->tracked = 0; } return; }
         KF_STAMP(1);
-        if (L.exp_mode == 1 || L.exp_mode == 3) { if (threadIdx.x == 0) s_code = STEP_APPLIED; __syncthreads(); } else
+        if (L.exp_mode == 1) { if (threadIdx.x == 0) s_code = STEP_APPLIED; __syncthreads(); } else     // timing only: skip the 6x6 solve
         apply_step(a, s_tot, s_cur, &s_code);
         if (s_code != STEP_APPLIED) {                                            // same verdict in every workgroup
           if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; }
@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
       float acc[27];
 #pragma unroll
       for (int k = 0; k < 27; ++k) acc[k] = 0.f;
-      if (has_px && L.exp_mode != 2 && L.exp_mode != 6) {
+      if (has_px) {
         float4 vg[ICP_PX], ng[ICP_PX], vt[ICP_PX], nt[ICP_PX]; int mi[ICP_PX];
 #pragma unroll
         for (int j = 0; j < ICP_PX; ++j) mi[j] = icp_project(a, s_cur, s_linv, iv[j], in_[j], vg[j], ng[j]);
