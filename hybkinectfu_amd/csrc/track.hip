@@ -241,29 +241,34 @@ __device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_to
       unpack27(s_tot, A, b);
       scratch[17] = ((double)det6(A) < 1E-10) ? 1.f : 0.f;
     }
-    if (threadIdx.x == 0) {
-      float A[36], b[6], x[6];
-      unpack27(s_tot, A, b);
-      llt_solve6(A, b, x);
+    // wave 0 runs the solve, the trigonometry and the increment as ONE chain: its lanes hand values to each other through LDS
+    // in program order (a wave's LDS operations complete in order), so no workgroup barrier is needed until the determinant
+    // wave is joined at the end -- the determinant (the longer of the two 6x6 factorizations) hides behind the whole chain.
+    if (threadIdx.x < 64) {
+      float* vs = scratch;                                                  // (plain accesses: the wavefront-scope fences below order them)
+      if (threadIdx.x == 0) {
+        float A[36], b[6], x[6];
+        unpack27(s_tot, A, b);
+        llt_solve6(A, b, x);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) scratch[20 + i] = x[i];
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) {                                                 // the three Euler angles: one lane each, one pass of the trig code
-      const float ang = scratch[20 + threadIdx.x];
-      scratch[26 + threadIdx.x] = cosf(ang); scratch[29 + threadIdx.x] = sinf(ang);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float x[6], T[16], ncur[16];
+        for (int i = 0; i < 6; ++i) vs[20 + i] = x[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (threadIdx.x < 3) {                                               // the three Euler angles: one lane each, one pass of the trig code
+        const float ang = vs[20 + threadIdx.x];
+        vs[26 + threadIdx.x] = cosf(ang); vs[29 + threadIdx.x] = sinf(ang);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (threadIdx.x == 0) {
+        float x[6], T[16], ncur[16];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) x[i] = scratch[20 + i];
-      const bool still = transform_from_sincos(x, scratch[26], scratch[29], scratch[27], scratch[30], scratch[28], scratch[31],
-                                               a.dist_shake, a.angle_shake, T);
-      scratch[16] = still ? 0.f : 1.f;
-      if (still) {
-        mat44_mul(T, s_cur, ncur);                                         // ICP.cpp:81 cur = T * cur
-        for (int i = 0; i < 16; ++i) scratch[i] = ncur[i];
+        for (int i = 0; i < 6; ++i) x[i] = vs[20 + i];
+        const bool still = transform_from_sincos(x, vs[26], vs[29], vs[27], vs[30], vs[28], vs[31], a.dist_shake, a.angle_shake, T);
+        vs[16] = still ? 0.f : 1.f;
+        if (still) {
+          mat44_mul(T, s_cur, ncur);                                       // ICP.cpp:81 cur = T * cur
+          for (int i = 0; i < 16; ++i) vs[i] = ncur[i];
+        }
       }
     }
     __syncthreads();
