@@ -256,7 +256,8 @@ __device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_to
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (threadIdx.x < 3) {                                               // the three Euler angles: one lane each, one pass of the trig code
         const float ang = vs[20 + threadIdx.x];
-        vs[26 + threadIdx.x] = cosf(ang); vs[29 + threadIdx.x] = sinf(ang);
+        float sn, cs; sincosf(ang, &sn, &cs);                              // one argument reduction for the pair
+        vs[26 + threadIdx.x] = cs; vs[29 + threadIdx.x] = sn;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (threadIdx.x == 0) {
@@ -438,7 +439,7 @@ struct IcpLoopArgs {
   int exp_mode;                                  // diagnostics only (KF_ICP_EXP): 1 = skip the solve (timing), 7 = shader-clock stamps per phase
 };
 
-#define ICP_SPIN_LIMIT 4000000u
+#define ICP_SPIN_LIMIT 200000u          // polls (~1-2 us each) before a workgroup gives up: a legitimate wait is tens of microseconds
 #define ICP_FOLD_BATCH 13
 // Partial sums of the persistent loop travel as 64-bit (value, tag) words: the tag is the launch's sequence number plus the
 // Gauss-Newton step, every step has its own slot array, and a word is published by ONE 8-byte write-through store -- so a
@@ -524,7 +525,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
       KF_STAMP(0);
       if (step > 0) {
         fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort);
-        if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = 3; st->tracked = 0; } return; }
+        if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; } return; }
         KF_STAMP(1);
         if (L.exp_mode == 1) { if (threadIdx.x == 0) s_code = STEP_APPLIED; __syncthreads(); } else     // timing only: skip the 6x6 solve
         apply_step(a, s_tot, s_cur, &s_code);
@@ -590,7 +591,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   if (stamp) { for (int i = 0; i < 6; ++i) st->reduced[20 + i] = seg[i]; }
   // the last step's system, then commit _pose (ICP.cpp:84)
   fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort);
-  if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = 3; st->tracked = 0; } return; }
+  if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; } return; }
   apply_step(a, s_tot, s_cur, &s_code);
   if (blockIdx.x != 0) return;
   if (threadIdx.x < 27 && L.exp_mode != 7) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
@@ -773,7 +774,7 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   const int grid0 = icp_grid(c->cols * c->rows);
   static int persistent_env = -1;
   if (persistent_env < 0) { const char* e = getenv("KF_ICP_PERSISTENT"); persistent_env = e ? atoi(e) : 1; }
-  if (persistent_env && grid0 <= c->num_cus && grid0 <= KF_ICP_MAX_WG && iters[0] + iters[1] + iters[2] <= KF_ICP_LOOP_STEPS &&
+  if (persistent_env && !c->persistent_disabled && grid0 <= c->num_cus && grid0 <= KF_ICP_MAX_WG && iters[0] + iters[1] + iters[2] <= KF_ICP_LOOP_STEPS &&
       kf_live_contexts(c->cfg.device) == 1) {
     // every workgroup must be resident at once (software grid barrier): one 1024-lane workgroup per CU, grid0 <= #CUs
     IcpLoopArgs L; memset(&L, 0, sizeof(L));
@@ -897,5 +898,8 @@ extern "C" int kf_read_track_result(kf_ctx* c, kf_track_result* out) {
   KF_CHECK(hipStreamSynchronize(c->stream));
   memcpy(out->pose.m, h->pose, 64);
   out->tracked = h->tracked; out->status = h->status; out->iterations = h->iterations; out->reserved = 0;
+  // status 3: the persistent loop gave up waiting for a partial sum -- some of its workgroups were not resident (another
+  // process on the GPU?).  The frame counts as lost; from now on this context tracks with one launch per step.
+  if (h->status == KF_TRACK_STALLED) c->persistent_disabled = 1;
   return 0;
 }

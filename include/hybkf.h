@@ -65,7 +65,8 @@ enum {
 };
 
 /* status of the device-side tracker after kf_icp_track / kf_sdf_track */
-enum { KF_TRACK_OK = 0, KF_TRACK_LOST_DET = 1, KF_TRACK_LOST_SHAKE = 2 };
+enum { KF_TRACK_OK = 0, KF_TRACK_LOST_DET = 1, KF_TRACK_LOST_SHAKE = 2,
+       KF_TRACK_STALLED = 3 /* device-side wait timed out (GPU shared with another process); frame lost, pose unchanged */ };
 
 typedef struct kf_track_result {
   kf_mat44 pose;            /* CameraPoseFinder::_pose after the call (unchanged when lost) */
