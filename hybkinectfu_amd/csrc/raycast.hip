@@ -260,6 +260,21 @@ extern "C" int kf_raycast_volume_slab(kf_ctx* c, int has_color, const kf_mat44* 
   return raycast_launch(c, has_color, transform, rp, cam, near_plane, far_plane, dev_t, (float4*)dev_v, (float4*)dev_n);
 }
 
+// after the MIN reduction of the crossing parameters over the slabs: keep this context's candidate where it IS the first
+// crossing (t == tmin, finite), zero it elsewhere -- the integer SUM reduction that follows then returns the winner's bits
+__global__ void __launch_bounds__(256) k_slab_mask(const float* __restrict__ t, const float* __restrict__ tmin, float4* __restrict__ v, float4* __restrict__ n, int npx) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= npx) return;
+  const float ti = t[i];
+  if (!(ti == tmin[i] && ti < __builtin_huge_valf())) { const float4 z = make_float4(0.f, 0.f, 0.f, 0.f); v[i] = z; n[i] = z; }
+}
+extern "C" int kf_slab_mask_candidates(kf_ctx* c, const float* dev_t, const float* dev_tmin, float* dev_v, float* dev_n) {
+  if (!c || !dev_t || !dev_tmin || !dev_v || !dev_n) return KF_ERR_ARG;
+  const int npx = c->cols * c->rows;
+  hipLaunchKernelGGL(k_slab_mask, dim3(kf_div_up(npx, 256)), dim3(256), 0, c->stream, dev_t, dev_tmin, (float4*)dev_v, (float4*)dev_n, npx);
+  return (int)hipGetLastError();
+}
+
 extern "C" int kf_set_model_maps_device(kf_ctx* c, const float* dev_v, const float* dev_n) {
   if (!c || !dev_v || !dev_n) return KF_ERR_ARG;
   const size_t bytes = (size_t)c->cols * c->rows * sizeof(float4);

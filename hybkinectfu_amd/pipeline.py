@@ -113,8 +113,11 @@ class SlabPipeline:
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)     # kernels and RCCL collectives ordered on one stream
         dev = torch.device("cuda", device)
         self.t = torch.empty((kcam.rows, kcam.cols), dtype=torch.float32, device=dev)
-        self.v = torch.empty((kcam.rows, kcam.cols, 4), dtype=torch.float32, device=dev)
-        self.n = torch.empty((kcam.rows, kcam.cols, 4), dtype=torch.float32, device=dev)
+        self.tmin = torch.empty_like(self.t)
+        # vertex and normal candidates share one buffer, so their merge is ONE integer SUM all-reduce (9.8 MB at VGA)
+        self.vn = torch.empty((2, kcam.rows, kcam.cols, 4), dtype=torch.float32, device=dev)
+        self.v, self.n = self.vn[0], self.vn[1]
+        self.vn_bits = self.vn.view(torch.int32)
         self.sums = torch.zeros(32, dtype=torch.float32, device=dev)
 
     def process_frame_device(self, dev_mm_ptr, frame_id, next_mm_ptr=None):
@@ -130,11 +133,13 @@ class SlabPipeline:
             c.prefetch_frame(next_mm_ptr, P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
         c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist)
         c.raycast_slab(None, self.inc, P["depth_trunc_min"], self.trunc_max, self.t.data_ptr(), self.v.data_ptr(), self.n.data_ptr())
-        v, n = merge_candidates(self.t, self.v, self.n,
-                                lambda x: dist.all_reduce(x, op=dist.ReduceOp.MIN),
-                                lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM))
-        self._keep = (v, n)                                               # alive until the copies below have run
-        c.set_model_maps_device(v.data_ptr(), n.data_ptr())
+        # first crossing along each ray wins (merge_candidates above is the same rule in plain torch, used by the CPU tests):
+        # MIN all-reduce of t, mask the losers on the device, ONE integer SUM all-reduce of both maps
+        self.tmin.copy_(self.t)
+        dist.all_reduce(self.tmin, op=dist.ReduceOp.MIN)
+        c.slab_mask_candidates(self.t.data_ptr(), self.tmin.data_ptr(), self.v.data_ptr(), self.n.data_ptr())
+        dist.all_reduce(self.vn_bits, op=dist.ReduceOp.SUM)
+        c.set_model_maps_device(self.v.data_ptr(), self.n.data_ptr())
 
     def sync(self):
         self.ctx.sync()

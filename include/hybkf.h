@@ -161,6 +161,9 @@ int kf_raycast_volume(kf_ctx* ctx, int has_color, const kf_mat44* transform, con
 int kf_raycast_volume_slab(kf_ctx* ctx, int has_color, const kf_mat44* transform, const kf_raycast_params* raycast_params,
                            const kf_camera_params* depth_camera, float near_plane, float far_plane,
                            float* dev_t, float* dev_v, float* dev_n);
+/* merge helper: with dev_tmin = MIN over all slabs of dev_t (an all-reduce), zero this context's candidate where it is not the
+ * first crossing; an integer SUM over the slabs of the masked dev_v / dev_n then yields the winner's bits everywhere */
+int kf_slab_mask_candidates(kf_ctx* ctx, const float* dev_t, const float* dev_tmin, float* dev_v, float* dev_n);
 int kf_set_model_maps_device(kf_ctx* ctx, const float* dev_v, const float* dev_n);   /* model_{vertices,normals}_pyramid[0] <- device buffers */
 
 /* Pixel-partitioned ICP ("partition pixels across GPUs, all-reduce the 27-float system").  `dev_sums` is a

@@ -127,3 +127,28 @@ def test_pixel_partitioned_icp_matches_replicated():
             c.raycast(None, 0.7 * trunc, P["depth_trunc_min"], P["depth_trunc_max"])
     for c in [ref] + ranks:
         c.close()
+
+
+def test_device_mask_equals_torch_merge_rule():
+    """kf_slab_mask_candidates (one launch) == the masking step of pipeline.merge_candidates (plain torch), bit for bit,
+    including -0.0 components, +inf 'no crossing' entries and ties between equal finite parameters."""
+    import torch
+    from hybkinectfu_amd import pipeline as PL
+    cam = (64, 48, 31.5, 23.5, 52.5, 52.5)
+    ctx = K.Context(K.camera(*cam), 32, 3.0, levels=3)
+    g = torch.Generator().manual_seed(5)
+    t = torch.rand((48, 64), generator=g) * 3 + 0.5
+    t[torch.rand((48, 64), generator=g) < 0.3] = float("inf")
+    tmin = torch.minimum(t, torch.rand((48, 64), generator=g) * 3 + 0.5)
+    tmin[5, :] = t[5, :]                                              # rows where this rank wins outright
+    v = torch.randn((48, 64, 4), generator=g); n = torch.randn((48, 64, 4), generator=g)
+    v[7, 3, 1] = -0.0; n[5, 9, 2] = -0.0
+    td, tmd, vd, nd = t.cuda(), tmin.cuda(), v.cuda(), n.cuda()
+    ctx.slab_mask_candidates(td.data_ptr(), tmd.data_ptr(), vd.data_ptr(), nd.data_ptr())
+    ctx.sync()
+    win = (t == tmin) & torch.isfinite(t)
+    want_v = v.view(torch.int32) * win.unsqueeze(-1).to(torch.int32)
+    want_n = n.view(torch.int32) * win.unsqueeze(-1).to(torch.int32)
+    assert torch.equal(vd.cpu().view(torch.int32), want_v) and torch.equal(nd.cpu().view(torch.int32), want_n)
+    assert win.any() and not win.all()
+    ctx.close()
