@@ -141,7 +141,18 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
     const float bcell = (float)KF_BRICK * v.cell, beps = 1e-3f * bcell;
     const float3 inv_dir = kf3(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
     const int nm = v.nm;
-    while (t < tmax) {
+    // z-slabs: only samples inside the owned layers can be this context's candidates, so the march is clipped to the ray's
+    // passage through them (one cell of margin on either side); the parameter still reaches the first such sample by the
+    // reference's repeated addition, and the previous sample is fetched lazily like after any other skip
+    float t_end = tmax;
+    if (v.own_z0 > 0 || v.own_z1 < R) {
+      const float za = ((float)(v.own_z0 - 1) * v.cell - org.z) * inv_dir.z, zb = ((float)(v.own_z1 + 1) * v.cell - org.z) * inv_dir.z;
+      const float t_in = fminf(za, zb), t_out = fmaxf(za, zb);
+      t_end = fminf(tmax, t_out);
+      const float t_first = fminf(t_in - 1e-6f * fabsf(t_in), t_end);
+      if (t < t_first) { do { t_prev = t; t += a.inc; } while (t < t_first); have_last = false; }
+    }
+    while (t < t_end) {
       ++n_iter;
       const float3 pos = kf_add(org, kf_scale(dir, t));
       // level 1: a 32^3-voxel macro cell without any negative voxel -> none of the samples inside it can be the negative
@@ -151,7 +162,7 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
         const int my = max(0, min((int)floorf(pos.y * inv_mcell), nm - 1));
         const int mz = max(0, min((int)floorf(pos.z * inv_mcell), nm - 1));
         if (!rc_bit(s_macro, (unsigned)((mz * nm + my) * nm + mx))) {
-          rc_skip_cell(pos, dir, inv_dir, (float)mx * mcell, (float)my * mcell, (float)mz * mcell, mcell, meps, a.inc, tmax, t, t_prev);
+          rc_skip_cell(pos, dir, inv_dir, (float)mx * mcell, (float)my * mcell, (float)mz * mcell, mcell, meps, a.inc, t_end, t, t_prev);
           have_last = false;
           continue;
         }
@@ -171,7 +182,7 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
         if (owned && neg_in_lds) {
           // the table is an LDS read away, so walking brick by brick is cheaper than sample by sample.  The cell is the
           // VOXEL's brick: if rounding put pos a hair outside it, the walk is merely shorter (never past the far face).
-          rc_skip_cell(pos, dir, inv_dir, (float)(gx >> 3) * bcell, (float)(gy >> 3) * bcell, (float)(gz >> 3) * bcell, bcell, beps, a.inc, tmax, t, t_prev);
+          rc_skip_cell(pos, dir, inv_dir, (float)(gx >> 3) * bcell, (float)(gy >> 3) * bcell, (float)(gz >> 3) * bcell, bcell, beps, a.inc, t_end, t, t_prev);
         } else { t_prev = t; t += a.inc; }
         have_last = false;
         continue;
