@@ -9,6 +9,8 @@ already resident in HBM when the timed region starts.  N=1 runs BASELINE.json co
 N>1 runs configs[3] ("C4": 1024^3 @ 6 m, z-slab per GPU, strong scaling) under torch.distributed/RCCL.
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (the TSDF fusion kernel, HBM-bound,
 timed with HIP events on the context's own stream) and `cpu_baseline` (the CPU oracle on a bounded sample, N=1 only).
+The N=1 line also carries `multi_gpu_workload_on_1_gpu`: C4 unpartitioned on this one GPU (50 frames), the same-workload
+reference for the N=2/4/8 lines -- the headline `value` at N=1 is C2, as BASELINE.json's metric states.
 """
 import argparse
 import json
@@ -36,7 +38,8 @@ def workload(n_gpus, name="auto"):
                     desc="C2: synthetic 640x480 depth stream (Scene S), 512^3 @ 4 m TSDF, 3-level ICP 10/5/4, %dxMI355X" % n_gpus)
     # C4: depth gates raised to the volume size so the whole 6 m volume is exercised
     return dict(name="C4", res=1024, size=6.0, cam=S.vga_camera(), trunc_max=6.0, integ_dist=6.0,
-                desc="C4: synthetic 640x480 depth (Scene S), 1024^3 @ 6 m TSDF, z-slab per GPU, %d GPUs" % n_gpus)
+                desc="C4: synthetic 640x480 depth (Scene S), 1024^3 @ 6 m TSDF, " +
+                     ("whole volume on 1 GPU" if n_gpus == 1 else "z-slab per GPU, %d GPUs" % n_gpus))
 
 
 def cpu_baseline(wl, frames_mm, n_sample=150):
@@ -68,6 +71,32 @@ def cpu_baseline(wl, frames_mm, n_sample=150):
                 sample="%d frames of the same stream through oracle/libkforacle.so (preprocess+ICP+integrate+raycast), %.1f s" % (n_sample, dt))
 
 
+def single_gpu_reference(name, n_frames=50, warmup=10):
+    """Frames/s of workload `name` on ONE GPU without partitioning: the same-workload reference point of the multi-GPU series
+    (BASELINE.json's metric quotes 1024^3 for 1/2/4/8 GPUs, while the N=1 headline line is the 512^3 configuration)."""
+    import torch
+    from hybkinectfu_amd.pipeline import SingleGpuPipeline
+    wl = workload(1, name)
+    cam = wl["cam"]
+    frames, _ = S.make_stream(n_frames, cam, wl["size"])
+    dev = torch.from_numpy(frames.astype(np.int16)).cuda()
+    fb = cam[0] * cam[1] * 2
+    pipe = SingleGpuPipeline(K.camera(*cam), wl["res"], wl["size"], wl, device=torch.cuda.current_device())
+    for k in range(warmup):
+        pipe.process_frame_device(dev.data_ptr() + k * fb, k)
+    pipe.sync(); torch.cuda.synchronize()
+    s0 = pipe.stats()
+    t0 = time.perf_counter()
+    for k in range(warmup, n_frames):
+        pipe.process_frame_device(dev.data_ptr() + k * fb, k)
+    pipe.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lost = pipe.stats()["frames_lost"] - s0["frames_lost"]
+    pipe.close()
+    return dict(workload=wl["desc"], value=round((n_frames - warmup) / dt, 2), unit="frames/s", steps=n_frames - warmup,
+                ms_per_step=round(1000.0 * dt / (n_frames - warmup), 4), frames_lost=int(lost))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +108,8 @@ def main():
                     help="auto: C2 (512^3 @ 4 m) on 1 GPU, C4 (1024^3 @ 6 m, z-slabs) on N > 1, as BASELINE.json's metric states")
     ap.add_argument("--icp-mode", default="replicated", choices=["replicated", "allreduce"],
                     help="multi-GPU tracking: every rank runs the whole ICP (default) or pixels are split and the 27-float system all-reduced")
+    ap.add_argument("--no-scaling-reference", action="store_true",
+                    help="skip the extra 50-frame run of the multi-GPU workload (C4) on this one GPU that the N=1 line reports beside the headline")
     ap.add_argument("--prefetch", action="store_true", help="preprocess frame k+1 on a side stream while frame k is tracked (measured neutral at VGA)")
     ap.add_argument("--force-slab", action="store_true", help="run the z-slab pipeline (and its collectives) even with one rank")
     args = ap.parse_args()
@@ -186,6 +217,9 @@ def main():
                            tracker="ICP 10/5/4 (device-resident Gauss-Newton)", frames_lost=int(lost),
                            partition="none" if world == 1 else "z-slab x%d" % world),
                roofline=roofline)
+    if world == 1 and args.config == "auto" and not args.force_slab and not args.no_scaling_reference:
+        pipe.close()
+        out["multi_gpu_workload_on_1_gpu"] = single_gpu_reference("c4")      # what --gpus 2/4/8 should be compared with
     if world == 1 and not args.no_cpu_baseline:
         pipe.close()
         out["cpu_baseline"] = cpu_baseline(wl, frames)
