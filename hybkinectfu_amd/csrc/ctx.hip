@@ -96,8 +96,8 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
     lc >>= 1; lr >>= 1;
   }
   TRY(dev_alloc(&c->icp_partials, (size_t)2 * KF_ICP_MAX_WG * 32));      // double-buffered by Gauss-Newton step parity
-  TRY(dev_alloc(&c->icp_loop_slots, (size_t)KF_ICP_LOOP_STEPS * KF_ICP_MAX_WG * 32));
-  TRY((int)hipMemsetAsync(c->icp_loop_slots, 0, (size_t)KF_ICP_LOOP_STEPS * KF_ICP_MAX_WG * 32 * sizeof(unsigned long long), c->stream));
+  TRY(dev_alloc(&c->icp_loop_slots, (size_t)KF_ICP_LOOP_STEPS * KF_ICP_LOOP_MAX_WG * 32));
+  TRY((int)hipMemsetAsync(c->icp_loop_slots, 0, (size_t)KF_ICP_LOOP_STEPS * KF_ICP_LOOP_MAX_WG * 32 * sizeof(unsigned long long), c->stream));
   TRY(dev_alloc(&c->track, 1)); TRY(dev_alloc(&c->counters, 1)); TRY(dev_alloc(&c->grid_barrier, 1));
   TRY((int)hipMemsetAsync(c->grid_barrier, 0, sizeof(KfGridBarrier), c->stream)); TRY(dev_alloc(&c->scratch_mats, 8 * 16));
   TRY((int)hipMemsetAsync(c->track, 0, sizeof(KfTrackState), c->stream));

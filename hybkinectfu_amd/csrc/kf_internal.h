@@ -15,7 +15,8 @@
 #define KF_FLAG_HASNEG 2u          // some voxel of the brick has (or once had) tsdf < 0
 #define KF_MACRO 32                // voxels per macro-cell edge (raycast empty-space skipping)
 #define KF_MAX_LEVELS 3
-#define KF_ICP_MAX_WG 512
+#define KF_ICP_MAX_WG 2048             // workgroups of one ICP / SDF step launch (1536 pixels each: up to 3.1 M pixels)
+#define KF_ICP_LOOP_MAX_WG 512         // workgroups of the persistent ICP loop (bounded by the CU count anyway)
 #define KF_ICP_LOOP_STEPS 32           // Gauss-Newton steps of one persistent ICP launch (stock: 4 + 5 + 10)
 
 enum { KF_ERR_ARG = 1001, KF_ERR_STATE = 1002, KF_ERR_ALLOC = 1003 };
@@ -95,7 +96,7 @@ struct kf_ctx {
   float4* new_v[KF_MAX_LEVELS]; float4* new_n[KF_MAX_LEVELS];
   float4* model_v[KF_MAX_LEVELS]; float4* model_n[KF_MAX_LEVELS];
   float* icp_partials;                // KF_ICP_MAX_WG x 32 floats
-  unsigned long long* icp_loop_slots; // persistent ICP loop: KF_ICP_LOOP_STEPS x KF_ICP_MAX_WG x 32 tagged partial sums
+  unsigned long long* icp_loop_slots; // persistent ICP loop: KF_ICP_LOOP_STEPS x KF_ICP_LOOP_MAX_WG x 32 tagged partial sums
   unsigned icp_loop_seq;              // host-side launch counter of that loop (x 64): tags never repeat across launches
   int persistent_disabled;            // set when a persistent loop reported KF_TRACK_STALLED: later frames use one launch per step
   KfTrackState* track;                // device

@@ -155,8 +155,10 @@ __device__ __forceinline__ bool block_may_have_surface(const McArgs& a, size_t f
 __global__ void __launch_bounds__(256) k_mc_count(McArgs a) {
   __shared__ int s_any; __shared__ unsigned s_sum[4];
   const int R = a.vol.res;
-  const size_t first = (size_t)blockIdx.x * 256;
-  if (!block_may_have_surface(a, first, &s_any)) { if (threadIdx.x == 0) a.block_counts[blockIdx.x] = 0; return; }
+  const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;      // 2-D grid: a 2048^3 volume has more 256-cell blocks than one grid dimension may hold threads
+  if (blk >= a.n_blocks) return;
+  const size_t first = (size_t)blk * 256;
+  if (!block_may_have_surface(a, first, &s_any)) { if (threadIdx.x == 0) a.block_counts[blk] = 0; return; }
   const size_t i = first + threadIdx.x;
   const size_t n_cells = (size_t)(a.z1 - a.z0) * R * R;
   int n = 0;
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(256) k_mc_count(McArgs a) {
   float s = kf_wave_sum((float)n);
   if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = (unsigned)s;
   __syncthreads();
-  if (threadIdx.x == 0) a.block_counts[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+  if (threadIdx.x == 0) a.block_counts[blk] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
 }
 
 // exclusive scan of block_counts[0..n) in place by ONE workgroup (chunks of 1024), total -> block_counts[n]
@@ -197,10 +199,12 @@ __global__ void __launch_bounds__(256) k_mc_scan(unsigned* counts, unsigned n, K
 
 __global__ void __launch_bounds__(256) k_mc_emit(McArgs a) {
   __shared__ unsigned s_wave[4];
-  const unsigned my_base = a.block_counts[blockIdx.x], my_count = a.block_counts[blockIdx.x + 1] - my_base;
+  const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
+  if (blk >= a.n_blocks) return;
+  const unsigned my_base = a.block_counts[blk], my_count = a.block_counts[blk + 1] - my_base;
   if (my_count == 0) return;
   const int R = a.vol.res;
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t i = (size_t)blk * 256 + threadIdx.x;
   const size_t n_cells = (size_t)(a.z1 - a.z0) * R * R;
   CellEval e; e.ntri = 0;
   int n = 0;
@@ -242,9 +246,10 @@ extern "C" int kf_marching_cubes(kf_ctx* c, int has_color, float thr) {
   a.n_blocks = (unsigned)((n_cells + 255) / 256);
   if (a.n_blocks > c->mc_blocks_cap) return KF_ERR_STATE;
   a.block_counts = c->mc_block_counts; a.tris = c->triangles; a.max_tris = c->max_triangles; a.cnt = c->counters;
-  hipLaunchKernelGGL(k_mc_count, dim3(a.n_blocks), dim3(256), 0, c->stream, a);
+  const unsigned gx = a.n_blocks < (1u << 20) ? a.n_blocks : (1u << 20), gy = (a.n_blocks + gx - 1) / gx;
+  hipLaunchKernelGGL(k_mc_count, dim3(gx, gy), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(k_mc_scan, dim3(1), dim3(256), 0, c->stream, a.block_counts, a.n_blocks, c->counters);
-  hipLaunchKernelGGL(k_mc_emit, dim3(a.n_blocks), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_mc_emit, dim3(gx, gy), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(k_mc_finish, dim3(1), dim3(64), 0, c->stream, c->counters, c->max_triangles);
   return (int)hipGetLastError();
 }

@@ -433,7 +433,7 @@ struct IcpLoopArgs {
   KfCam cam[KF_MAX_LEVELS];
   int iters[KF_MAX_LEVELS]; int levels;
   float dist_thres, sin_thres, dist_shake, angle_shake;
-  unsigned long long* slots;                     // KF_ICP_LOOP_STEPS x KF_ICP_MAX_WG x 32 tagged partial sums, one array per step
+  unsigned long long* slots;                     // KF_ICP_LOOP_STEPS x KF_ICP_LOOP_MAX_WG x 32 tagged partial sums, one array per step
   unsigned tag_base;                             // this launch's sequence number (host counter x 64); tag = tag_base + step
   KfTrackState* track;
   int exp_mode;                                  // diagnostics only (KF_ICP_EXP): 1 = skip the solve (timing), 7 = shader-clock stamps per phase
@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     for (int it = 0; it < L.iters[l]; ++it, ++step) {
       KF_STAMP(0);
       if (step > 0) {
-        fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort);
+        fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort);
         if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; } return; }
         KF_STAMP(1);
         if (L.exp_mode == 1) { if (threadIdx.x == 0) s_code = STEP_APPLIED; __syncthreads(); } else     // timing only: skip the 6x6 solve
@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
           sw += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sw), 0x111, 0xf, 0xf, true));   // row_shr:1
           sw += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sw), 0x112, 0xf, 0xf, true));   // row_shr:2
           if (part == 3)
-            __hip_atomic_store(L.slots + (size_t)step * KF_ICP_MAX_WG * 32 + blockIdx.x * 32 + k,
+            __hip_atomic_store(L.slots + (size_t)step * KF_ICP_LOOP_MAX_WG * 32 + blockIdx.x * 32 + k,
                                ((unsigned long long)(L.tag_base + (unsigned)step) << 32) | (unsigned long long)__float_as_uint(sw),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   }
   if (stamp) { for (int i = 0; i < 6; ++i) st->reduced[20 + i] = seg[i]; }
   // the last step's system, then commit _pose (ICP.cpp:84)
-  fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort);
+  fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort);
   if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; } return; }
   apply_step(a, s_tot, s_cur, &s_code);
   if (blockIdx.x != 0) return;
@@ -774,7 +774,7 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   const int grid0 = icp_grid(c->cols * c->rows);
   static int persistent_env = -1;
   if (persistent_env < 0) { const char* e = getenv("KF_ICP_PERSISTENT"); persistent_env = e ? atoi(e) : 1; }
-  if (persistent_env && !c->persistent_disabled && grid0 <= c->num_cus && grid0 <= KF_ICP_MAX_WG && iters[0] + iters[1] + iters[2] <= KF_ICP_LOOP_STEPS &&
+  if (persistent_env && !c->persistent_disabled && grid0 <= c->num_cus && grid0 <= KF_ICP_LOOP_MAX_WG && iters[0] + iters[1] + iters[2] <= KF_ICP_LOOP_STEPS &&
       kf_live_contexts(c->cfg.device) == 1) {
     // every workgroup must be resident at once (software grid barrier): one 1024-lane workgroup per CU, grid0 <= #CUs
     IcpLoopArgs L; memset(&L, 0, sizeof(L));

@@ -335,3 +335,36 @@ def test_prefetched_preprocess_is_bit_identical():
         for a, b in zip(outs[0][1], other[1]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
         assert np.array_equal(outs[0][2][0], other[2][0]) and np.array_equal(outs[0][2][1], other[2][1])
+
+
+def test_maximum_configuration_2048_cubed():
+    """BASELINE.json's largest configuration on ONE GPU: 2048^3 @ 8 m (68.7 GB of voxels), 1280x960 depth.  Exercises the 64-bit
+    voxel addressing, a brick queue of > 1 M entries, the one-launch-per-step ICP (1.2 M pixels exceed the persistent loop's
+    workgroup budget) and the 2-D marching-cubes grid (33.5 M blocks)."""
+    import ctypes as C
+    import torch
+    from hybkinectfu_amd.pipeline import SingleGpuPipeline
+    free, _ = torch.cuda.mem_get_info()
+    if free < 90 * 2**30:
+        pytest.skip("needs ~75 GB of free HBM")
+    res, size, cam = 2048, 8.0, S.vga_camera(2)
+    n = 4
+    frames = np.stack([S.render_depth_mm(S.trajectory_pose(k, size), cam, size) for k in range(n)])
+    dev = torch.from_numpy(frames.astype(np.int16)).cuda()
+    fb = cam[0] * cam[1] * 2
+    pipe = SingleGpuPipeline(K.camera(*cam), res, size, dict(trunc_max=8.0, integ_dist=8.0), max_triangles=16_000_000)
+    for k in range(n):
+        pipe.process_frame_device(dev.data_ptr() + k * fb, k)
+        ok, pose, status, iters = pipe.track_result()
+        assert ok and status == 0 and iters == (0 if k == 0 else 19)
+        assert np.linalg.norm(pose[:3, 3] - S.trajectory_pose(k, size)[:3, 3]) < 2e-3
+    st = pipe.stats()
+    assert st["frames_fused"] == n and st["frames_lost"] == 0
+    assert st["updated_last"] > 4e8 and st["weight_gt0"] >= st["updated_last"] and st["bricks_active"] > 1_000_000
+    hit = pipe.ctx.download_map(K.MAP_MODEL_VERTICES)[..., 3] != 0
+    assert hit.sum() > 0.9 * hit.size
+    pipe.ctx.marching_cubes(300 * size / res)
+    cnt = C.c_uint32()
+    assert pipe.ctx.lib.kf_triangle_count(pipe.ctx.h, C.byref(cnt)) == 0
+    assert 1_000_000 < cnt.value < 16_000_000
+    pipe.close()
