@@ -34,10 +34,16 @@ extern "C" int kf_destroy(kf_ctx* c) {
   hipSetDevice(c->cfg.device);
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->own_stream) hipStreamSynchronize(c->own_stream);
-  void* ptrs[] = {c->depth_mm, c->raw_depth, c->trunced_depth, c->filtered_depth, c->raw_rgb, c->raycast_rgb, c->icp_partials, c->icp_loop_slots,
+  void* ptrs[] = {c->up_dev[0], c->up_dev[1], c->raw_depth, c->trunced_depth, c->filtered_depth, c->raw_rgb, c->raycast_rgb, c->icp_partials, c->icp_loop_slots,
                   c->track, c->counters, c->grid_barrier, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macro, c->vol.negbits, c->active_bricks,
                   c->tile_max_depth, c->triangles, c->mc_block_counts};
   for (void* p : ptrs) if (p) hipFree(p);
+  if (c->up_stream) { hipStreamSynchronize(c->up_stream); hipStreamDestroy(c->up_stream); }
+  for (int i = 0; i < 2; ++i) {
+    if (c->up_host[i]) hipHostFree(c->up_host[i]);
+    if (c->up_copied[i]) hipEventDestroy(c->up_copied[i]);
+    if (c->up_consumed[i]) hipEventDestroy(c->up_consumed[i]);
+  }
   void* alts[] = {c->alt_raw, c->alt_trunced, c->alt_filtered, c->alt_v0, c->alt_n0};
   for (void* p : alts) if (p) hipFree(p);
   if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
@@ -79,7 +85,7 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
 #define TRY(x) do { st = (x); if (st) { kf_destroy(c); return st; } } while (0)
   TRY((int)hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   const size_t npx = (size_t)c->cols * c->rows;
-  TRY(dev_alloc(&c->depth_mm, npx));
+  c->pending_slot = -1;
   TRY(dev_alloc(&c->raw_depth, npx)); TRY(dev_alloc(&c->trunced_depth, npx)); TRY(dev_alloc(&c->filtered_depth, npx));
   const size_t nrgb = (size_t)cfg->rgb_camera.cols * cfg->rgb_camera.rows;
   if (cfg->has_color) { TRY(dev_alloc(&c->raw_rgb, nrgb ? nrgb : npx)); TRY(dev_alloc(&c->raycast_rgb, npx)); }
@@ -179,7 +185,12 @@ __global__ void __launch_bounds__(256) k_depth_mm_to_m(const uint16_t* __restric
 // (kf_trunc_depth, kf_download_map) materialises it first.  The caller keeps dev_mm alive until then (bench: resident frames).
 extern "C" int kf_set_depth_mm_device(kf_ctx* c, const uint16_t* dev_mm, uint32_t cols, uint32_t rows) {
   if (!c || !dev_mm || (int)cols != c->cols || (int)rows != c->rows) return KF_ERR_ARG;
-  c->pending_mm = dev_mm;
+  c->pending_mm = dev_mm; c->pending_slot = -1;
+  return 0;
+}
+// the kernel that reads pending_mm has just been enqueued on the main stream: its upload buffer may be refilled after it
+int kf_pending_depth_consumed(kf_ctx* c) {
+  if (c->pending_slot >= 0) { KF_CHECK(hipEventRecord(c->up_consumed[c->pending_slot], c->stream)); c->pending_slot = -1; }
   return 0;
 }
 int kf_materialize_raw_depth(kf_ctx* c) {
@@ -187,13 +198,37 @@ int kf_materialize_raw_depth(kf_ctx* c) {
   int n = c->cols * c->rows;
   hipLaunchKernelGGL(k_depth_mm_to_m, dim3(kf_div_up(n, 256)), dim3(256), 0, c->stream, c->pending_mm, c->raw_depth, n);
   c->pending_mm = nullptr;
-  return (int)hipGetLastError();
+  int st = (int)hipGetLastError();
+  return st ? st : kf_pending_depth_consumed(c);
 }
 
 extern "C" int kf_upload_depth_mm(kf_ctx* c, const uint16_t* host_mm, uint32_t cols, uint32_t rows) {
   if (!c || !host_mm || (int)cols != c->cols || (int)rows != c->rows) return KF_ERR_ARG;
-  KF_CHECK(hipMemcpyAsync(c->depth_mm, host_mm, (size_t)cols * rows * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
-  return kf_set_depth_mm_device(c, c->depth_mm, cols, rows);
+  KF_CHECK(hipSetDevice(c->cfg.device));
+  const size_t bytes = (size_t)cols * rows * sizeof(uint16_t);
+  if (!c->up_stream) {
+    KF_CHECK(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      KF_CHECK(hipHostMalloc((void**)&c->up_host[i], bytes, hipHostMallocDefault));
+      KF_CHECK(hipMalloc((void**)&c->up_dev[i], bytes));
+      KF_CHECK(hipEventCreateWithFlags(&c->up_copied[i], hipEventDisableTiming));
+      KF_CHECK(hipEventCreateWithFlags(&c->up_consumed[i], hipEventDisableTiming));
+    }
+  }
+  const int p = c->up_next; c->up_next ^= 1;
+  if (c->pending_slot == p) c->pending_slot = -1;            // the frame uploaded two calls ago was never consumed: it is being replaced
+  if (c->up_used[p]) {
+    KF_CHECK(hipEventSynchronize(c->up_copied[p]));           // the pinned buffer's previous DMA (two uploads ago: long finished)
+    KF_CHECK(hipStreamWaitEvent(c->up_stream, c->up_consumed[p], 0));   // the device buffer's last reader
+  }
+  memcpy(c->up_host[p], host_mm, bytes);
+  KF_CHECK(hipMemcpyAsync(c->up_dev[p], c->up_host[p], bytes, hipMemcpyHostToDevice, c->up_stream));
+  KF_CHECK(hipEventRecord(c->up_copied[p], c->up_stream));
+  KF_CHECK(hipStreamWaitEvent(c->stream, c->up_copied[p], 0));
+  if (!c->up_used[p]) KF_CHECK(hipEventRecord(c->up_consumed[p], c->stream));   // give the event a defined state before its first wait
+  c->up_used[p] = 1;
+  c->pending_mm = c->up_dev[p]; c->pending_slot = p;
+  return 0;
 }
 
 __global__ void __launch_bounds__(256) k_rgb3_to_rgb4(const unsigned char* __restrict__ in, uchar4* __restrict__ out, int n) {

@@ -83,7 +83,10 @@ struct kf_ctx {
   int num_cus;                        // compute units of the device (co-residency bound of the persistent ICP loop)
   int lvl_cols[KF_MAX_LEVELS], lvl_rows[KF_MAX_LEVELS];
   // frame maps (CudaDeviceDataMan.h:56-67)
-  uint16_t* depth_mm;                 // staging for host uploads
+  // host uploads (kf_upload_depth_mm) are double-buffered: pinned host staging -> DMA on a copy stream -> device buffer, so
+  // frame k+1 crosses PCIe while frame k is computed; events order the copy after the last reader of the buffer it reuses
+  uint16_t* up_host[2]; uint16_t* up_dev[2]; hipStream_t up_stream; hipEvent_t up_copied[2], up_consumed[2];
+  int up_next, up_used[2], pending_slot;   // pending_slot: which up_dev[] pending_mm points at (-1: a caller-owned device frame)
   const uint16_t* pending_mm;         // device u16 frame whose conversion is deferred into the fused preprocess kernel
   float* raw_depth; float* trunced_depth; float* filtered_depth;
   uchar4* raw_rgb; uchar4* raycast_rgb;   // stored 4 bytes/pixel on the device
@@ -387,3 +390,4 @@ int kf_launch_pyramids(kf_ctx* ctx, bool model, bool vertices, bool normals);
 int kf_launch_pyramids_and_begin(kf_ctx* ctx, int begin_mode);
 int kf_live_contexts(int device);
 int kf_materialize_raw_depth(kf_ctx* ctx);
+int kf_pending_depth_consumed(kf_ctx* ctx);

@@ -315,6 +315,7 @@ extern "C" int kf_preprocess(kf_ctx* c, float tmin, float tmax, float sigma_pixe
     st = launch_fused_preprocess(c, c->stream, c->pending_mm, c->raw_depth, c->raw_depth, c->trunced_depth, c->filtered_depth, c->new_v[0], c->new_n[0],
                                  tmin, tmax, sigma_pixel, sigma_depth, cam);
     c->pending_mm = nullptr;
+    if (st == 0) st = kf_pending_depth_consumed(c);
   } else {
     c->prefetch_valid = 0;
     if ((st = kf_trunc_depth(c, tmin, tmax))) return st;
