@@ -121,15 +121,18 @@ __global__ void __launch_bounds__(256) k_vertices_normals(const float* __restric
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= cam.cols || y >= cam.rows) return;
   const int i = y * cam.cols + x;
+  // DepthCamera.h:19-29 `depth*(x - cx)/fx`: ten quotients by the two focal lengths per pixel -> their reciprocals are refined once
+  const KfRecip rfx = kf_recip(cam.fx), rfy = kf_recip(cam.fy);
+  auto skeleton = [&](int px, int py, float d) { return kf3(kf_div(d * ((float)(unsigned)px - cam.cx), rfx), kf_div(d * ((float)(unsigned)py - cam.cy), rfy), d); };
   const float d0 = depth[i];
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f), n = v;
   float3 v0 = kf3(0.f, 0.f, 0.f);
-  if (d0 != 0.f) { v0 = kf_depth_to_skeleton((unsigned)x, (unsigned)y, d0, cam); v = make_float4(v0.x, v0.y, v0.z, 1.0f); }
+  if (d0 != 0.f) { v0 = skeleton(x, y, d0); v = make_float4(v0.x, v0.y, v0.z, 1.0f); }
   if (d0 != 0.f && !(x == cam.cols - 1 || y == cam.rows - 1 || x == 0 || y == 0)) {
     const float dr = depth[i + 1], du = depth[i + cam.cols], dl = depth[i - 1], dd = depth[i - cam.cols];
     if (dr != 0.f && du != 0.f && dl != 0.f && dd != 0.f) {                       // a vertex's z is its depth: z == 0 <=> depth == 0
-      const float3 vr = kf_depth_to_skeleton((unsigned)(x + 1), (unsigned)y, dr, cam), vu = kf_depth_to_skeleton((unsigned)x, (unsigned)(y + 1), du, cam);
-      const float3 vl = kf_depth_to_skeleton((unsigned)(x - 1), (unsigned)y, dl, cam), vd = kf_depth_to_skeleton((unsigned)x, (unsigned)(y - 1), dd, cam);
+      const float3 vr = skeleton(x + 1, y, dr), vu = skeleton(x, y + 1, du);
+      const float3 vl = skeleton(x - 1, y, dl), vd = skeleton(x, y - 1, dd);
       const float3 c = kf_normalize(kf_cross(kf_sub(vu, vd), kf_sub(vr, vl)));
       n = make_float4(c.x, c.y, c.z, 0.f);
     }
