@@ -90,11 +90,11 @@ def test_empty_and_invalid_depth():
     ctx.close()
 
 
-def _fuse_sequence(res, size, cam, n_frames, sdf_trunc, max_dist, color=False):
+def _fuse_sequence(res, size, cam, n_frames, sdf_trunc, max_dist, color=False, levels=3):
     """Integrate n_frames of Scene S with ground-truth poses on both sides; returns (ctx, ovol, last pose, maps)."""
     ocam, kcam = O.Cam.make(*cam), K.camera(*cam)
     ovol = O.OVolume(res, size, P["volume_max_weight"])
-    ctx = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=400000, has_color=color)
+    ctx = K.Context(kcam, res, size, P["volume_max_weight"], levels=levels, max_triangles=400000, has_color=color)
     rng = np.random.default_rng(5)
     pose = None
     for k in range(n_frames):
@@ -178,9 +178,9 @@ def test_integrate_color_bit_exact():
     ctx.close()
 
 
-def _tracking_case(res, size, cam, trunc, n_warm=2):
+def _tracking_case(res, size, cam, trunc, n_warm=2, levels=3):
     """Fuse a few frames, raycast from the last pose, then present the NEXT frame: returns everything ICP needs."""
-    ctx, ovol, pose, ocam = _fuse_sequence(res, size, cam, n_warm, trunc, 2.5)
+    ctx, ovol, pose, ocam = _fuse_sequence(res, size, cam, n_warm, trunc, 2.5, levels=levels)
     inc = 0.7 * trunc
     ov, on, _ = O.raycast(ovol, False, pose, inc, ocam, P["depth_trunc_min"], P["depth_trunc_max"])
     ctx.raycast(pose, inc, P["depth_trunc_min"], P["depth_trunc_max"])
@@ -228,6 +228,22 @@ def test_icp_system_and_track(res, cam, trunc):
     ctx.icp_track(0, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
     ok0, pose0, _, it0 = ctx.track_result()
     assert ok0 and it0 == 0 and np.array_equal(pose0, pose)
+    ctx.close()
+
+
+@pytest.mark.parametrize("levels,iters", [(1, 3), (2, 15)])
+def test_icp_track_with_fewer_pyramid_levels(levels, iters):
+    """nPyramidLevels 1 and 2 (src/CameraPoseFinderICP.cpp:14-35: 3 iterations, resp. 10 + 5) against the oracle's loop."""
+    size, res, cam, trunc = 3.0, 64, mid_cam(), 5 * 3.0 / 64
+    ctx, ovol, pose, nxt, ocam, (v, n, ov, on, tr) = _tracking_case(res, size, cam, trunc, levels=levels)
+    nv, nn = O.pyramid(v, levels), O.pyramid(n, levels, normals=True)
+    mv, mn = O.pyramid(ov, levels), O.pyramid(on, levels, normals=True)
+    ok_o, pose_o = O.icp_estimate(nv, nn, mv, mn, ocam, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"], pose)
+    ctx.set_pose(pose)
+    ctx.icp_track(1, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+    ok_g, pose_g, status, it = ctx.track_result()
+    assert ok_o and ok_g and status == 0 and it == iters
+    assert np.max(np.abs(pose_g[:3, 3] - pose_o[:3, 3])) < 1e-4 and np.max(np.abs(pose_g[:3, :3] - pose_o[:3, :3])) < 1e-4
     ctx.close()
 
 
