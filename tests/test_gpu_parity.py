@@ -384,3 +384,25 @@ def test_maximum_configuration_2048_cubed():
     assert pipe.ctx.lib.kf_triangle_count(pipe.ctx.h, C.byref(cnt)) == 0
     assert 1_000_000 < cnt.value < 16_000_000
     pipe.close()
+
+
+def test_weight_saturation_bit_exact():
+    """tsdfVolume.h:65 `fminf(weight + 1, max_weight)`: with max_weight = 2 the running average stops adapting after two frames;
+    five integrations must still match the oracle bit for bit (tsdf, weight, update counts)."""
+    size, res, cam, trunc = 3.0, 64, mid_cam(), 0.1
+    ocam, kcam = O.Cam.make(*cam), K.camera(*cam)
+    ovol = O.OVolume(res, size, 2.0)
+    ctx = K.Context(kcam, res, size, 2.0, levels=3)
+    for k in range(5):
+        pose = S.trajectory_pose(4 * k, size).astype(np.float32)
+        mm = S.render_depth_mm(pose, cam, size)
+        d, tr, fl, v, n = oracle_preprocess(mm, ocam)
+        n_o = O.integrate(ovol, tr, n, None, False, False, pose, trunc, 2.5, ocam, ocam)
+        ctx.upload_depth_mm(mm)
+        ctx.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+        ctx.integrate(pose, trunc, 2.5)
+        assert ctx.stats()["updated_last"] == n_o
+    t, w = ctx.download_volume()
+    assert np.array_equal(bits(t), bits(ovol.tsdf)) and np.array_equal(bits(w), bits(ovol.weight))
+    assert w.max() == 2.0 and (w == 2.0).sum() > 1000
+    ctx.close()
