@@ -110,8 +110,13 @@ class SlabPipeline:
         self.ctx = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=max_triangles, device=device,
                              slab=self.slab, halo=SLAB_HALO)
         self.ctx.set_pose(S.pose0(size))
-        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)     # kernels and RCCL collectives ordered on one stream
         dev = torch.device("cuda", device)
+        # ONE stream orders the library's kernels, torch's elementwise ops and the RCCL collectives (which synchronise with the
+        # CURRENT torch stream).  It has to be a stream of its own: torch's default stream has the null handle, which
+        # kf_set_stream reads as "back to the private stream" -- the kernels would then race with the collectives.
+        self.stream = torch.cuda.Stream(device=dev)
+        assert self.stream.cuda_stream != 0
+        self.ctx.set_stream(self.stream.cuda_stream)
         self.t = torch.empty((kcam.rows, kcam.cols), dtype=torch.float32, device=dev)
         self.tmin = torch.empty_like(self.t)
         # vertex and normal candidates share one buffer, so their merge is ONE integer SUM all-reduce (9.8 MB at VGA)
@@ -121,6 +126,10 @@ class SlabPipeline:
         self.sums = torch.zeros(32, dtype=torch.float32, device=dev)
 
     def process_frame_device(self, dev_mm_ptr, frame_id, next_mm_ptr=None):
+        with self.torch.cuda.stream(self.stream):
+            self._process_frame_device(dev_mm_ptr, frame_id, next_mm_ptr)
+
+    def _process_frame_device(self, dev_mm_ptr, frame_id, next_mm_ptr):
         c, dist = self.ctx, self.dist
         c.set_depth_mm_device(dev_mm_ptr)
         c.preprocess(P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])

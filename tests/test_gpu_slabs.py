@@ -152,3 +152,41 @@ def test_device_mask_equals_torch_merge_rule():
     assert torch.equal(vd.cpu().view(torch.int32), want_v) and torch.equal(nd.cpu().view(torch.int32), want_n)
     assert win.any() and not win.all()
     ctx.close()
+
+
+def test_slab_pipeline_over_rccl_matches_single_gpu_pipeline():
+    """The pipeline bench.py runs on N > 1 GPUs (SlabPipeline: z-slab context, RCCL all-reduces, device-side masking, everything
+    ordered on ONE torch stream) on a one-rank RCCL group must reproduce the plain single-GPU pipeline bit for bit: poses, model
+    maps and volume after several frames.  A mis-ordered collective or kernel shows up here as a mismatch."""
+    import os
+    import torch.distributed as dist
+    res, size, cam = 384, 3.0, S.vga_camera()                     # stock truncation (0.05 m) = 6.4 voxels, as at C2
+    wl = dict(trunc_max=P["depth_trunc_max"], integ_dist=P["integrate_depth_trunc"])
+    n = 6
+    frames = np.stack([S.render_depth_mm(S.trajectory_pose(k, size), cam, size) for k in range(n)])
+    dev = torch.from_numpy(frames.astype(np.int16)).cuda()
+    fb = cam[0] * cam[1] * 2
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29547")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        outs = []
+        for cls in (PL.SingleGpuPipeline, PL.SlabPipeline):
+            pipe = cls(K.camera(*cam), res, size, wl)
+            poses = []
+            for k in range(n):
+                pipe.process_frame_device(dev.data_ptr() + k * fb, k)
+                ok, pose, status, iters = pipe.track_result()
+                assert ok
+                poses.append(pose.copy())
+            pipe.sync()
+            maps = [pipe.ctx.download_map(m) for m in (K.MAP_MODEL_VERTICES, K.MAP_MODEL_NORMALS)]
+            vol = pipe.ctx.download_volume()
+            outs.append((poses, maps, vol))
+            pipe.close()
+        for a, b in zip(outs[0][0], outs[1][0]):
+            assert np.array_equal(a, b)
+        for a, b in zip(outs[0][1], outs[1][1]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert np.array_equal(outs[0][2][0], outs[1][2][0]) and np.array_equal(outs[0][2][1], outs[1][2][1])
+    finally:
+        dist.destroy_process_group()
