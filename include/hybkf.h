@@ -94,7 +94,9 @@ int kf_create(const kf_config* cfg, kf_ctx** out);
 int kf_destroy(kf_ctx* ctx);
 int kf_synchronize(kf_ctx* ctx);
 void* kf_stream(kf_ctx* ctx);                        /* hipStream_t of the context */
-int kf_set_stream(kf_ctx* ctx, void* hip_stream);    /* enqueue on a caller-owned hipStream_t (NULL: back to the private one) */
+/* enqueue on a caller-owned hipStream_t.  NULL means "back to the private stream", NOT the null stream: a framework whose
+ * default stream has the null handle (PyTorch) must create a stream of its own and make it current around its own work */
+int kf_set_stream(kf_ctx* ctx, void* hip_stream);
 int kf_reset_volume(kf_ctx* ctx);                    /* tsdfvolume::init clearData  src/cuda/tsdfVolume.h:29-37 */
 
 /* HybKinectfu::copyFrameToGPU  src/HybKinectfu.cpp:63-96 : u16 mm -> f32 m ((float)((double)mm*0.001)) into raw_depth */
