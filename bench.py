@@ -189,6 +189,14 @@ def main():
     # roofline of the dominant HBM kernel (k_integrate_pairs, the fusion pass): algorithmic bytes per launch / measured duration
     launches = max(int(cnt[5]), 1)
     kern_ms = float(ms[5]) / launches
+    roof_rank = 0
+    if dist is not None and world > 1:
+        # z-slabs are not equally busy (the camera's near slabs see a narrow frustum): quote the rank that fuses the most voxels
+        mine = torch.tensor([float(n_upd), kern_ms, float(launches)], device="cuda", dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        roof_rank = int(max(range(world), key=lambda r: float(every[r][0])))
+        n_upd, kern_ms, launches = int(every[roof_rank][0].item()), float(every[roof_rank][1].item()), int(every[roof_rank][2].item())
     alg_bytes = (n_upd / max(args.steps, 1)) * 16.0 + cam[0] * cam[1] * 4.0       # N_upd x 2 x 8 B + depth map
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     traffic = None
@@ -199,7 +207,7 @@ def main():
         except Exception:
             traffic = None
     roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                    traffic=traffic, kernel="k_integrate_pairs", kernel_ms=round(kern_ms, 5), launches_timed=int(cnt[5]),
+                    traffic=traffic if world == 1 else None, kernel="k_integrate_pairs", kernel_ms=round(kern_ms, 5), launches_timed=int(launches), rank=roof_rank,
                     algorithmic_bytes_per_launch=int(alg_bytes), n_upd_per_frame=int(n_upd / max(args.steps, 1)))
 
     if args.stages and rank == 0:
