@@ -406,3 +406,38 @@ def test_weight_saturation_bit_exact():
     assert np.array_equal(bits(t), bits(ovol.tsdf)) and np.array_equal(bits(w), bits(ovol.weight))
     assert w.max() == 2.0 and (w == 2.0).sum() > 1000
     ctx.close()
+
+
+def test_reset_volume_equals_fresh_context():
+    """kf_reset_volume: voxels, brick flags, skip tables and counters all return to their initial state -- a sequence fused after a
+    reset is bit-identical (volume, raycast maps, triangles) to the same sequence on a new context."""
+    size, res, cam, trunc = 3.0, 64, mid_cam(), 0.1
+    kcam = K.camera(*cam)
+
+    def fuse(ctx, ks):
+        for k in ks:
+            pose = S.trajectory_pose(3 * k, size).astype(np.float32)
+            ctx.upload_depth_mm(S.render_depth_mm(pose, cam, size))
+            ctx.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+            ctx.integrate(pose, trunc, 2.5)
+        ctx.raycast(pose, 0.7 * trunc, P["depth_trunc_min"], P["depth_trunc_max"])
+        ctx.marching_cubes(300 * size / res)
+        return ctx.download_volume(), ctx.download_map(K.MAP_MODEL_VERTICES), ctx.download_map(K.MAP_MODEL_NORMALS), ctx.triangles()
+
+    a = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=200000)
+    fuse(a, [5, 6, 7])                                            # something else first
+    a.reset_volume()
+    st = a.stats()
+    assert st["weight_gt0"] == 0 and st["updated_total"] == 0 and st["frames_fused"] == 0
+    t, w = a.download_volume()
+    assert not t.any() and not w.any()
+    a.raycast(S.trajectory_pose(0, size).astype(np.float32), 0.7 * trunc, P["depth_trunc_min"], P["depth_trunc_max"])
+    assert not a.download_map(K.MAP_MODEL_VERTICES).any()
+    a.clear_triangles()
+    got = fuse(a, [0, 1, 2])
+    b = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=200000)
+    want = fuse(b, [0, 1, 2])
+    assert np.array_equal(bits(got[0][0]), bits(want[0][0])) and np.array_equal(bits(got[0][1]), bits(want[0][1]))
+    assert np.array_equal(bits(got[1]), bits(want[1])) and np.array_equal(bits(got[2]), bits(want[2]))
+    assert len(got[3]) == len(want[3]) > 1000 and got[3].tobytes() == want[3].tobytes()
+    a.close(); b.close()
