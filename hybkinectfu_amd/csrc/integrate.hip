@@ -103,13 +103,31 @@ __global__ void __launch_bounds__(CULL_WAVES * 64) k_integrate_cull(IntegrateArg
               cull_sphere_visible(a, m, (float)(mx * 32 + 16) * cell, (float)(my * 32 + 16) * cell, (float)(mz * 32 + 16) * cell,
                                   27.0f * cell + 1e-4f * v.size, px, py, pz);
   keep = keep && bx < v.nb && by < v.nb && bz >= v.bz0 && bz < v.bz1;
-  // brick: voxel centres span [(8b+0.5), (8b+7.5)] * cell per axis -> centre (8b+4)*cell, half-diagonal 3.5*sqrt(3)*cell
-  const float r = 6.1f * cell + 1e-4f * v.size;
-  if (keep) keep = cull_sphere_visible(a, m, (float)(bx * 8 + 4) * cell, (float)(by * 8 + 4) * cell, (float)(bz * 8 + 4) * cell, r, px, py, pz);
+  // brick: voxel centres span [(8b+0.5), (8b+7.5)] * cell per axis: an axis-aligned box of half-extent 3.5 cells around
+  // (8b+4)*cell.  Every test below is linear in the voxel position, so its extreme over the box is the value at the centre plus
+  // the box's support h * sum |coefficients| -- up to 42 % tighter than the bounding sphere for planes along the axes, which is
+  // what decides bricks on the frustum's sides and just behind a surface.
+  const float h = 3.5f * cell, eps = 1e-4f * v.size;
+  const float ex = h * (fabsf(m[0]) + fabsf(m[1]) + fabsf(m[2])) + eps, ey = h * (fabsf(m[4]) + fabsf(m[5]) + fabsf(m[6])) + eps;
+  const float ez = h * (fabsf(m[8]) + fabsf(m[9]) + fabsf(m[10])) + eps;
+  if (keep) {
+    const float cx = (float)(bx * 8 + 4) * cell, cy = (float)(by * 8 + 4) * cell, cz = (float)(bz * 8 + 4) * cell;
+    px = m[0] * cx + m[1] * cy + m[2] * cz + m[3];
+    py = m[4] * cx + m[5] * cy + m[6] * cz + m[7];
+    pz = m[8] * cx + m[9] * cy + m[10] * cz + m[11];
+    keep = pz + ez > 0.f && pz - ez < a.max_dist + a.sdf_trunc;         // some voxel with 0 < pf.z < max_dist + trunc
+    // frustum sides (through the eye, one pixel wider): inside means x - tl*z >= 0, tr*z - x >= 0, y - tt*z >= 0, tb*z - y >= 0
+    const float tl = a.fr_slope[0], tr = a.fr_slope[1], tt = a.fr_slope[2], tb = a.fr_slope[3];
+    const float sl = h * (fabsf(m[0] - tl * m[8]) + fabsf(m[1] - tl * m[9]) + fabsf(m[2] - tl * m[10])) + eps * a.fr_norm[0];
+    const float sr = h * (fabsf(tr * m[8] - m[0]) + fabsf(tr * m[9] - m[1]) + fabsf(tr * m[10] - m[2])) + eps * a.fr_norm[1];
+    const float st = h * (fabsf(m[4] - tt * m[8]) + fabsf(m[5] - tt * m[9]) + fabsf(m[6] - tt * m[10])) + eps * a.fr_norm[2];
+    const float sb = h * (fabsf(tb * m[8] - m[4]) + fabsf(tb * m[9] - m[5]) + fabsf(tb * m[10] - m[6])) + eps * a.fr_norm[3];
+    keep = keep && (px - tl * pz) + sl >= 0.f && (tr * pz - px) + sr >= 0.f && (py - tt * pz) + st >= 0.f && (tb * pz - py) + sb >= 0.f;
+  }
   // depth test against the tile max over the brick's pixel footprint (only when the brick is clear of the eye plane)
-  const float zn = pz - r, zf = pz + r;
+  const float zn = pz - ez, zf = pz + ez;
   if (keep && zn > 4.f * cell) {
-    const float xl = px - r, xr = px + r, yl = py - r, yr = py + r;
+    const float xl = px - ex, xr = px + ex, yl = py - ey, yr = py + ey;
     float u0 = (xl < 0.f ? xl / zn : xl / zf) * a.dcam.fx + a.dcam.cx, u1 = (xr > 0.f ? xr / zn : xr / zf) * a.dcam.fx + a.dcam.cx;
     float w0 = (yl < 0.f ? yl / zn : yl / zf) * a.dcam.fy + a.dcam.cy, w1 = (yr > 0.f ? yr / zn : yr / zf) * a.dcam.fy + a.dcam.cy;
     int ix0 = (int)floorf(u0) - 1, ix1 = (int)ceilf(u1) + 2, iy0 = (int)floorf(w0) - 1, iy1 = (int)ceilf(w1) + 2;
