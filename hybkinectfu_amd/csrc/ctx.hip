@@ -126,7 +126,12 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
   TRY(dev_alloc(&v.macro, (size_t)v.nm * v.nm * v.nm + 4));   // read as 32-bit words by the raycast's LDS copy
   TRY(dev_alloc(&v.negbits, kf_negbit_words(c->n_stored_bricks)));
   TRY(dev_alloc(&c->active_bricks, c->n_stored_bricks));
-  TRY(dev_alloc(&c->tile_max_depth, (size_t)kf_div_up(c->cols, 16) * kf_div_up(c->rows, 16)));
+  {                                                          // tile maxima over 8- and 16-pixel tiles, see integrate.hip
+    size_t n = 0;
+    for (int l = 0; l < 2; ++l) n += (size_t)kf_div_up(c->cols, 8 << l) * kf_div_up(c->rows, 8 << l);
+    TRY(dev_alloc(&c->tile_max_depth, n));
+    TRY((int)hipMemsetAsync(c->tile_max_depth, 0, n * sizeof(float), c->stream));
+  }
   c->max_triangles = cfg->max_triangles;
   if (c->max_triangles) TRY(dev_alloc(&c->triangles, (size_t)c->max_triangles));
   c->mc_blocks_cap = (c->n_stored_vox + 255) / 256;
