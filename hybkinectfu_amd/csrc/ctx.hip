@@ -44,7 +44,7 @@ extern "C" int kf_destroy(kf_ctx* c) {
     if (c->up_copied[i]) hipEventDestroy(c->up_copied[i]);
     if (c->up_consumed[i]) hipEventDestroy(c->up_consumed[i]);
   }
-  void* alts[] = {c->alt_raw, c->alt_trunced, c->alt_filtered, c->alt_v0, c->alt_n0};
+  void* alts[] = {c->alt_raw, c->alt_trunced, c->alt_filtered, c->alt_v0, c->alt_n0, c->rgb_staging};
   for (void* p : alts) if (p) hipFree(p);
   if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
   if (c->ev_preprocessed) hipEventDestroy(c->ev_preprocessed);
@@ -247,16 +247,12 @@ __global__ void __launch_bounds__(256) k_rgb4_to_rgb3(const uchar4* __restrict__
 
 extern "C" int kf_upload_rgb(kf_ctx* c, const uint8_t* host_bgr, uint32_t cols, uint32_t rows) {
   if (!c || !host_bgr || !c->raw_rgb || cols != c->cfg.rgb_camera.cols || rows != c->cfg.rgb_camera.rows) return KF_ERR_ARG;
-  size_t n = (size_t)cols * rows;
-  unsigned char* tmp = nullptr;
-  KF_CHECK(hipMalloc((void**)&tmp, n * 3));
-  hipError_t e = hipMemcpyAsync(tmp, host_bgr, n * 3, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_rgb3_to_rgb4, dim3(kf_div_up((int)n, 256)), dim3(256), 0, c->stream, tmp, c->raw_rgb, (int)n);
-    e = hipStreamSynchronize(c->stream);
-  }
-  hipFree(tmp);
-  return (int)e;
+  const size_t n = (size_t)cols * rows;
+  if (!c->rgb_staging) KF_CHECK(hipMalloc((void**)&c->rgb_staging, n * 3));        // 3-byte pixels as they come from the host
+  // the copy out of (pageable) host memory has returned to the caller by the time this function does: no synchronisation needed
+  KF_CHECK(hipMemcpyAsync(c->rgb_staging, host_bgr, n * 3, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_rgb3_to_rgb4, dim3(kf_div_up((int)n, 256)), dim3(256), 0, c->stream, c->rgb_staging, c->raw_rgb, (int)n);
+  return (int)hipGetLastError();
 }
 
 // ---- map download / upload (CudaMap2D::clone(CPU), DataMap.h) -----------------------------------------------------

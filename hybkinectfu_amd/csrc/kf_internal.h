@@ -90,6 +90,7 @@ struct kf_ctx {
   const uint16_t* pending_mm;         // device u16 frame whose conversion is deferred into the fused preprocess kernel
   float* raw_depth; float* trunced_depth; float* filtered_depth;
   uchar4* raw_rgb; uchar4* raycast_rgb;   // stored 4 bytes/pixel on the device
+  unsigned char* rgb_staging;             // kf_upload_rgb: the host's 3-byte pixels before they are widened (allocated on first use)
   // next-frame prefetch (kf_prefetch_frame): a second set of the per-frame preprocess outputs, filled on a side stream while the
   // current frame is tracked (the persistent ICP loop leaves ~100 CUs idle); kf_preprocess swaps the sets when it is asked for
   // exactly that frame with exactly those parameters.  Allocated on first use.
