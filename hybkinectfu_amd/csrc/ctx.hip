@@ -47,6 +47,7 @@ extern "C" int kf_destroy(kf_ctx* c) {
   void* alts[] = {c->alt_raw, c->alt_trunced, c->alt_filtered, c->alt_v0, c->alt_n0, c->rgb_staging};
   for (void* p : alts) if (p) hipFree(p);
   if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
+  if (c->ev_track) hipEventDestroy(c->ev_track);
   if (c->ev_preprocessed) hipEventDestroy(c->ev_preprocessed);
   if (c->ev_prefetched) hipEventDestroy(c->ev_prefetched);
   for (int l = 0; l < KF_MAX_LEVELS; ++l) {

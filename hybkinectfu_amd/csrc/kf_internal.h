@@ -102,6 +102,7 @@ struct kf_ctx {
   float* icp_partials;                // KF_ICP_MAX_WG x 32 floats
   unsigned long long* icp_loop_slots; // persistent ICP loop: KF_ICP_LOOP_STEPS x KF_ICP_LOOP_MAX_WG x 32 tagged partial sums
   unsigned icp_loop_seq;              // host-side launch counter of that loop (x 64): tags never repeat across launches
+  hipEvent_t ev_track; int track_requested;   // kf_request_track_result / kf_wait_track_result
   int persistent_disabled;            // set when a persistent loop reported KF_TRACK_STALLED: later frames use one launch per step
   KfTrackState* track;                // device
   KfCounters* counters;               // device

@@ -898,6 +898,29 @@ extern "C" int kf_sdf_track(kf_ctx* c, uint32_t frame_id, const kf_sdf_tracker_p
   return (int)hipGetLastError();
 }
 
+// The blocking read-back split in two, so that a caller can put more work behind the tracker before it waits for the verdict:
+// kf_request_track_result enqueues the copy of the tracking state (into pinned memory) right where the stream stands and marks
+// the spot with an event; kf_wait_track_result blocks on THAT event only -- whatever was enqueued after the request keeps running.
+extern "C" int kf_request_track_result(kf_ctx* c) {
+  if (!c) return KF_ERR_ARG;
+  if (!c->ev_track) KF_CHECK(hipEventCreateWithFlags(&c->ev_track, hipEventDisableTiming));
+  KF_CHECK(hipMemcpyAsync((char*)c->host_pinned + 1024, c->track, sizeof(KfTrackState), hipMemcpyDeviceToHost, c->stream));
+  KF_CHECK(hipEventRecord(c->ev_track, c->stream));
+  c->track_requested = 1;
+  return 0;
+}
+extern "C" int kf_wait_track_result(kf_ctx* c, kf_track_result* out) {
+  if (!c || !out) return KF_ERR_ARG;
+  if (!c->track_requested) return KF_ERR_STATE;
+  KF_CHECK(hipEventSynchronize(c->ev_track));
+  c->track_requested = 0;
+  const KfTrackState* h = (const KfTrackState*)((const char*)c->host_pinned + 1024);
+  memcpy(out->pose.m, h->pose, 64);
+  out->tracked = h->tracked; out->status = h->status; out->iterations = h->iterations; out->reserved = 0;
+  if (h->status == KF_TRACK_STALLED) c->persistent_disabled = 1;
+  return 0;
+}
+
 extern "C" int kf_read_track_result(kf_ctx* c, kf_track_result* out) {
   if (!c || !out) return KF_ERR_ARG;
   KfTrackState* h = (KfTrackState*)c->host_pinned;

@@ -139,6 +139,15 @@ void CameraPoseFinder::setCameraPose(const Mat44& t) {
   CudaDeviceDataMan::instance()->check(kf_set_pose(CudaDeviceDataMan::instance()->ctx(), &k));
 }
 bool CameraPoseFinder::enqueueCameraPose(const DepthFrameData& d) { return _inited && enqueueEstimate(d); }
+bool CameraPoseFinder::requestPose() {
+  return !CudaDeviceDataMan::instance()->check(kf_request_track_result(CudaDeviceDataMan::instance()->ctx()));
+}
+bool CameraPoseFinder::waitPose() {
+  kf_track_result r;
+  if (CudaDeviceDataMan::instance()->check(kf_wait_track_result(CudaDeviceDataMan::instance()->ctx(), &r))) return false;
+  memcpy(_pose.entries, r.pose.m, 64);
+  return r.tracked != 0;
+}
 bool CameraPoseFinder::syncPose() {
   kf_track_result r;
   if (CudaDeviceDataMan::instance()->check(kf_read_track_result(CudaDeviceDataMan::instance()->ctx(), &r))) return false;
@@ -316,6 +325,22 @@ bool HybKinectfu::processNewFrame(const DepthFrameData& depth_frame, const Color
   copyFrameToGPU(depth_frame, rgb_frame);
   if (dm->check(kf_preprocess(ctx, p->_depth_prepocess_params.fMinTrunc, p->_depth_prepocess_params.fMaxTrunc, p->_depth_prepocess_params.fSigmaPixel,
                               p->_depth_prepocess_params.fSigmaDepth, &p->_depth_camera_params))) return false;
+  if (_camera_pose_finder->deviceResident()) {
+    // Same results as the sequence below, without a bubble: the verdict is requested right behind the tracker, integrate and
+    // raycast are enqueued with the device-resident pose (integrate is predicated on the verdict inside the kernel, :123; a lost
+    // frame leaves the pose untouched, so the raycast sees what getCameraPose() would have returned), and only then does the
+    // host wait -- for the tracker's result, not for the rest of the frame.
+    if (!_camera_pose_finder->enqueueCameraPose(depth_frame) || !_camera_pose_finder->requestPose()) return false;
+    kf_integrate_params ip = {p->_integrate_params.fSdfTruncation, p->_integrate_params.fMaxIntegrateDist};
+    if (dm->check(kf_integrate_volume(ctx, p->_switch_params.useRGBData, p->_switch_params.colorAngleWeight, nullptr, &ip,
+                                      &p->_depth_camera_params, &p->_rgb_camera_params))) return false;
+    kf_raycast_params rp = {p->_raycast_params.fRayIncrement};
+    if (dm->check(kf_raycast_volume(ctx, p->_switch_params.useRGBData, nullptr, &rp, &p->_depth_camera_params,
+                                    p->_depth_prepocess_params.fMinTrunc, p->_depth_prepocess_params.fMaxTrunc))) return false;
+    _last_tracked = _camera_pose_finder->waitPose(); _pending = false;
+    if (_last_tracked && _camera_pose_recorder) _camera_pose_recorder->recordCameraPose(_camera_pose_finder->getCameraPose(), depth_frame.timeStamp());
+    return true;
+  }
   bool camera_tracking_success = _camera_pose_finder->findCameraPose(depth_frame, rgb_frame);
   _last_tracked = camera_tracking_success; _pending = false;
   Mat44 cur_camera_pose = _camera_pose_finder->getCameraPose();

@@ -93,6 +93,11 @@ public:
   // streaming use: enqueue tracking only; the verdict and pose stay on the device until syncPose()
   bool enqueueCameraPose(const DepthFrameData& depth_frame);
   bool syncPose();                                           // blocking read of (tracked, pose) into _pose
+  // the same read-back split in two (kf_request_track_result / kf_wait_track_result): work enqueued between the two calls
+  // overlaps with the host's wait.  deviceResident(): the verdict and the pose of this finder live on the device until read.
+  bool requestPose();
+  bool waitPose();
+  virtual bool deviceResident() const { return !_host_loop; }
 protected:
   Mat44 _pose;
   bool _host_loop = false;
@@ -144,6 +149,7 @@ private:
 
 class CameraPoseFinderFromFile : public CameraPoseFinder {
 public:
+  bool deviceResident() const override { return false; }     // poses are computed on the host
   static Mat44 transformFromQuaternion(const float t[3], const float q_xyzw[4]);   // Eigen's Quaternion -> Matrix3f, in fp32
 protected:
   bool initPoseFinder() override;

@@ -79,7 +79,7 @@ SYMBOLS = [
     "kf_calculate_new_vertices", "kf_calculate_new_normals", "kf_preprocess", "kf_prefetch_frame", "kf_downsample_new_vertices",
     "kf_downsample_new_normals", "kf_downsample_model_vertices", "kf_downsample_model_normals",
     "kf_cal_point_to_plane_solver_params", "kf_cal_sdf_solver_params", "kf_read_solver_params", "kf_set_pose",
-    "kf_icp_track", "kf_sdf_track", "kf_read_track_result", "kf_integrate_volume", "kf_raycast_volume",
+    "kf_icp_track", "kf_sdf_track", "kf_read_track_result", "kf_request_track_result", "kf_wait_track_result", "kf_integrate_volume", "kf_raycast_volume",
     "kf_marching_cubes", "kf_clear_triangles", "kf_triangle_count", "kf_read_triangles", "kf_download_map",
     "kf_upload_map", "kf_download_volume", "kf_upload_volume", "kf_get_volume_stats", "kf_stored_z_range",
     "kf_stage_timers", "kf_read_stage_ms", "kf_set_stream", "kf_raycast_volume_slab", "kf_slab_mask_candidates", "kf_set_model_maps_device", "kf_selftest_div",

@@ -146,6 +146,10 @@ int kf_set_pose(kf_ctx* ctx, const kf_mat44* pose);
 int kf_icp_track(kf_ctx* ctx, uint32_t frame_id, const kf_icp_params* icp, const kf_camera_params* depth_camera);
 int kf_sdf_track(kf_ctx* ctx, uint32_t frame_id, const kf_sdf_tracker_params* sdf, const kf_camera_params* depth_camera);
 int kf_read_track_result(kf_ctx* ctx, kf_track_result* out);          /* blocking */
+/* the same read-back in two halves: `request` enqueues the copy where the stream stands, `wait` blocks until that copy has
+ * arrived -- work enqueued in between (integrate and raycast with transform == NULL) keeps the GPU busy meanwhile */
+int kf_request_track_result(kf_ctx* ctx);
+int kf_wait_track_result(kf_ctx* ctx, kf_track_result* out);
 
 /* cudaIntegrateVolume  src/cuda/integrateVolume.cu:78-96.  transform == NULL: use the device-resident pose and
  * integrate only if the last kf_*_track call tracked (src/HybKinectfu.cpp:123-140). */
