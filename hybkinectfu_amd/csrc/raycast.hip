@@ -286,6 +286,43 @@ extern "C" int kf_slab_mask_candidates(kf_ctx* c, const float* dev_t, const floa
   return (int)hipGetLastError();
 }
 
+// The same merge with a smaller exchange: the winner's vertex and normal travel as six floats per pixel (the two w components
+// are constants of a valid pixel -- 1 and 0 -- and zero otherwise), so the integer SUM all-reduce moves 24 instead of 32 bytes
+// per pixel.  kf_slab_pack_candidates masks and packs in one launch; kf_set_model_maps_packed unpacks the reduced buffer
+// straight into the model maps (a unit normal is never all-zero, which is what marks a valid pixel).
+__global__ void __launch_bounds__(256) k_slab_pack(const float* __restrict__ t, const float* __restrict__ tmin, const float4* __restrict__ v,
+                                                   const float4* __restrict__ n, float* __restrict__ packed, int npx) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= npx) return;
+  const float ti = t[i];
+  const bool win = ti == tmin[i] && ti < __builtin_huge_valf();
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 vi = win ? v[i] : z, ni = win ? n[i] : z;
+  float* o = packed + (size_t)i * 6;
+  o[0] = vi.x; o[1] = vi.y; o[2] = vi.z; o[3] = ni.x; o[4] = ni.y; o[5] = ni.z;
+}
+__global__ void __launch_bounds__(256) k_slab_unpack(const float* __restrict__ packed, float4* __restrict__ v, float4* __restrict__ n, int npx) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= npx) return;
+  const float* p = packed + (size_t)i * 6;
+  const float nx = p[3], ny = p[4], nz = p[5];
+  const bool valid = nx != 0.f || ny != 0.f || nz != 0.f;
+  v[i] = valid ? make_float4(p[0], p[1], p[2], 1.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
+  n[i] = make_float4(nx, ny, nz, 0.f);
+}
+extern "C" int kf_slab_pack_candidates(kf_ctx* c, const float* dev_t, const float* dev_tmin, const float* dev_v, const float* dev_n, float* dev_packed) {
+  if (!c || !dev_t || !dev_tmin || !dev_v || !dev_n || !dev_packed) return KF_ERR_ARG;
+  const int npx = c->cols * c->rows;
+  hipLaunchKernelGGL(k_slab_pack, dim3(kf_div_up(npx, 256)), dim3(256), 0, c->stream, dev_t, dev_tmin, (const float4*)dev_v, (const float4*)dev_n, dev_packed, npx);
+  return (int)hipGetLastError();
+}
+extern "C" int kf_set_model_maps_packed(kf_ctx* c, const float* dev_packed) {
+  if (!c || !dev_packed) return KF_ERR_ARG;
+  const int npx = c->cols * c->rows;
+  hipLaunchKernelGGL(k_slab_unpack, dim3(kf_div_up(npx, 256)), dim3(256), 0, c->stream, dev_packed, c->model_v[0], c->model_n[0], npx);
+  return (int)hipGetLastError();
+}
+
 extern "C" int kf_set_model_maps_device(kf_ctx* c, const float* dev_v, const float* dev_n) {
   if (!c || !dev_v || !dev_n) return KF_ERR_ARG;
   const size_t bytes = (size_t)c->cols * c->rows * sizeof(float4);

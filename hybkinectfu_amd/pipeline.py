@@ -123,6 +123,9 @@ class SlabPipeline:
         self.vn = torch.empty((2, kcam.rows, kcam.cols, 4), dtype=torch.float32, device=dev)
         self.v, self.n = self.vn[0], self.vn[1]
         self.vn_bits = self.vn.view(torch.int32)
+        # what actually crosses xGMI: vertex xyz + normal xyz of the winner, 24 bytes per pixel (7.4 MB at VGA)
+        self.packed = torch.empty((kcam.rows, kcam.cols, 6), dtype=torch.float32, device=dev)
+        self.packed_bits = self.packed.view(torch.int32)
         self.sums = torch.zeros(32, dtype=torch.float32, device=dev)
 
     def process_frame_device(self, dev_mm_ptr, frame_id, next_mm_ptr=None):
@@ -143,12 +146,12 @@ class SlabPipeline:
         c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist)
         c.raycast_slab(None, self.inc, P["depth_trunc_min"], self.trunc_max, self.t.data_ptr(), self.v.data_ptr(), self.n.data_ptr())
         # first crossing along each ray wins (merge_candidates above is the same rule in plain torch, used by the CPU tests):
-        # MIN all-reduce of t, mask the losers on the device, ONE integer SUM all-reduce of both maps
+        # MIN all-reduce of t, mask the losers and pack xyz + xyz on the device, ONE integer SUM all-reduce, unpack into the maps
         self.tmin.copy_(self.t)
         dist.all_reduce(self.tmin, op=dist.ReduceOp.MIN)
-        c.slab_mask_candidates(self.t.data_ptr(), self.tmin.data_ptr(), self.v.data_ptr(), self.n.data_ptr())
-        dist.all_reduce(self.vn_bits, op=dist.ReduceOp.SUM)
-        c.set_model_maps_device(self.v.data_ptr(), self.n.data_ptr())
+        c.slab_pack_candidates(self.t.data_ptr(), self.tmin.data_ptr(), self.v.data_ptr(), self.n.data_ptr(), self.packed.data_ptr())
+        dist.all_reduce(self.packed_bits, op=dist.ReduceOp.SUM)
+        c.set_model_maps_packed(self.packed.data_ptr())
 
     def sync(self):
         self.ctx.sync()

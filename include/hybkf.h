@@ -171,6 +171,10 @@ int kf_raycast_volume_slab(kf_ctx* ctx, int has_color, const kf_mat44* transform
  * first crossing; an integer SUM over the slabs of the masked dev_v / dev_n then yields the winner's bits everywhere */
 int kf_slab_mask_candidates(kf_ctx* ctx, const float* dev_t, const float* dev_tmin, float* dev_v, float* dev_n);
 int kf_set_model_maps_device(kf_ctx* ctx, const float* dev_v, const float* dev_n);   /* model_{vertices,normals}_pyramid[0] <- device buffers */
+/* the same merge with 24 instead of 32 bytes per pixel on the wire: mask + pack (vertex xyz, normal xyz) into dev_packed
+ * [rows x cols x 6 floats], integer-SUM all-reduce that buffer, then unpack it straight into the model maps */
+int kf_slab_pack_candidates(kf_ctx* ctx, const float* dev_t, const float* dev_tmin, const float* dev_v, const float* dev_n, float* dev_packed);
+int kf_set_model_maps_packed(kf_ctx* ctx, const float* dev_packed);
 
 /* Pixel-partitioned ICP ("partition pixels across GPUs, all-reduce the 27-float system").  `dev_sums` is a
  * caller-owned 32-float device buffer.  kf_icp_partition_begin builds the pyramids and arms the loop; for step = 0 ..
