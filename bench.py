@@ -142,7 +142,8 @@ def main():
     dev_frames = torch.from_numpy(frames.astype(np.int16)).cuda()        # u16 bits, resident in HBM
     frame_bytes = cam[0] * cam[1] * 2
 
-    if world == 1 and not args.force_slab:
+    slab = not (world == 1 and not args.force_slab)
+    if not slab:
         from hybkinectfu_amd.pipeline import SingleGpuPipeline as Pipe
         pipe = Pipe(kcam, res, size, wl, device=local_rank)
     else:
@@ -152,7 +153,8 @@ def main():
     def run(first, count):
         # --prefetch: frame k+1 is preprocessed on the context's side stream while frame k is tracked (kf_prefetch_frame)
         for k in range(first, first + count):
-            nxt = dev_frames.data_ptr() + ((k + 1) % n_unique) * frame_bytes if args.prefetch else None
+            # (the z-slab pipeline always gets the hint: it fills the wait for its first all-reduce with the next frame's preprocess)
+            nxt = dev_frames.data_ptr() + ((k + 1) % n_unique) * frame_bytes if (args.prefetch or slab) else None
             pipe.process_frame_device(dev_frames.data_ptr() + (k % n_unique) * frame_bytes, k, nxt)
 
     def barrier():

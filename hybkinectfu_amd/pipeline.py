@@ -127,6 +127,7 @@ class SlabPipeline:
         self.packed = torch.empty((kcam.rows, kcam.cols, 6), dtype=torch.float32, device=dev)
         self.packed_bits = self.packed.view(torch.int32)
         self.sums = torch.zeros(32, dtype=torch.float32, device=dev)
+        self._preprocessed = None           # device pointer of a frame whose preprocess was enqueued during the previous frame's merge
 
     def process_frame_device(self, dev_mm_ptr, frame_id, next_mm_ptr=None):
         with self.torch.cuda.stream(self.stream):
@@ -134,21 +135,28 @@ class SlabPipeline:
 
     def _process_frame_device(self, dev_mm_ptr, frame_id, next_mm_ptr):
         c, dist = self.ctx, self.dist
-        c.set_depth_mm_device(dev_mm_ptr)
-        c.preprocess(P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
+        if self._preprocessed != dev_mm_ptr:                              # not done ahead of time by the previous call (see below)
+            c.set_depth_mm_device(dev_mm_ptr)
+            c.preprocess(P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
+        self._preprocessed = None
         if self.icp_mode == "allreduce":
             c.icp_partition_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"],
                                   self.rank, self.world, self.sums.data_ptr(), lambda: dist.all_reduce(self.sums, op=dist.ReduceOp.SUM))
         else:
             c.icp_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
-        if next_mm_ptr is not None:
-            c.prefetch_frame(next_mm_ptr, P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
         c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist)
         c.raycast_slab(None, self.inc, P["depth_trunc_min"], self.trunc_max, self.t.data_ptr(), self.v.data_ptr(), self.n.data_ptr())
         # first crossing along each ray wins (merge_candidates above is the same rule in plain torch, used by the CPU tests):
         # MIN all-reduce of t, mask the losers and pack xyz + xyz on the device, ONE integer SUM all-reduce, unpack into the maps
         self.tmin.copy_(self.t)
-        dist.all_reduce(self.tmin, op=dist.ReduceOp.MIN)
+        pending = dist.all_reduce(self.tmin, op=dist.ReduceOp.MIN, async_op=True)
+        if next_mm_ptr is not None:
+            # the collective runs on RCCL's own stream until wait() joins it: the next frame's preprocess -- every reader of this
+            # frame's maps is already behind us in the stream -- fills that time instead of the start of the next frame
+            c.set_depth_mm_device(next_mm_ptr)
+            c.preprocess(P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
+            self._preprocessed = next_mm_ptr
+        pending.wait()
         c.slab_pack_candidates(self.t.data_ptr(), self.tmin.data_ptr(), self.v.data_ptr(), self.n.data_ptr(), self.packed.data_ptr())
         dist.all_reduce(self.packed_bits, op=dist.ReduceOp.SUM)
         c.set_model_maps_packed(self.packed.data_ptr())

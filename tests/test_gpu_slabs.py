@@ -174,7 +174,9 @@ def test_slab_pipeline_over_rccl_matches_single_gpu_pipeline():
             pipe = cls(K.camera(*cam), res, size, wl)
             poses = []
             for k in range(n):
-                pipe.process_frame_device(dev.data_ptr() + k * fb, k)
+                # every other frame announces its successor: the slab pipeline then preprocesses it during its merge
+                nxt = dev.data_ptr() + (k + 1) * fb if (k % 2 == 0 and k + 1 < n) else None
+                pipe.process_frame_device(dev.data_ptr() + k * fb, k, nxt)
                 ok, pose, status, iters = pipe.track_result()
                 assert ok
                 poses.append(pose.copy())
