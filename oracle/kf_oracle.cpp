@@ -5,6 +5,13 @@
  * Build: g++ -O2 -ffp-contract=off -fopenmp (oracle/Makefile).  Every fp32 source operation of the
  * reference is one rounded fp32 operation here; double promotions caused by unsuffixed literals in the
  * reference are reproduced explicitly and commented.
+ *
+ * How it is pinned (details in DESIGN.md section 2.2): the header arithmetic (Mat44, voxel <-> world, nearest voxel, trilinear
+ * lookup, updateVoxel, camera projection) is checked bit for bit against the reference's own headers compiled as they lie
+ * (oracle/ref_harness.cpp -> oracle/_ref/libkfref.so, tests/test_oracle_vs_ref.py); the integrate / raycast / marching-cubes
+ * bodies reproduce the numbers the reference's kernels produced in the survey session (SURVEY.md section 8c,
+ * tests/test_oracle_golden.py).  PARITY UNPINNED for: the bilateral filter body, the ICP / SDF row builders and the host
+ * Gauss-Newton solves (Eigen is not vendored: LLT, determinant and AngleAxis are restated by hand) -- closed-form tests only.
  */
 #include "kf_oracle.h"
 #include <math.h>
