@@ -23,10 +23,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from hybkinectfu_amd import lib as K  # noqa: E402
-from hybkinectfu_amd import scene as S  # noqa: E402
+from hybkinectfu_amd import scene as S  # noqa: E402   (numpy only: no GPU, no library load)
 
 P = S.STOCK
+K = None                       # hybkinectfu_amd.lib, bound in main() of a RANK process (the launching parent never loads it)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -97,13 +97,96 @@ def single_gpu_reference(name, n_frames=50, warmup=10):
                 ms_per_step=round(1000.0 * dt / (n_frames - warmup), 4), frames_lost=int(lost))
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process is only a parent.  It has made no GPU call
+    (no torch.cuda, no libhybkf) and starts N fresh rank processes -- `python -m torch.distributed.run`, one per GPU, rendezvous on
+    127.0.0.1 -- waits for them and exits with their status.  It never exec()s."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def collective_selftest(args):
+    """No GPU needed: the ranks form a gloo group and run SlabExchange -- the very sequence of collectives SlabPipeline issues per
+    frame (async MIN all-reduce, overlap hook, pack, integer SUM all-reduce, unpack) -- on CPU tensors, with plain-torch
+    restatements of the pack / unpack kernels (tests/slab_cpu_ops.py), and check the merged maps against the first-crossing rule.
+    Used by tests/test_slab_distributed_cpu.py to cover the launcher path end to end at world_size 2."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import slab_cpu_ops as ops
+    from hybkinectfu_amd.pipeline import SlabExchange
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    rows, cols = 48, 64
+    model = {}
+    ex = SlabExchange(rows, cols, torch.device("cpu"), dist, pack=ops.pack, unpack=lambda packed: model.update(zip("vn", ops.unpack(packed))))
+    ok, overlapped = True, 0
+    for frame in range(3):
+        t, v, n, want_v, want_n = ops.synthetic_candidates(rows, cols, rank, world, seed=100 + frame)
+        ex.t.copy_(t); ex.v.copy_(v); ex.n.copy_(n)
+
+        def overlap():
+            nonlocal overlapped
+            overlapped += 1
+        ex.merge(overlap)
+        ok = ok and torch.equal(model["v"].view(torch.int32), want_v.view(torch.int32)) and torch.equal(model["n"].view(torch.int32), want_n.view(torch.int32))
+    flag = torch.tensor([1 if ok and overlapped == 3 else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps(dict(selftest="slab-collectives", n_gpus=args.gpus, world_size=dist.get_world_size(), backend="gloo",
+                              frames=3, ok=bool(flag.item()))))
+    dist.destroy_process_group()
+    return 0 if flag.item() else 1
+
+
+def pcie_inclusive(wl, frames_mm, n_frames=100, warmup=10):
+    """Frames/s when every frame starts in HOST memory (kf_upload_depth_mm: pinned double-buffered staging, DMA on a copy stream
+    while the previous frame is computed).  Reported beside `value`, never as `value`."""
+    import torch
+    from hybkinectfu_amd.pipeline import SingleGpuPipeline
+    cam = wl["cam"]
+    pipe = SingleGpuPipeline(K.camera(*cam), wl["res"], wl["size"], wl, device=torch.cuda.current_device())
+    c = pipe.ctx
+    host = [np.ascontiguousarray(f, np.uint16) for f in frames_mm]
+
+    def run(first, count):
+        for k in range(first, first + count):
+            mm = host[k % len(host)]
+            K._chk(c.lib.kf_upload_depth_mm(c.h, K._p(mm), mm.shape[1], mm.shape[0]), "kf_upload_depth_mm")
+            c.preprocess(P["depth_trunc_min"], pipe.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
+            c.icp_track(k, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+            c.integrate(None, P["integrate_sdf_trunc"], pipe.integ_dist)
+            c.raycast(None, pipe.inc, P["depth_trunc_min"], pipe.trunc_max)
+    run(0, warmup)
+    pipe.sync()
+    t0 = time.perf_counter()
+    run(warmup, n_frames)
+    pipe.sync()
+    dt = time.perf_counter() - t0
+    pipe.close()
+    return dict(value=round(n_frames / dt, 2), unit="frames/s", steps=n_frames, bytes_per_frame=int(cam[0] * cam[1] * 2),
+                note="every frame uploaded from host memory over PCIe inside the timed region (kf_upload_depth_mm)")
+
+
+STAGE_NAMES = ["upload", "preprocess", "track", "integrate", "raycast", "integrate_kernel", "mcubes", "raycast_kernel"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stages", action="store_true", help="extra instrumented pass: per-stage milliseconds to stderr")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra legs of the N=1 line (per-stage pass, raycast / marching-cubes rooflines, PCIe-inclusive rate)")
     ap.add_argument("--config", default="auto", choices=["auto", "c2", "c4"],
                     help="auto: C2 (512^3 @ 4 m) on 1 GPU, C4 (1024^3 @ 6 m, z-slabs) on N > 1, as BASELINE.json's metric states")
     ap.add_argument("--icp-mode", default="replicated", choices=["replicated", "allreduce"],
@@ -112,17 +195,34 @@ def main():
                     help="skip the extra 50-frame run of the multi-GPU workload (C4) on this one GPU that the N=1 line reports beside the headline")
     ap.add_argument("--prefetch", action="store_true", help="preprocess frame k+1 on a side stream while frame k is tracked (measured neutral at VGA)")
     ap.add_argument("--force-slab", action="store_true", help="run the z-slab pipeline (and its collectives) even with one rank")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL, one GPU per rank (the measured configuration).  gloo: rehearsal only -- ranks may SHARE a GPU "
+                         "(device = local_rank %% device_count), collectives staged through host memory")
+    ap.add_argument("--collective-selftest", action="store_true",
+                    help="CPU only: run the z-slab pipeline's collective sequence over gloo on synthetic candidates and print one JSON line")
     args = ap.parse_args()
 
-    import torch
+    # ---- launcher: a parent that has touched neither the GPU nor the library starts the N ranks ----
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if args.gpus != world:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.collective_selftest:
+        sys.exit(collective_selftest(args))
+
+    global K
+    import torch
+    from hybkinectfu_amd import lib as K
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > n_dev:
+        raise SystemExit("--gpus %d needs %d GPUs, %d visible (RCCL wants one GPU per rank; --backend gloo rehearses ranks sharing a GPU)" % (world, world, n_dev))
+    device = local_rank % n_dev
+    torch.cuda.set_device(device)
     dist = None
     if world > 1 or args.force_slab:
         import torch.distributed as dist
@@ -131,7 +231,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29511")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
 
     wl = workload(world, args.config)
     cam, res, size = wl["cam"], wl["res"], wl["size"]
@@ -145,10 +248,10 @@ def main():
     slab = not (world == 1 and not args.force_slab)
     if not slab:
         from hybkinectfu_amd.pipeline import SingleGpuPipeline as Pipe
-        pipe = Pipe(kcam, res, size, wl, device=local_rank)
+        pipe = Pipe(kcam, res, size, wl, device=device)
     else:
         from hybkinectfu_amd.pipeline import SlabPipeline as Pipe
-        pipe = Pipe(kcam, res, size, wl, rank=rank, world=world, device=local_rank, icp_mode=args.icp_mode)
+        pipe = Pipe(kcam, res, size, wl, rank=rank, world=world, device=device, icp_mode=args.icp_mode)
 
     def run(first, count):
         # --prefetch: frame k+1 is preprocessed on the context's side stream while frame k is tracked (kf_prefetch_frame)
@@ -166,7 +269,11 @@ def main():
     run(0, args.warmup)
     barrier()
     s0 = pipe.stats()
-    pipe.stage_timers((8 << 8) | (1 << 5))    # time the fusion kernel inside the timed region, on every 8th frame (two event records each)
+    # Time the fusion kernel (bit 5) and the whole integrate stage (bit 3) inside the timed region with HIP events on the context's
+    # own stream.  Every `period`-th frame is sampled so that a short run still yields >= 10 timed launches (two event records each
+    # cost ~3 us: sampled sparsely in long runs so they do not perturb `value`).
+    timer_period = max(1, min(8, args.steps // 20))
+    pipe.stage_timers((timer_period << 8) | (1 << 5) | (1 << 3))
     barrier()
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
@@ -189,47 +296,68 @@ def main():
     fps = args.steps / dt
 
     # roofline of the dominant HBM kernel (k_integrate_pairs, the fusion pass): algorithmic bytes per launch / measured duration
-    launches = max(int(cnt[5]), 1)
-    kern_ms = float(ms[5]) / launches
+    launches = int(cnt[5])
+    kern_ms = float(ms[5]) / max(launches, 1)
+    stage_ms = float(ms[3]) / max(int(cnt[3]), 1)
     roof_rank = 0
     if dist is not None and world > 1:
         # z-slabs are not equally busy (the camera's near slabs see a narrow frustum): quote the rank that fuses the most voxels
-        mine = torch.tensor([float(n_upd), kern_ms, float(launches)], device="cuda", dtype=torch.float64)
+        mine = torch.tensor([float(n_upd), kern_ms, float(launches), stage_ms], device="cuda", dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         roof_rank = int(max(range(world), key=lambda r: float(every[r][0])))
-        n_upd, kern_ms, launches = int(every[roof_rank][0].item()), float(every[roof_rank][1].item()), int(every[roof_rank][2].item())
+        n_upd, kern_ms, launches, stage_ms = (int(every[roof_rank][0].item()), float(every[roof_rank][1].item()),
+                                              int(every[roof_rank][2].item()), float(every[roof_rank][3].item()))
     alg_bytes = (n_upd / max(args.steps, 1)) * 16.0 + cam[0] * cam[1] * 4.0       # N_upd x 2 x 8 B + depth map
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "integrate_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(wl["name"])
-        except Exception:
-            traffic = None
-    roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                    traffic=traffic if world == 1 else None, kernel="k_integrate_pairs", kernel_ms=round(kern_ms, 5), launches_timed=int(launches), rank=roof_rank,
-                    algorithmic_bytes_per_launch=int(alg_bytes), n_upd_per_frame=int(n_upd / max(args.steps, 1)))
-
-    if args.stages and rank == 0:
-        pipe.stage_timers(0xFF)
-        run(args.warmup + args.steps, min(args.steps, 50))
-        pipe.sync()
-        sm, sc = pipe.read_stage_ms()
-        names = ["upload", "preprocess", "track", "integrate", "raycast", "integrate_kernel", "mcubes", "raycast_kernel"]
-        print("stage ms/frame: " + ", ".join("%s=%.4f" % (n, sm[i] / max(int(sc[i]), 1)) for i, n in enumerate(names)), file=sys.stderr)
+    if launches >= 10 and kern_ms > 0:
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, "profiles", "integrate_traffic.json")
+        if world == 1 and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(wl["name"])
+                traffic_source = tj.get("source", "profiles/integrate_traffic.json (builder's rocprofv3 --pmc run, not measured in this run)")
+            except Exception:
+                traffic = None
+        roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                        traffic=traffic, traffic_source=traffic_source, kernel="k_integrate_pairs", kernel_ms=round(kern_ms, 5),
+                        launches_timed=int(launches), rank=roof_rank, algorithmic_bytes_per_launch=int(alg_bytes),
+                        n_upd_per_frame=int(n_upd / max(args.steps, 1)),
+                        stage=dict(kernels="k_integrate_cull + k_integrate_pairs (whole integrate stage)", ms=round(stage_ms, 5),
+                                   achieved=round(alg_bytes / (stage_ms * 1e-3) / 1e9, 2) if stage_ms > 0 else None,
+                                   frac=round(alg_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if stage_ms > 0 else None))
+    else:
+        roofline = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None, kernel="k_integrate_pairs",
+                        launches_timed=int(launches), refused="fewer than 10 timed launches of the kernel: run with --steps >= 10")
 
     out = dict(metric="depth frames/sec into TSDF (integrate+ICP+raycast)", value=round(fps, 2), unit="frames/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(1000.0 * dt / args.steps, 4), higher_is_better=True,
                scaling="weak" if world == 1 else "strong", vs_baseline=None, dtype="f32", data="synthetic",
                config=dict(workload=wl["desc"], volume="%d^3 @ %g m" % (res, size), image="%dx%d" % (cam[0], cam[1]),
                            tracker="ICP 10/5/4 (device-resident Gauss-Newton)", frames_lost=int(lost),
-                           partition="none" if world == 1 else "z-slab x%d" % world),
+                           world_size=(dist.get_world_size() if dist is not None else 1),
+                           backend=("none" if dist is None else ("rccl" if args.backend == "nccl" else "gloo (rehearsal: host-staged collectives, ranks may share a GPU)")),
+                           partition="none" if not slab else
+                           "z-slab x%d; %d halo layers per side RE-INTEGRATED by both neighbours (recomputed, not exchanged over xGMI); "
+                           "raycast merge = MIN all-reduce (t, 1.2 MB) + integer SUM all-reduce (vertex+normal, 7.4 MB); ICP %s" % (world, pipe.halo, args.icp_mode)),
                roofline=roofline)
+    extras = world == 1 and not args.force_slab and not args.no_extras
+    if extras:
+        # per-stage device time (HIP events around every stage, 50 extra frames outside the timed region)
+        pipe.stage_timers(0x1F | (1 << 5))
+        run(args.warmup + args.steps, 50)
+        pipe.sync()
+        sm, sc = pipe.read_stage_ms()
+        out["stage_us"] = {STAGE_NAMES[i]: round(1000.0 * float(sm[i]) / max(int(sc[i]), 1), 2) for i in (1, 2, 3, 4, 5)}
+        out["stage_us"]["note"] = "mean device time per frame, HIP events around each stage, 50 frames after the timed region"
+        pipe.stage_timers(0)
     if world == 1 and args.config == "auto" and not args.force_slab and not args.no_scaling_reference:
         pipe.close()
         out["multi_gpu_workload_on_1_gpu"] = single_gpu_reference("c4")      # what --gpus 2/4/8 should be compared with
+    if extras:
+        pipe.close()
+        out["pcie_inclusive"] = pcie_inclusive(wl, frames)
     if world == 1 and not args.no_cpu_baseline:
         pipe.close()
         out["cpu_baseline"] = cpu_baseline(wl, frames)

@@ -138,6 +138,7 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
   c->mc_blocks_cap = (c->n_stored_vox + 255) / 256;
   TRY(dev_alloc(&c->mc_block_counts, c->mc_blocks_cap + 1));
   TRY((int)hipHostMalloc(&c->host_pinned, 4096, hipHostMallocDefault));
+  memset(c->host_pinned, 0, 4096);
   TRY(kf_reset_volume(c));
   TRY((int)hipStreamSynchronize(c->stream));
 #undef TRY

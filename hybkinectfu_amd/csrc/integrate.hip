@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
     for (int b = 0; b < BR; ++b) {
       p[b] = reinterpret_cast<float4*>(v.tw + (size_t)slot[b] * KF_BRICK_VOX) + threadIdx.x;
       q[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((upd[b][0] || upd[b][1]) && a.exp_mode < 2) q[b] = *p[b];
+      if ((upd[b][0] || upd[b][1]) && KF_EXP_MODE(a) < 2) q[b] = *p[b];
     }
 #pragma unroll
     for (int b = 0; b < BR; ++b) {
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
           ++upd_total;
           flags |= KF_FLAG_OBSERVED | (nt < 0.f ? KF_FLAG_HASNEG : 0u);
         }
-        if (a.exp_mode < 1) *p[b] = q[b];
+        if (KF_EXP_MODE(a) < 1) *p[b] = q[b];
         else if (q[b].x == 123.456f) *p[b] = q[b];
       }
       // brick flags: each wave ORs its NEW bits into the brick's byte with a fire-and-forget 32-bit atomic -- no barrier and
@@ -351,7 +351,7 @@ __device__ __forceinline__ kf_f2 kf_div2(kf_f2 a, const KfRecip2& k) {     // kf
 template <int BR>
 __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   const KfVolume& v = a.vol;
-  const unsigned n_active = a.cnt->n_active_bricks >> (a.exp_mode >= 8 ? a.exp_mode - 7 : 0);     // exp_mode 8 / 9: half / quarter of the queue (timing only)
+  const unsigned n_active = a.cnt->n_active_bricks >> (KF_EXP_MODE(a) >= 8 ? KF_EXP_MODE(a) - 7 : 0);     // exp_mode 8 / 9: half / quarter of the queue (timing only)
   const float* m = a.tinv;
   const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8], m9 = m[9], m10 = m[10], m11 = m[11];
   const float cell = v.cell;
@@ -473,7 +473,7 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   a.fr_slope[0] = (-1.f - a.dcam.cx) / a.dcam.fx; a.fr_slope[1] = ((float)a.dcam.cols - a.dcam.cx) / a.dcam.fx;
   a.fr_slope[2] = (-1.f - a.dcam.cy) / a.dcam.fy; a.fr_slope[3] = ((float)a.dcam.rows - a.dcam.cy) / a.dcam.fy;
   for (int i = 0; i < 4; ++i) a.fr_norm[i] = sqrtf(1.f + a.fr_slope[i] * a.fr_slope[i]);
-  { static int em = -1; if (em < 0) { const char* e = getenv("KF_INTEGRATE_EXP"); em = e ? atoi(e) : 0; } a.exp_mode = em; }
+  { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_INTEGRATE_EXP"); a.exp_mode = em; }
   if (transform) {
     for (int i = 0; i < 16; ++i) a.pose_val.m[i] = transform->m[i];
     a.pose = nullptr; a.track = nullptr;

@@ -19,6 +19,21 @@
 #define KF_ICP_LOOP_MAX_WG 512         // workgroups of the persistent ICP loop (bounded by the CU count anyway)
 #define KF_ICP_LOOP_STEPS 32           // Gauss-Newton steps of one persistent ICP launch (stock: 4 + 5 + 10)
 
+// Result-changing timing experiments (KF_INTEGRATE_EXP / KF_ICP_EXP / KF_RAYCAST_EXP: skipped stores, partial queues, clock
+// stamps written into the outputs) exist only in the variant built with -DKF_EXPERIMENTS (`make experiments` ->
+// libhybkf_exp.so, loaded by tools/ via KF_LIB).  In the product library the mode is the constant 0: the branches fold away
+// and the environment is never consulted for them.
+#ifdef KF_EXPERIMENTS
+#include <stdlib.h>
+static inline int kf_exp_env(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+#define KF_EXP_MODE(a) ((a).exp_mode)
+#define KF_EXP_ENV(name) kf_exp_env(name)
+#else
+#define KF_EXP_MODE(a) 0
+#define KF_EXP_ENV(name) 0
+#endif
+
+#define KF_PINNED_STALL_WORD 2048
 enum { KF_ERR_ARG = 1001, KF_ERR_STATE = 1002, KF_ERR_ALLOC = 1003 };
 
 // Dense TSDF volume, bricked: voxel (x,y,z) lives in brick (x>>3, y>>3, z>>3) at offset ((z&7)<<6 | (y&7)<<3 | (x&7)).
@@ -114,7 +129,7 @@ struct kf_ctx {
   float* tile_max_depth;              // device: per 16x16-pixel tile max of gated depth
   kf_triangle* triangles; uint32_t max_triangles;
   unsigned* mc_block_counts; size_t mc_blocks_cap;
-  void* host_pinned;                  // small pinned staging buffer
+  void* host_pinned;                  // small pinned staging buffer (4 KiB); byte KF_PINNED_STALL_WORD: the ICP loop's stall word
   // per-stage hipEvent timers (KF_STAGE_*): bit s of timers_enabled turns stage s on
   int timers_enabled;
   unsigned timers_period;             // time every timers_period-th interval of a stage (>= 1)

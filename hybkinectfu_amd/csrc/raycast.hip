@@ -79,9 +79,11 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
   // march is latency-bound: halving the rays does not shorten it): one bit per 32^3 macro cell of the whole volume
   // (packed here from the byte table), and -- when it fits -- one bit per stored 8^3 brick (KfVolume::negbits).
   extern __shared__ unsigned s_tables[];
+#ifdef KF_EXPERIMENTS
   const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
   const int nm3 = v.nm * v.nm * v.nm;
-  const int macro_words = (nm3 + 31) >> 5;
+  const int macro_words = (((nm3 + 31) >> 5) + 3) & ~3;        // multiple of 4: the brick table behind it is moved as uint4
   unsigned* s_macro = s_tables;
   const unsigned* s_neg = s_tables + macro_words;
   {
@@ -108,7 +110,7 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int x = blockIdx.x * 32 + (wave & 3) * 8 + (lane & 7), y = blockIdx.y * 16 + (wave >> 2) * 8 + (lane >> 3);
   if (x >= a.cam.cols || y >= a.cam.rows) return;
-  if (a.exp_mode == 2 && ((blockIdx.x + blockIdx.y) & 1)) return;      // timing experiment: half the rays (latency- or throughput-bound?)
+  if (KF_EXP_MODE(a) == 2 && ((blockIdx.x + blockIdx.y) & 1)) return;      // timing experiment: half the rays (latency- or throughput-bound?)
   const int pix = y * a.cam.cols + x;
   float4 out_v = make_float4(0.f, 0.f, 0.f, 0.f), out_n = make_float4(0.f, 0.f, 0.f, 0.f);
   uchar4 out_c = make_uchar4(0, 0, 0, 0);
@@ -127,7 +129,10 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
   float tmax = fminf(fminf(((dir.x > 0 ? S : 0.f) - org.x) / dir.x, ((dir.y > 0 ? S : 0.f) - org.y) / dir.y), ((dir.z > 0 ? S : 0.f) - org.z) / dir.z);
   tmin = fmaxf(tmin, a.near_plane / cam_dir.z);
   tmax = fminf(tmax, a.far_plane / cam_dir.z);
-  unsigned long long st1 = __builtin_amdgcn_s_memtime(), st2 = st1; int n_iter = 0, n_samp = 0;
+#ifdef KF_EXPERIMENTS
+  unsigned long long st1 = __builtin_amdgcn_s_memtime(), st2 = st1;
+#endif
+  int n_iter = 0, n_samp = 0;
   if (tmin < tmax) {
     // raySample :65-119
     const int R = v.res;
@@ -137,7 +142,7 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
     const int zs0 = v.bz0 * KF_BRICK, zs1 = v.bz1 * KF_BRICK;
     float t = tmin, t_prev = tmin;
     float last_sdf = 0.f; bool have_last = true;
-    const float mcell = (float)KF_MACRO * v.cell, inv_mcell = 1.f / mcell, meps = 1e-4f * mcell;
+    const float mcell = (float)KF_MACRO * v.cell, meps = 1e-4f * mcell;
     const float bcell = (float)KF_BRICK * v.cell, beps = 1e-3f * bcell;
     const float3 inv_dir = kf3(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
     const int nm = v.nm;
@@ -155,21 +160,21 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
     while (t < t_end) {
       ++n_iter;
       const float3 pos = kf_add(org, kf_scale(dir, t));
+      // the sample's own voxel -- tsdfvolume::getVoxel(world) tsdfVolume.h:81-97: nearest voxel, index clamped
+      int gx = kf_f2i(kf_div(pos.x * rf, rS)), gy = kf_f2i(kf_div(pos.y * rf, rS)), gz = kf_f2i(kf_div(pos.z * rf, rS));
+      gx = max(0, min(gx, R - 1)); gy = max(0, min(gy, R - 1)); gz = max(0, min(gz, R - 1));
       // level 1: a 32^3-voxel macro cell without any negative voxel -> none of the samples inside it can be the negative
-      // side of a crossing: walk to its far side.
+      // side of a crossing: walk to its far side.  The cell is the VOXEL's macro cell (g >> 5), like the brick level below:
+      // picking it from the position with a different rounding could disagree with the voxel index at a cell face and skip
+      // a sample whose voxel lies in the neighbouring (non-empty) cell.
       {
-        const int mx = max(0, min((int)floorf(pos.x * inv_mcell), nm - 1));
-        const int my = max(0, min((int)floorf(pos.y * inv_mcell), nm - 1));
-        const int mz = max(0, min((int)floorf(pos.z * inv_mcell), nm - 1));
+        const int mx = gx >> 5, my = gy >> 5, mz = gz >> 5;
         if (!rc_bit(s_macro, (unsigned)((mz * nm + my) * nm + mx))) {
           rc_skip_cell(pos, dir, inv_dir, (float)mx * mcell, (float)my * mcell, (float)mz * mcell, mcell, meps, a.inc, t_end, t, t_prev);
           have_last = false;
           continue;
         }
       }
-      // level 2: the sample's own voxel -- tsdfvolume::getVoxel(world) tsdfVolume.h:81-97: nearest voxel, index clamped
-      int gx = kf_f2i(kf_div(pos.x * rf, rS)), gy = kf_f2i(kf_div(pos.y * rf, rS)), gz = kf_f2i(kf_div(pos.z * rf, rS));
-      gx = max(0, min(gx, R - 1)); gy = max(0, min(gy, R - 1)); gz = max(0, min(gz, R - 1));
       // only samples whose voxel this context OWNS can be its crossing candidates (the whole volume on one GPU; with
       // z-slabs the neighbour's layers are stored as halo and serve the previous-sample / trilinear / gradient reads only)
       const bool owned = gz >= v.own_z0 && gz < v.own_z1;
@@ -202,11 +207,13 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
       last_sdf = sdf; have_last = true; t_prev = t;
       t += a.inc;
     }
+#ifdef KF_EXPERIMENTS
     st2 = __builtin_amdgcn_s_memtime();
+#endif
     // The crossing is evaluated HERE, after the march loop, not inside it: lanes of a wave meet their crossings at
     // different iterations, and inside the loop the 64-gather evaluation would run once per distinct iteration with a
     // handful of active lanes each time.  After the loop every lane that found a crossing evaluates together.
-    if (t_cross < __builtin_huge_valf() && a.exp_mode != 1) {
+    if (t_cross < __builtin_huge_valf() && KF_EXP_MODE(a) != 1) {
       const float3 pos = kf_add(org, kf_scale(dir, t_cross)), last_pos = kf_add(org, kf_scale(dir, t_cross_prev));
       float ftdt, ft; bool ok_cur, ok_last;
       kf_interpolate_sdf_pair(v, pos, last_pos, rS, rcell, ok_cur, ftdt, ok_last, ft);
@@ -222,11 +229,13 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
       }
     } else if (t_cross < __builtin_huge_valf()) out_v = make_float4(t_cross, 0.f, 0.f, 1.f);
   }
-  if (a.exp_mode == 3) {                                                // diagnostics: shader-clock ticks of the three phases, loop trips
+#ifdef KF_EXPERIMENTS
+  if (KF_EXP_MODE(a) == 3) {                                                // diagnostics: shader-clock ticks of the three phases, loop trips
     const unsigned long long st3 = __builtin_amdgcn_s_memtime();
     out_v = make_float4((float)(st1 - st0), (float)(st2 - st1), (float)(st3 - st2), (float)n_iter);
     out_n = make_float4((float)n_samp, 0.f, 0.f, 0.f);
   }
+#endif
   a.out_v[pix] = out_v; a.out_n[pix] = out_n;
   if (a.out_t) a.out_t[pix] = t_cross;
   if (a.has_color) a.out_rgb[pix] = out_c;
@@ -244,8 +253,8 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
   else a.pose = c->track->pose;
   a.out_v = out_v ? out_v : c->model_v[0]; a.out_n = out_n ? out_n : c->model_n[0]; a.out_rgb = c->raycast_rgb; a.out_t = out_t;
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
-  { static int em = -1; if (em < 0) { const char* e = getenv("KF_RAYCAST_EXP"); em = e ? atoi(e) : 0; } a.exp_mode = em; }
-  const size_t macro_bytes = (((size_t)c->vol.nm * c->vol.nm * c->vol.nm + 31) / 32) * 4, neg_bytes = kf_negbit_words(c->n_stored_bricks) * 4;
+  { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_RAYCAST_EXP"); a.exp_mode = em; }
+  const size_t macro_bytes = (((((size_t)c->vol.nm * c->vol.nm * c->vol.nm + 31) / 32) + 3) & ~(size_t)3) * 4, neg_bytes = kf_negbit_words(c->n_stored_bricks) * 4;
   a.neg_words = (macro_bytes + neg_bytes <= RAYCAST_LDS_BYTES) ? (int)(neg_bytes / 4) : 0;
   if (macro_bytes > RAYCAST_LDS_BYTES) return KF_ERR_STATE;
   dim3 grid(kf_div_up(c->cols, 32), kf_div_up(c->rows, 16));
@@ -267,7 +276,15 @@ extern "C" int kf_raycast_volume(kf_ctx* c, int has_color, const kf_mat44* trans
 extern "C" int kf_raycast_volume_slab(kf_ctx* c, int has_color, const kf_mat44* transform, const kf_raycast_params* rp,
                                       const kf_camera_params* cam, float near_plane, float far_plane,
                                       float* dev_t, float* dev_v, float* dev_n) {
-  if (!dev_t || !dev_v || !dev_n) return KF_ERR_ARG;
+  if (!c || !rp || !dev_t || !dev_v || !dev_n) return KF_ERR_ARG;
+  // The previous sample of the first owned one lies up to x = inc/cell layers outside the owned range and the trilinear +
+  // gradient taps around a vertex next to it reach ceil(x) + 2 layers: a thinner halo would silently lose crossings at the
+  // slab faces (those reads fail), so it is refused.  Layers clipped by the volume's own faces do not count.
+  {
+    const int need = (int)ceilf(rp->ray_increment / c->vol.cell) + 2;
+    const int lo = c->vol.own_z0 - c->vol.bz0 * KF_BRICK, hi = c->vol.bz1 * KF_BRICK - c->vol.own_z1;
+    if ((c->vol.own_z0 > 0 && lo < need) || (c->vol.own_z1 < c->vol.res && hi < need)) return KF_ERR_ARG;
+  }
   return raycast_launch(c, has_color, transform, rp, cam, near_plane, far_plane, dev_t, (float4*)dev_v, (float4*)dev_n);
 }
 

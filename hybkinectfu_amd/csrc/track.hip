@@ -352,7 +352,7 @@ __device__ __forceinline__ void store_partial(float acc[27], float* partials_out
 }
 
 // ---- ICP ------------------------------------------------------------------------------------------------------------
-// findCorrs (:17-60) + buildPointToPlaneSolverRows (:7-16), split so the 4 pixels of a lane overlap their memory round trips:
+// findCorrs (:17-60) + buildPointToPlaneSolverRows (:7-16), split so the ICP_PX pixels of a lane overlap their memory round trips:
 // stage A (icp_project) needs only the lane's own vertex/normal and yields the model-map index; stage B (icp_finish)
 // consumes the gathered model vertex/normal.
 __device__ __forceinline__ int icp_project(const TrackArgs& a, const float* cur, const float* linv, float4 iv, float4 in_,
@@ -377,7 +377,7 @@ __device__ __forceinline__ bool icp_finish(const TrackArgs& a, float4 vg, float4
   return true;
 }
 
-// 512 lanes x 4 pixels per workgroup: 150 / 38 / 10 workgroups at VGA level 0 / 1 / 2 (few partials to fold, no register spills).
+// 512 lanes x ICP_PX (3) pixels per workgroup: 200 / 50 / 13 workgroups at VGA level 0 / 1 / 2 (few partials to fold, no register spills).
 #define ICP_THREADS 512
 #define ICP_PX 3
 __global__ void __launch_bounds__(ICP_THREADS) k_icp_step(TrackArgs a) {
@@ -437,6 +437,7 @@ struct IcpLoopArgs {
   unsigned long long* slots;                     // KF_ICP_LOOP_STEPS x KF_ICP_LOOP_MAX_WG x 32 tagged partial sums, one array per step
   unsigned tag_base;                             // this launch's sequence number (host counter x 64); tag = tag_base + step
   KfTrackState* track;
+  unsigned* stall_word;                          // pinned host word: set when the loop gives up waiting, polled by the next kf_icp_track
   int exp_mode;                                  // diagnostics only (KF_ICP_EXP): 1 = skip the solve (timing), 7 = shader-clock stamps per phase
 };
 
@@ -445,7 +446,8 @@ struct IcpLoopArgs {
 // Partial sums of the persistent loop travel as 64-bit (value, tag) words: the tag is the launch's sequence number plus the
 // Gauss-Newton step, every step has its own slot array, and a word is published by ONE 8-byte write-through store -- so a
 // reader needs no barrier and no flag: it polls the words it is about to add until their tags are current.  The adds run
-// in the order of fold_partials (workgroup-major within a part, then the parts), so both launch forms give the same bits.
+// in a fixed order (workgroup-major within a part, then the parts): every workgroup of the loop arrives at the same bits.  The
+// per-step launch form (k_icp_step) deals pixels to workgroups differently, so the two forms agree to tolerance, not bitwise.
 __device__ __forceinline__ void fold_partials_tagged(const unsigned long long* slots, int n_wg, unsigned tag, float* s_tot, int* s_abort) {
   const int k = threadIdx.x & 31, part = threadIdx.x >> 5, parts = blockDim.x >> 5;
   float s = 0.f;
@@ -499,7 +501,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   a.dist_thres = L.dist_thres; a.sin_thres = L.sin_thres; a.dist_shake = L.dist_shake; a.angle_shake = L.angle_shake; a.sdf = 0;
   int step = 0, n_prev = 0, applied = 0;
   // diagnostic build path (KF_ICP_EXP=7): workgroup 0 accumulates shader-clock ticks per segment into track->reduced
-  const bool stamp = L.exp_mode == 7 && blockIdx.x == 0 && threadIdx.x == 0;
+  const bool stamp = KF_EXP_MODE(L) == 7 && blockIdx.x == 0 && threadIdx.x == 0;
   unsigned long long t_last = 0; float seg[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #define KF_STAMP(i) do { if (stamp) { unsigned long long t_now = __builtin_amdgcn_s_memtime(); seg[i] += (float)(t_now - t_last); t_last = t_now; } } while (0)
   if (stamp) t_last = __builtin_amdgcn_s_memtime();
@@ -526,9 +528,9 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
       KF_STAMP(0);
       if (step > 0) {
         fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort);
-        if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; } return; }
+        if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; __hip_atomic_store(L.stall_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } return; }
         KF_STAMP(1);
-        if (L.exp_mode == 1) { if (threadIdx.x == 0) s_code = STEP_APPLIED; __syncthreads(); } else     // timing only: skip the 6x6 solve
+        if (KF_EXP_MODE(L) == 1) { if (threadIdx.x == 0) s_code = STEP_APPLIED; __syncthreads(); } else     // timing only: skip the 6x6 solve
         apply_step(a, s_tot, s_cur, &s_code);
         if (s_code != STEP_APPLIED) {                                            // same verdict in every workgroup
           if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; }
@@ -592,10 +594,10 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   if (stamp) { for (int i = 0; i < 6; ++i) st->reduced[20 + i] = seg[i]; }
   // the last step's system, then commit _pose (ICP.cpp:84)
   fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort);
-  if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; } return; }
+  if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; __hip_atomic_store(L.stall_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } return; }
   apply_step(a, s_tot, s_cur, &s_code);
   if (blockIdx.x != 0) return;
-  if (threadIdx.x < 27 && L.exp_mode != 7) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
+  if (threadIdx.x < 27 && KF_EXP_MODE(L) != 7) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
   if (s_code != STEP_APPLIED) { if (threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; } return; }
   if (threadIdx.x < 16) st->pose[threadIdx.x] = s_cur[threadIdx.x];
   if (threadIdx.x == 0) { st->tracked = 1; st->iterations = applied + 1; }
@@ -781,9 +783,12 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   const int grid0 = icp_grid(c->cols * c->rows);
   static int persistent_env = -1;
   if (persistent_env < 0) { const char* e = getenv("KF_ICP_PERSISTENT"); persistent_env = e ? atoi(e) : 1; }
+  // a persistent loop of an EARLIER frame that gave up waiting (its workgroups were not co-resident: another process on the
+  // GPU) has set the pinned stall word by now -- no read-back of the verdict needed: from here on one launch per step
+  if (*(volatile unsigned*)((char*)c->host_pinned + KF_PINNED_STALL_WORD)) c->persistent_disabled = 1;
   if (persistent_env && !c->persistent_disabled && grid0 <= c->num_cus && grid0 <= KF_ICP_LOOP_MAX_WG && iters[0] + iters[1] + iters[2] <= KF_ICP_LOOP_STEPS &&
       kf_live_contexts(c->cfg.device) == 1) {
-    // every workgroup must be resident at once (software grid barrier): one 1024-lane workgroup per CU, grid0 <= #CUs
+    // every workgroup must be resident at once (they wait for each other's tagged partial sums): one 512-lane workgroup per CU, grid0 <= #CUs
     IcpLoopArgs L; memset(&L, 0, sizeof(L));
     for (int l = 0; l < c->levels; ++l) {
       L.new_v[l] = c->new_v[l]; L.new_n[l] = c->new_n[l]; L.model_v[l] = c->model_v[l]; L.model_n[l] = c->model_n[l];
@@ -793,7 +798,8 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
     L.dist_thres = icp->dist_thres; L.sin_thres = icp->norm_sin_thres; L.dist_shake = icp->dist_shake; L.angle_shake = icp->angle_shake;
     c->icp_loop_seq += 64u;                                  // tags of one launch never collide with an earlier launch's slots
     L.slots = c->icp_loop_slots; L.tag_base = c->icp_loop_seq; L.track = c->track;
-    { static int em = -1; if (em < 0) { const char* e = getenv("KF_ICP_EXP"); em = e ? atoi(e) : 0; } L.exp_mode = em; }
+    L.stall_word = (unsigned*)((char*)c->host_pinned + KF_PINNED_STALL_WORD);
+    { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_ICP_EXP"); L.exp_mode = em; }
     hipLaunchKernelGGL(k_icp_loop, dim3(grid0), dim3(ICP_THREADS), 0, c->stream, L);
     kf_evt_end(c, KF_STAGE_TRACK);
     return (int)hipGetLastError();

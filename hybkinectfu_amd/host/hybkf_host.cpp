@@ -398,7 +398,18 @@ unsigned MeshData::mergeCloseVertices(float thresh) {            // meshData.cpp
   for (auto& f : faces) f = lookup[f];
   vertices.swap(nv);
   if (has_col) colors.swap(nc);
+  removeDegeneratedFaces();                                      // meshData.cpp:281
   return cnt;
+}
+unsigned MeshData::removeDegeneratedFaces() {                    // meshData.cpp:289-310: a face that names a vertex twice (an edge the weld collapsed) goes
+  size_t w = 0;
+  for (size_t i = 0; i + 2 < faces.size(); i += 3) {
+    const unsigned a = faces[i], b = faces[i + 1], c = faces[i + 2];
+    if (a == b || a == c || b == c) continue;
+    faces[w] = a; faces[w + 1] = b; faces[w + 2] = c; w += 3;
+  }
+  faces.resize(w);
+  return (unsigned)(w / 3);
 }
 unsigned MeshData::removeDuplicateFaces() {                      // meshData.cpp:42-82: same index set in any order = duplicate, first kept
   struct Key { unsigned a, b, c; bool operator==(const Key& o) const { return a == o.a && b == o.b && c == o.c; } };
@@ -425,14 +436,16 @@ void MeshData::computeVertexNormals() {                          // meshData.h:7
   }
   for (size_t v = 0; v + 2 < normals.size(); v += 3) nrm(&normals[v]);
 }
-bool MeshData::saveToFile(const std::string& filename) const {  // MeshIO.cpp:492-662
+bool MeshData::saveToFile(const std::string& filename) const {  // MeshIO.h:50-76 (dispatch), MeshIO.cpp:490-662 (writers): same bytes as the reference's files
   const size_t nv = vertices.size() / 3, nf = faces.size() / 3;
-  const bool has_col = colors.size() == nv * 4, has_n = normals.size() == nv * 3;
-  std::string ext = filename.size() >= 4 ? filename.substr(filename.size() - 4) : "";
-  std::ofstream f(filename);
-  if (!f.is_open()) return false;
-  if (ext == ".obj") {                                           // MeshIO.cpp:609-662
-    f << "####\n#\n# OBJ file Generated by hybkinectfu_amd\n#\n####\n# Object " << filename << "\n#\n# Vertices: " << nv << "\n# Faces: " << nf << "\n#\n####\n";
+  if (nv == 0) return false;                                     // MeshIO.h:52 "empty mesh"
+  const bool has_col = colors.size() == nv * 4 && nv > 0, has_n = normals.size() == nv * 3 && nv > 0;
+  std::string ext = filename.substr(filename.find_last_of(".") + 1);      // MeshIO.h:20-26: text after the last '.', case-insensitive
+  for (auto& ch : ext) ch = (char)tolower(ch);
+  if (ext == "obj") {                                            // MeshIO.cpp:609-662
+    std::ofstream f(filename);
+    if (!f.is_open()) return false;
+    f << "####\n#\n# OBJ file Generated by MLIB\n#\n####\n# Object " << filename << "\n#\n# Vertices: " << nv << "\n# Faces: " << nf << "\n#\n####\n";
     for (size_t i = 0; i < nv; ++i) {
       f << "v " << vertices[3 * i] << " " << vertices[3 * i + 1] << " " << vertices[3 * i + 2];
       if (has_col) f << " " << colors[4 * i] << " " << colors[4 * i + 1] << " " << colors[4 * i + 2];
@@ -440,24 +453,45 @@ bool MeshData::saveToFile(const std::string& filename) const {  // MeshIO.cpp:49
     }
     if (has_n) for (size_t i = 0; i < nv; ++i) f << "vn " << normals[3 * i] << " " << normals[3 * i + 1] << " " << normals[3 * i + 2] << "\n";
     for (size_t i = 0; i < nf; ++i) f << "f " << faces[3 * i] + 1 << " " << faces[3 * i + 1] + 1 << " " << faces[3 * i + 2] + 1 << " \n";
-  } else if (ext == ".ply") {
-    f << "ply\nformat ascii 1.0\nelement vertex " << nv << "\nproperty float x\nproperty float y\nproperty float z\n";
+    return f.good();
+  }
+  if (ext == "ply") {                                            // MeshIO.cpp:490-571: binary little-endian, interleaved vertex records
+    std::ofstream f(filename, std::ios::binary);
+    if (!f.is_open()) return false;
+    f << "ply\nformat binary_little_endian 1.0\ncomment MLIB generated\nelement vertex " << nv << "\nproperty float x\nproperty float y\nproperty float z\n";
     if (has_n) f << "property float nx\nproperty float ny\nproperty float nz\n";
     if (has_col) f << "property uchar red\nproperty uchar green\nproperty uchar blue\nproperty uchar alpha\n";
     f << "element face " << nf << "\nproperty list uchar int vertex_indices\nend_header\n";
+    std::vector<unsigned char> rec;
+    rec.reserve(nv * 28);
+    for (size_t i = 0; i < nv; ++i) {
+      const unsigned char* p = (const unsigned char*)&vertices[3 * i];
+      rec.insert(rec.end(), p, p + 12);
+      if (has_n) { const unsigned char* q = (const unsigned char*)&normals[3 * i]; rec.insert(rec.end(), q, q + 12); }
+      if (has_col) {
+        // :547-548: uchar3(r*255, g*255, b*255) copied as FOUR bytes -- the reference's 4th (alpha) byte is whatever follows the
+        // 3-byte local on its stack; we write 255 (opaque), the only byte of the file that is not defined by the reference
+        rec.push_back((unsigned char)(colors[4 * i] * 255)); rec.push_back((unsigned char)(colors[4 * i + 1] * 255)); rec.push_back((unsigned char)(colors[4 * i + 2] * 255));
+        rec.push_back(255);
+      }
+    }
+    f.write((const char*)rec.data(), (std::streamsize)rec.size());
+    for (size_t i = 0; i < nf; ++i) { const unsigned char three = 3; f.write((const char*)&three, 1); f.write((const char*)&faces[3 * i], 12); }
+    return f.good();
+  }
+  if (ext == "off") {                                            // MeshIO.cpp:574-606: "COFF", integer colours with a trailing blank
+    std::ofstream f(filename);
+    if (!f.is_open()) return false;
+    f << "COFF\n" << nv << " " << nf << " " << 0 << "\n";
     for (size_t i = 0; i < nv; ++i) {
       f << vertices[3 * i] << " " << vertices[3 * i + 1] << " " << vertices[3 * i + 2];
-      if (has_n) f << " " << normals[3 * i] << " " << normals[3 * i + 1] << " " << normals[3 * i + 2];
-      if (has_col) for (int k = 0; k < 4; ++k) f << " " << (int)(colors[4 * i + k] * 255.f);
+      if (has_col) f << " " << (unsigned)(colors[4 * i] * 255) << " " << (unsigned)(colors[4 * i + 1] * 255) << " " << (unsigned)(colors[4 * i + 2] * 255) << " " << (unsigned)(colors[4 * i + 3] * 255) << " ";
       f << "\n";
     }
-    for (size_t i = 0; i < nf; ++i) f << "3 " << faces[3 * i] << " " << faces[3 * i + 1] << " " << faces[3 * i + 2] << "\n";
-  } else if (ext == ".off") {
-    f << "OFF\n" << nv << " " << nf << " 0\n";
-    for (size_t i = 0; i < nv; ++i) f << vertices[3 * i] << " " << vertices[3 * i + 1] << " " << vertices[3 * i + 2] << "\n";
-    for (size_t i = 0; i < nf; ++i) f << "3 " << faces[3 * i] << " " << faces[3 * i + 1] << " " << faces[3 * i + 2] << "\n";
-  } else return false;
-  return f.good();
+    for (size_t i = 0; i < nf; ++i) f << 3 << " " << faces[3 * i] << " " << faces[3 * i + 1] << " " << faces[3 * i + 2] << "\n";
+    return f.good();
+  }
+  return false;                                                  // MeshIO.h:72 "unknown file format"
 }
 
 // ---- MeshGeneratorMarchingcube (src/MeshGeneratorMarchingcube.cpp) -------------------------------------------------------------------------
@@ -477,7 +511,10 @@ bool MeshGeneratorMarchingcube::copyTrianglesToCPU() {          // :30-60
   if (n == 0) return false;
   std::vector<kf_triangle> tris(n);
   if (dm->check(kf_read_triangles(dm->ctx(), tris.data(), 0, n))) return false;
-  const bool col = AppParams::instance()->_switch_params.useRGBData;
+  setTriangles(tris.data(), n, AppParams::instance()->_switch_params.useRGBData);
+  return true;
+}
+void MeshGeneratorMarchingcube::setTriangles(const kf_triangle* tris, unsigned n, bool col) {   // :39-58, the copy loop
   _meshes = MeshData();
   _meshes.vertices.resize((size_t)n * 9);
   if (col) _meshes.colors.resize((size_t)n * 12);
@@ -488,16 +525,20 @@ bool MeshGeneratorMarchingcube::copyTrianglesToCPU() {          // :30-60
       if (col) { float* c = &_meshes.colors[(size_t)(3 * i + k) * 4]; c[0] = v[k]->color[2]; c[1] = v[k]->color[1]; c[2] = v[k]->color[0]; c[3] = 1.0f; }   // :53 x<->z swap
     }
   }
-  return true;
 }
-bool MeshGeneratorMarchingcube::saveMesh(const std::string& filename) {   // :61-96
-  if (!copyTrianglesToCPU()) return false;
+void MeshGeneratorMarchingcube::weldMesh() {                    // :69-84
+  // The reference sizes its index buffer by the VERTEX count (:70) and fills one face per triangle: the surplus two thirds are
+  // (0,0,0) faces, which mergeCloseVertices' closing removeDegeneratedFaces drops again -- same result as one face per triangle.
   const size_t nv = _meshes.vertices.size() / 3;
   _meshes.faces.resize(nv);
   for (size_t i = 0; i < nv; ++i) _meshes.faces[i] = (unsigned)i;   // index buffer of the triangle soup
   _meshes.mergeCloseVertices(0.0001f);
   _meshes.removeDuplicateFaces();
   _meshes.computeVertexNormals();
+}
+bool MeshGeneratorMarchingcube::saveMesh(const std::string& filename) {   // :61-96
+  if (!copyTrianglesToCPU()) return false;
+  weldMesh();
   // the reference returns 0 here even on success (:95); we report whether the file was written
   return _meshes.saveToFile(filename);
 }

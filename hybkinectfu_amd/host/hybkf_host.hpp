@@ -231,7 +231,8 @@ struct MeshData {
   std::vector<float> colors;                                 // rgba, empty when the volume has no colour
   std::vector<float> normals;                                // xyz
   std::vector<unsigned> faces;                               // 3 indices per face
-  unsigned mergeCloseVertices(float thresh);                 // meshData.cpp:198-283, approx = true path (hash grid, first come wins)
+  unsigned mergeCloseVertices(float thresh);                 // meshData.cpp:198-283, approx = true path (hash grid, first come wins); ends with removeDegeneratedFaces
+  unsigned removeDegeneratedFaces();                         // meshData.cpp:289-310: faces with a repeated index are dropped
   unsigned removeDuplicateFaces();                           // meshData.cpp:42-82
   void computeVertexNormals();                               // meshData.h:713-736
   bool saveToFile(const std::string& filename) const;        // by extension: .obj / .ply / .off (MeshIO.cpp:492-662)

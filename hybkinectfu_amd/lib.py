@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libhybkf.so")
+# KF_LIB: tools/ may point at the experiments variant (libhybkf_exp.so, `make -C csrc experiments`); default = the product library
+LIB_PATH = os.environ.get("KF_LIB") or os.path.join(PKG_DIR, "libhybkf.so")
 
 
 class CameraParams(C.Structure):

@@ -54,8 +54,6 @@ class SingleGpuPipeline:
 # ---------------------------------------------------------------------------------------------------------------------------
 # z-slab partitioning over the GPUs of one node: one process per GPU, torch.distributed over RCCL.
 # ---------------------------------------------------------------------------------------------------------------------------
-SLAB_HALO = 16      # voxel layers stored AND integrated on each side of the owned range: covers the previous ray sample
-                    # (ray increment <= ~6 voxels at 1024^3 @ 6 m), the 2x2x2 trilinear taps and the +-1-cell gradient taps
 
 
 def slab_ranges(res, world):
@@ -88,12 +86,59 @@ def merge_candidates(t, v, n, all_reduce_min, all_reduce_sum_i32):
     return vi.view(torch.float32), ni.view(torch.float32)
 
 
+class SlabExchange:
+    """The collective sequence that merges one frame's per-slab raycast candidates (first crossing along each ray wins):
+
+        tmin <- t;  MIN all-reduce(tmin), asynchronous  ->  [overlap(): independent work]  ->  wait
+        pack(t, tmin, v, n -> packed)          losers zeroed, winner's vertex xyz + normal xyz: 24 B per pixel
+        integer SUM all-reduce(packed bits)    exactly one rank contributes non-zero bits per pixel; integer sums keep -0.0
+        unpack(packed)                         -> model maps of every rank
+
+    `pack` / `unpack` are the device launches (kf_slab_pack_candidates / kf_set_model_maps_packed) in SlabPipeline; the
+    CPU-only tests and `bench.py --collective-selftest` pass plain-torch restatements of the two kernels and a gloo group, so
+    the SAME sequence of collectives runs at world_size 2 without a GPU.
+    """
+
+    def __init__(self, rows, cols, device, dist, pack, unpack):
+        import torch
+        self.dist, self.pack, self.unpack = dist, pack, unpack
+        self.t = torch.empty((rows, cols), dtype=torch.float32, device=device)
+        self.tmin = torch.empty_like(self.t)
+        self.vn = torch.empty((2, rows, cols, 4), dtype=torch.float32, device=device)       # candidates: vertex map, normal map
+        self.v, self.n = self.vn[0], self.vn[1]
+        # what actually crosses xGMI: vertex xyz + normal xyz of the winner, 24 bytes per pixel (7.4 MB at VGA)
+        self.packed = torch.empty((rows, cols, 6), dtype=torch.float32, device=device)
+        self.packed_bits = self.packed.view(torch.int32)
+
+    def merge(self, overlap=None):
+        dist = self.dist
+        self.tmin.copy_(self.t)
+        pending = dist.all_reduce(self.tmin, op=dist.ReduceOp.MIN, async_op=True)
+        if overlap is not None:
+            overlap()             # runs while the collective is in flight (RCCL's own stream until wait() joins it)
+        pending.wait()
+        self.pack(self.t, self.tmin, self.v, self.n, self.packed)
+        dist.all_reduce(self.packed_bits, op=dist.ReduceOp.SUM)
+        self.unpack(self.packed)
+
+
+def slab_halo_layers(res, size, ray_increment):
+    """Voxel layers a slab stores AND integrates beyond its owned range, per side: ceil(inc/voxel) + 2,
+    rounded up to whole 8-layer bricks.  With x = inc/voxel: the previous ray sample lies at most x layers outside the owned
+    range (raycast.hip reads it from the halo), its trilinear taps reach floor(-x - 0.5) and the gradient taps around a vertex
+    next to it floor(-x - 1.5) >= -(ceil(x) + 2).  kf_raycast_volume_slab refuses a context whose halo is thinner."""
+    import math
+    need = int(math.ceil(ray_increment * res / size)) + 2
+    return ((need + 7) // 8) * 8
+
+
 class SlabPipeline:
     """One rank of the z-slab partitioned pipeline.
 
     Replicated per rank (cheap, and bitwise identical everywhere): preprocess, pyramids, the whole ICP loop.
-    Partitioned: TSDF integrate (own slab + halo, no communication) and raycast (own samples only), followed by one
-    MIN all-reduce of the crossing parameter and one integer SUM all-reduce of the winning vertex/normal maps.
+    Partitioned: TSDF integrate (own slab + halo, no communication: the halo layers are RE-INTEGRATED by both neighbours
+    instead of exchanged -- integration is a pure function of voxel, depth and pose) and raycast (own samples only), followed
+    by SlabExchange's two all-reduces.
     """
 
     def __init__(self, kcam, res, size, wl=None, rank=0, world=1, device=0, max_triangles=0, icp_mode="replicated"):
@@ -107,8 +152,9 @@ class SlabPipeline:
         self.integ_dist = wl.get("integ_dist", P["integrate_depth_trunc"])
         self.inc = P["raycast_increment_factor"] * P["integrate_sdf_trunc"]
         self.slab = slab_ranges(res, world)[rank]
+        self.halo = slab_halo_layers(res, size, self.inc)
         self.ctx = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=max_triangles, device=device,
-                             slab=self.slab, halo=SLAB_HALO)
+                             slab=self.slab, halo=self.halo)
         self.ctx.set_pose(S.pose0(size))
         dev = torch.device("cuda", device)
         # ONE stream orders the library's kernels, torch's elementwise ops and the RCCL collectives (which synchronise with the
@@ -117,15 +163,10 @@ class SlabPipeline:
         self.stream = torch.cuda.Stream(device=dev)
         assert self.stream.cuda_stream != 0
         self.ctx.set_stream(self.stream.cuda_stream)
-        self.t = torch.empty((kcam.rows, kcam.cols), dtype=torch.float32, device=dev)
-        self.tmin = torch.empty_like(self.t)
-        # vertex and normal candidates share one buffer, so their merge is ONE integer SUM all-reduce (9.8 MB at VGA)
-        self.vn = torch.empty((2, kcam.rows, kcam.cols, 4), dtype=torch.float32, device=dev)
-        self.v, self.n = self.vn[0], self.vn[1]
-        self.vn_bits = self.vn.view(torch.int32)
-        # what actually crosses xGMI: vertex xyz + normal xyz of the winner, 24 bytes per pixel (7.4 MB at VGA)
-        self.packed = torch.empty((kcam.rows, kcam.cols, 6), dtype=torch.float32, device=dev)
-        self.packed_bits = self.packed.view(torch.int32)
+        c = self.ctx
+        self.ex = SlabExchange(kcam.rows, kcam.cols, dev, dist,
+                               pack=lambda t, tmin, v, n, packed: c.slab_pack_candidates(t.data_ptr(), tmin.data_ptr(), v.data_ptr(), n.data_ptr(), packed.data_ptr()),
+                               unpack=lambda packed: c.set_model_maps_packed(packed.data_ptr()))
         self.sums = torch.zeros(32, dtype=torch.float32, device=dev)
         self._preprocessed = None           # device pointer of a frame whose preprocess was enqueued during the previous frame's merge
 
@@ -133,11 +174,15 @@ class SlabPipeline:
         with self.torch.cuda.stream(self.stream):
             self._process_frame_device(dev_mm_ptr, frame_id, next_mm_ptr)
 
+    def _preprocess(self, dev_mm_ptr):
+        c = self.ctx
+        c.set_depth_mm_device(dev_mm_ptr)
+        c.preprocess(P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
+
     def _process_frame_device(self, dev_mm_ptr, frame_id, next_mm_ptr):
-        c, dist = self.ctx, self.dist
+        c, dist, ex = self.ctx, self.dist, self.ex
         if self._preprocessed != dev_mm_ptr:                              # not done ahead of time by the previous call (see below)
-            c.set_depth_mm_device(dev_mm_ptr)
-            c.preprocess(P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
+            self._preprocess(dev_mm_ptr)
         self._preprocessed = None
         if self.icp_mode == "allreduce":
             c.icp_partition_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"],
@@ -145,21 +190,15 @@ class SlabPipeline:
         else:
             c.icp_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
         c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist)
-        c.raycast_slab(None, self.inc, P["depth_trunc_min"], self.trunc_max, self.t.data_ptr(), self.v.data_ptr(), self.n.data_ptr())
-        # first crossing along each ray wins (merge_candidates above is the same rule in plain torch, used by the CPU tests):
-        # MIN all-reduce of t, mask the losers and pack xyz + xyz on the device, ONE integer SUM all-reduce, unpack into the maps
-        self.tmin.copy_(self.t)
-        pending = dist.all_reduce(self.tmin, op=dist.ReduceOp.MIN, async_op=True)
-        if next_mm_ptr is not None:
-            # the collective runs on RCCL's own stream until wait() joins it: the next frame's preprocess -- every reader of this
-            # frame's maps is already behind us in the stream -- fills that time instead of the start of the next frame
-            c.set_depth_mm_device(next_mm_ptr)
-            c.preprocess(P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
-            self._preprocessed = next_mm_ptr
-        pending.wait()
-        c.slab_pack_candidates(self.t.data_ptr(), self.tmin.data_ptr(), self.v.data_ptr(), self.n.data_ptr(), self.packed.data_ptr())
-        dist.all_reduce(self.packed_bits, op=dist.ReduceOp.SUM)
-        c.set_model_maps_packed(self.packed.data_ptr())
+        c.raycast_slab(None, self.inc, P["depth_trunc_min"], self.trunc_max, ex.t.data_ptr(), ex.v.data_ptr(), ex.n.data_ptr())
+
+        def overlap():
+            # the MIN all-reduce runs on RCCL's own stream until wait() joins it: the next frame's preprocess -- every reader of
+            # this frame's maps is already behind us in the stream -- fills that time instead of the start of the next frame
+            if next_mm_ptr is not None:
+                self._preprocess(next_mm_ptr)
+                self._preprocessed = next_mm_ptr
+        ex.merge(overlap)
 
     def sync(self):
         self.ctx.sync()

@@ -21,7 +21,7 @@ def test_slabs_equal_whole_volume(world):
     trunc = 5 * size / res
     inc = 0.7 * trunc
     whole = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=600000)
-    slabs = [K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=600000, slab=r, halo=PL.SLAB_HALO)
+    slabs = [K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=600000, slab=r, halo=PL.slab_halo_layers(res, size, inc))
              for r in PL.slab_ranges(res, world)]
     dev = torch.device("cuda", 0)
     bufs = [(torch.empty((cam[1], cam[0]), dtype=torch.float32, device=dev), torch.empty((cam[1], cam[0], 4), dtype=torch.float32, device=dev),
@@ -192,3 +192,59 @@ def test_slab_pipeline_over_rccl_matches_single_gpu_pipeline():
         assert np.array_equal(outs[0][2][0], outs[1][2][0]) and np.array_equal(outs[0][2][1], outs[1][2][1])
     finally:
         dist.destroy_process_group()
+
+
+def test_pack_unpack_kernels_equal_torch_restatement():
+    """k_slab_pack / k_slab_unpack (what SlabPipeline launches between its two all-reduces) == tests/slab_cpu_ops.py, the
+    restatement the CPU-only world-2 tests run in their place -- bit for bit, for every rank's view of a synthetic frame."""
+    import slab_cpu_ops as ops
+    cam = (64, 48, 31.5, 23.5, 52.5, 52.5)
+    ctx = K.Context(K.camera(*cam), 32, 3.0, levels=3)
+    world = 3
+    total = torch.zeros((48, 64, 6), dtype=torch.int32)
+    for rank in range(world):
+        t, v, n, want_v, want_n = ops.synthetic_candidates(48, 64, rank, world, seed=11)
+        ts = torch.stack([ops.synthetic_candidates(48, 64, r, world, seed=11)[0] for r in range(world)])
+        tmin = ts.min(dim=0).values
+        want = torch.empty((48, 64, 6), dtype=torch.float32)
+        ops.pack(t, tmin, v, n, want)
+        td, tmd, vd, nd = t.cuda(), tmin.cuda(), v.cuda(), n.cuda()
+        pd = torch.full((48, 64, 6), 9.0, dtype=torch.float32, device="cuda")
+        ctx.slab_pack_candidates(td.data_ptr(), tmd.data_ptr(), vd.data_ptr(), nd.data_ptr(), pd.data_ptr())
+        ctx.sync()
+        assert torch.equal(pd.cpu().view(torch.int32), want.view(torch.int32))
+        total += want.view(torch.int32)
+    merged = total.view(torch.float32).contiguous()
+    md = merged.cuda()
+    ctx.set_model_maps_packed(md.data_ptr())
+    ctx.sync()
+    uv, un = ops.unpack(merged)
+    assert np.array_equal(ctx.download_map(K.MAP_MODEL_VERTICES).view(np.uint32), uv.numpy().view(np.uint32))
+    assert np.array_equal(ctx.download_map(K.MAP_MODEL_NORMALS).view(np.uint32), un.numpy().view(np.uint32))
+    assert torch.equal(uv.view(torch.int32), want_v.view(torch.int32)) and torch.equal(un.view(torch.int32), want_n.view(torch.int32))
+    ctx.close()
+
+
+def test_slab_raycast_refuses_thin_halo():
+    """A halo thinner than ceil(inc/voxel)+2 layers would silently lose crossings at the slab faces: KF_ERR_ARG instead."""
+    cam = (64, 48, 31.5, 23.5, 52.5, 52.5)
+    res, size = 128, 3.0
+    dev = torch.device("cuda", 0)
+    t = torch.empty((48, 64), dtype=torch.float32, device=dev)
+    v = torch.empty((48, 64, 4), dtype=torch.float32, device=dev)
+    n = torch.empty_like(v)
+    inc = 10.5 * size / res                                        # 10.5 voxels per step: needs 11 + 2 = 13 layers
+    assert PL.slab_halo_layers(res, size, inc) == 16
+    thin = K.Context(K.camera(*cam), res, size, levels=3, slab=(32, 64), halo=8)
+    with pytest.raises(K.KfError):
+        thin.raycast_slab(S.pose0(size), inc, 0.3, 4.0, t.data_ptr(), v.data_ptr(), n.data_ptr())
+    thin.close()
+    ok = K.Context(K.camera(*cam), res, size, levels=3, slab=(32, 64), halo=16)
+    ok.raycast_slab(S.pose0(size), inc, 0.3, 4.0, t.data_ptr(), v.data_ptr(), n.data_ptr())
+    ok.sync()
+    ok.close()
+    # a slab touching the volume's own face needs no halo there
+    edge = K.Context(K.camera(*cam), res, size, levels=3, slab=(0, 64), halo=16)
+    edge.raycast_slab(S.pose0(size), inc, 0.3, 4.0, t.data_ptr(), v.data_ptr(), n.data_ptr())
+    edge.sync()
+    edge.close()

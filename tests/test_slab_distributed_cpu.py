@@ -61,3 +61,81 @@ def test_merge_candidates_gloo_world2(tmp_path):
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() == "ok"
+
+
+def _exchange_worker(rank, world, port, out_dir):
+    """SlabExchange (the sequence SlabPipeline runs per frame) over gloo, with the torch restatements of the two kernels."""
+    import slab_cpu_ops as ops
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows, cols = 30, 44
+    model = {}
+    ex = PL.SlabExchange(rows, cols, torch.device("cpu"), dist, pack=ops.pack,
+                         unpack=lambda packed: model.update(zip("vn", ops.unpack(packed))))
+    ok = True
+    for frame in range(4):
+        t, v, n, want_v, want_n = ops.synthetic_candidates(rows, cols, rank, world, seed=7 + frame)
+        ex.t.copy_(t); ex.v.copy_(v); ex.n.copy_(n)
+        calls = []
+        ex.merge(lambda: calls.append(1))
+        ok = ok and calls == [1]
+        ok = ok and torch.equal(model["v"].view(torch.int32), want_v.view(torch.int32))
+        ok = ok and torch.equal(model["n"].view(torch.int32), want_n.view(torch.int32))
+        # the same rule through the unpacked reference merge
+        mv, mn = PL.merge_candidates(t, v, n, lambda x: dist.all_reduce(x, op=dist.ReduceOp.MIN), lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM))
+        ok = ok and torch.equal(mv.view(torch.int32), want_v.view(torch.int32)) and torch.equal(mn.view(torch.int32), want_n.view(torch.int32))
+    open(os.path.join(out_dir, "rank%d.txt" % rank), "w").write("ok" if ok else "mismatch")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_exchange_sequence_gloo(tmp_path, world):
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_exchange_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() == "ok"
+
+
+def test_bench_launcher_starts_ranks_itself():
+    """`python bench.py --gpus 2` with NO WORLD_SIZE/RANK in the environment: the parent (which loads neither torch.cuda nor
+    the library) must start two rank processes itself; they rendezvous over gloo, run the pipeline's collective sequence and
+    rank 0 prints exactly one JSON line reporting the world size it saw."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--collective-selftest"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    assert lines[0]["world_size"] == 2 and lines[0]["n_gpus"] == 2 and lines[0]["ok"] is True
+
+
+def test_bench_refuses_mismatched_world():
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--collective-selftest"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_bench_parent_is_gpu_free():
+    """The launching parent must not have loaded the HIP library or touched torch.cuda before it starts the ranks."""
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    head = src[:src.index("def main():")]
+    body = src[src.index("def main():"):]
+    launch_at = body.index("launch_ranks(args.gpus")
+    assert "import torch" not in body[:launch_at] and "lib as K" not in body[:launch_at]
+    # module level: only numpy-side helpers are imported
+    top = head[:head.index("def workload")]
+    assert "import torch" not in top and "lib as K" not in top
+
+
+def test_halo_follows_ray_increment():
+    # C4: inc 0.035 m = 5.97 voxels -> 6 + 2 = 8 layers; 2048^3 @ 4 m: 17.9 voxels -> 20 -> 24 layers (16 would lose crossings)
+    assert PL.slab_halo_layers(1024, 6.0, 0.035) == 8
+    assert PL.slab_halo_layers(2048, 4.0, 0.035) == 24
+    assert PL.slab_halo_layers(512, 4.0, 0.035) == 8
+    assert PL.slab_halo_layers(2048, 8.0, 0.035) == 16

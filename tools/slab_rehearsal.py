@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Rehearsal of the N-rank z-slab pipeline on a box with ONE GPU: `python tools/slab_rehearsal.py [--ranks 2]`.
+
+The parent touches no GPU; it starts N rank processes (torch.distributed.run).  The ranks share GPU 0 and form a gloo group
+(RCCL refuses two ranks on one device), run SlabPipeline -- real kernels, real collectives, the launcher path bench.py uses --
+for a few frames, and every rank compares against SingleGpuPipeline run in the same process: tracked poses and merged model
+maps bit for bit, its owned volume layers bit for bit.  Prints `REHEARSAL OK ranks=N` from rank 0 on success."""
+import argparse
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def worker(a):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from hybkinectfu_amd import lib as K
+    from hybkinectfu_amd import pipeline as PL
+    from hybkinectfu_amd import scene as S
+    P = S.STOCK
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    res, size, cam = a.res, a.size, S.vga_camera()
+    wl = dict(trunc_max=P["depth_trunc_max"], integ_dist=P["integrate_depth_trunc"])
+    n = a.frames
+    frames = np.stack([S.render_depth_mm(S.trajectory_pose(k, size), cam, size) for k in range(n)])
+    dev = torch.from_numpy(frames.astype(np.int16)).cuda()
+    fb = cam[0] * cam[1] * 2
+    outs = []
+    for cls in (PL.SingleGpuPipeline, PL.SlabPipeline):
+        pipe = cls(K.camera(*cam), res, size, wl) if cls is PL.SingleGpuPipeline else cls(K.camera(*cam), res, size, wl, rank=rank, world=world)
+        poses = []
+        for k in range(n):
+            nxt = dev.data_ptr() + (k + 1) * fb if (k % 2 == 0 and k + 1 < n) else None
+            pipe.process_frame_device(dev.data_ptr() + k * fb, k, nxt)
+            ok, pose, _, _ = pipe.track_result()
+            assert ok, "rank %d lost frame %d" % (rank, k)
+            poses.append(pose.copy())
+        pipe.sync()
+        maps = [pipe.ctx.download_map(m) for m in (K.MAP_MODEL_VERTICES, K.MAP_MODEL_NORMALS)]
+        z0, z1 = pipe.ctx.owned
+        vol = pipe.ctx.download_volume(z0, z1)
+        outs.append((poses, maps, vol, (z0, z1), pipe.stats()["updated_total"]))
+        pipe.close()
+    (p1, m1, v1, _, _), (p2, m2, v2, (z0, z1), upd) = outs
+    ok = all(np.array_equal(a_, b_) for a_, b_ in zip(p1, p2))
+    ok = ok and all(np.array_equal(a_.view(np.uint32), b_.view(np.uint32)) for a_, b_ in zip(m1, m2))
+    ok = ok and np.array_equal(v1[0][z0:z1].view(np.uint32), v2[0].view(np.uint32)) and np.array_equal(v1[1][z0:z1], v2[1])
+    valid = int((m2[0][..., 3] != 0).sum())
+    flag = torch.tensor([1 if ok else 0, valid], dtype=torch.int64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    print("rank %d: slab z[%d,%d) poses/maps/volume %s, %d valid model pixels, %d voxel updates" % (rank, z0, z1, "bit-exact" if ok else "MISMATCH", valid, upd), flush=True)
+    if rank == 0:
+        print(("REHEARSAL OK" if flag[0].item() == 1 and flag[1].item() > 10000 else "REHEARSAL FAILED") + " ranks=%d res=%d frames=%d" % (world, res, n), flush=True)
+    dist.destroy_process_group()
+    return 0 if flag[0].item() == 1 else 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ranks", type=int, default=2)
+    ap.add_argument("--res", type=int, default=384)
+    ap.add_argument("--size", type=float, default=3.0)
+    ap.add_argument("--frames", type=int, default=6)
+    a = ap.parse_args()
+    if "WORLD_SIZE" in os.environ:
+        sys.exit(worker(a))
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.ranks),
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:], env=env))
+
+
+if __name__ == "__main__":
+    main()
