@@ -93,6 +93,33 @@ int hkf_app_save_mesh(const char* filename, unsigned* n_vertices, unsigned* n_fa
   return ok ? 1 : 0;
 }
 
+// ---- GPU-free mesh post-processing on a caller-supplied triangle soup (kf_triangle layout) ---------------------------------------
+static MeshGeneratorMarchingcube* g_soup = nullptr;
+int hkf_mesh_from_soup(const void* triangles, unsigned n, int with_color, unsigned* n_vertices, unsigned* n_faces) {
+  delete g_soup; g_soup = new MeshGeneratorMarchingcube();
+  g_soup->setTriangles((const kf_triangle*)triangles, n, with_color != 0);
+  g_soup->weldMesh();
+  if (n_vertices) *n_vertices = (unsigned)(g_soup->mesh().vertices.size() / 3);
+  if (n_faces) *n_faces = (unsigned)(g_soup->mesh().faces.size() / 3);
+  return 0;
+}
+// which: 0 = the soup mesh (hkf_mesh_from_soup), 1 = the application's mesh (after hkf_app_save_mesh)
+static const MeshData* mesh_of(int which) { return which == 0 ? (g_soup ? &g_soup->mesh() : nullptr) : (g_mesh ? &g_mesh->mesh() : nullptr); }
+int hkf_mesh_sizes(int which, unsigned* n_vertices, unsigned* n_faces, unsigned* n_colors) {
+  const MeshData* m = mesh_of(which); if (!m) return -1;
+  *n_vertices = (unsigned)(m->vertices.size() / 3); *n_faces = (unsigned)(m->faces.size() / 3); *n_colors = (unsigned)(m->colors.size() / 4);
+  return 0;
+}
+int hkf_mesh_read(int which, float* vertices, float* normals, float* colors, unsigned* faces) {
+  const MeshData* m = mesh_of(which); if (!m) return -1;
+  if (vertices) memcpy(vertices, m->vertices.data(), m->vertices.size() * 4);
+  if (normals) memcpy(normals, m->normals.data(), m->normals.size() * 4);
+  if (colors) memcpy(colors, m->colors.data(), m->colors.size() * 4);
+  if (faces) memcpy(faces, m->faces.data(), m->faces.size() * 4);
+  return 0;
+}
+int hkf_mesh_save(int which, const char* filename) { const MeshData* m = mesh_of(which); return m && m->saveToFile(filename) ? 1 : 0; }
+
 // ---- GPU-free entry points of the dataset / trajectory code (CPU tests) ---------------------------------------------------------
 // reads frames [0, n) of a TUM directory into caller buffers: depth n x rows x cols u16 mm, bgr n x rows x cols x 3 (may be null)
 int hkf_dataset_read(const char* dir, unsigned cols, unsigned rows, int with_color, int n, uint16_t* depth_mm, uint8_t* bgr,

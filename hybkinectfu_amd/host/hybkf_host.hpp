@@ -251,6 +251,10 @@ public:
   bool saveMesh(const std::string& filename) override;
   unsigned triangleCount();
   const MeshData& mesh() const { return _meshes; }
+  // the two halves of copyTrianglesToCPU + saveMesh that need no device: usable on any triangle soup (CPU tests pin them
+  // against the reference's own ml::MeshData, tests/golden/mesh_*.npz)
+  void setTriangles(const kf_triangle* tris, unsigned n, bool with_color);   // :39-58
+  void weldMesh();                                                           // :69-84 index buffer, weld, dedupe, normals
 protected:
   bool copyTrianglesToCPU();
   MeshData _meshes;

@@ -139,3 +139,36 @@ def table_nearest(path, header_lines, targets):
     if n < 0:
         raise K.KfError("cannot read " + path)
     return out
+
+
+# ---- mesh post-processing (MeshGeneratorMarchingcube::saveMesh's weld / dedupe / normals / writers) ------------------------------
+def _mesh_read(which):
+    h = load()
+    nv, nf, nc = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    if h.hkf_mesh_sizes(which, C.byref(nv), C.byref(nf), C.byref(nc)) != 0:
+        raise K.KfError("no mesh")
+    v = np.empty((nv.value, 3), np.float32)
+    n = np.empty((nv.value, 3), np.float32)
+    c = np.empty((nc.value, 4), np.float32)
+    f = np.empty((nf.value, 3), np.uint32)
+    h.hkf_mesh_read(which, v.ctypes.data_as(C.c_void_p), n.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p) if nc.value else None,
+                    f.ctypes.data_as(C.c_void_p))
+    return dict(vertices=v, normals=n, colors=c, faces=f)
+
+
+def mesh_from_soup(triangles, with_color=False):
+    """GPU-free: weld / dedupe / normals of a triangle soup (numpy array of lib.TRI_DTYPE), as saveMesh does after the copy."""
+    h = load()
+    tris = np.ascontiguousarray(triangles)
+    assert tris.dtype.itemsize == 72
+    h.hkf_mesh_from_soup(tris.ctypes.data_as(C.c_void_p), len(tris), int(with_color), None, None)
+    return _mesh_read(0)
+
+
+def mesh_save(which, filename):
+    """which: 0 = the mesh of mesh_from_soup, 1 = the application's mesh (after App.save_mesh)"""
+    return bool(load().hkf_mesh_save(which, filename.encode()))
+
+
+def app_mesh():
+    return _mesh_read(1)

@@ -66,6 +66,8 @@ def test_hybkinectfu_icp_sequence(host_loop):
     path = "/tmp/hybkf_test_mesh.obj"
     ok, nv, nf = app.save_mesh(path)
     assert ok and os.path.getsize(path) > 1000 and nf <= ntri and nv < 3 * ntri // 2
+    gm = H.app_mesh()["faces"]                                  # no degenerate, no duplicate face survives (meshData.cpp:281, :42-82)
+    assert not np.any((gm[:, 0] == gm[:, 1]) | (gm[:, 0] == gm[:, 2]) | (gm[:, 1] == gm[:, 2]))
     txt = open(path).read().splitlines()
     assert sum(1 for l in txt if l.startswith("v ")) == nv and sum(1 for l in txt if l.startswith("f ")) == nf
     app.close()
@@ -83,4 +85,35 @@ def test_hybkinectfu_sdf_tracker_sequence():
         assert ok == o_tracked[k]
         if ok:
             assert np.max(np.abs(pose - o_poses[k])) < 2e-3, (k, pose, o_poses[k])
+    app.close()
+
+
+def test_save_mesh_matches_reference_meshdata_fixture(tmp_path):
+    """MeshGeneratorMarchingcube::generateMesh + saveMesh on the golden 64^3 volume: the GPU's triangle soup equals the soup the
+    reference-MeshData fixture was made from (tests/golden/mesh_s64.npz, tools/make_mesh_golden.py), and the saved mesh --
+    vertex array, face INDICES, normals, OBJ bytes -- equals what the reference's own ml::MeshData / ml::MeshIO produced."""
+    from hybkinectfu_amd import lib as K
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "s64.npz"))
+    m = np.load(os.path.join(gold, "mesh_s64.npz"))
+    cam = (160, 120, 79.5, 59.5, 131.25, 131.25)
+    app = H.App(64, 3.0, cam, max_triangles=400000)
+    ctx = K.Context.borrow(app.ctx_handle(), K.camera(*cam), 64, 3.0)
+    ctx.upload_volume(g["tsdf"], g["weight"])
+    ntri = app.generate_mesh()
+    soup = ctx.triangles()
+    assert ntri == len(soup) == len(m["soup"])
+    assert np.array_equal(soup.view(np.uint32).reshape(-1, 18), m["soup"].view(np.uint32))            # same soup, same order
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        ok, nv, nf = app.save_mesh("mesh.obj")
+        assert ok and nv == len(m["vertices"]) and nf == len(m["faces"])
+        got = H.app_mesh()
+        assert np.array_equal(got["faces"], m["faces"])
+        assert np.array_equal(got["vertices"].view(np.uint32), m["vertices"].view(np.uint32))
+        assert np.array_equal(got["normals"].view(np.uint32), m["normals"].view(np.uint32))
+        assert np.array_equal(np.frombuffer(open("mesh.obj", "rb").read(), np.uint8), m["obj"])
+    finally:
+        os.chdir(cwd)
     app.close()
