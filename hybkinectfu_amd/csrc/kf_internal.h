@@ -187,14 +187,19 @@ __device__ __forceinline__ float3 kf_mat_point3(const float* m, float x, float y
              m[8] * x + m[9] * y + m[10] * z + m[11] * w);
 }
 
-// (int) of a double the way the host reference rounds it: truncation; NaN and out-of-range give INT_MIN
+// (int) of a double / float the way the reference's CUDA path converts (cvt.rzi.s32): truncation, saturating, NaN -> 0 --
+// which is also what gfx950's v_cvt_i32_f64 / v_cvt_i32_f32 do.  Written out (C++ leaves the out-of-range cast undefined,
+// so the compiler may not be handed it).
 __device__ __forceinline__ int kf_to_int(double v) {
-  if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
+  if (v != v) return 0;
+  if (v >= 2147483648.0) return 2147483647;
+  if (v <= -2147483649.0) return (int)0x80000000;
   return (int)v;
 }
-// (int) of a float with the same out-of-range convention, without a trip through fp64
 __device__ __forceinline__ int kf_f2i(float v) {
-  if (!(v > -2147483904.f && v < 2147483648.f)) return (int)0x80000000;
+  if (v != v) return 0;
+  if (v >= 2147483648.f) return 2147483647;
+  if (v <= -2147483648.f) return (int)0x80000000;
   return (int)v;
 }
 
@@ -219,7 +224,7 @@ __device__ __forceinline__ float kf_div(float a, const KfRecip& k) {
 }
 // `(int)(p + 0.5)` of DepthCamera.h:42 (double literal) for callers that only accept results >= 1: for p >= 0.5 the double sum
 // is exact and its truncation equals floor(p) + (frac(p) >= 0.5), all exact in fp32; every p < 0.5, NaN or huge value maps to a
-// result the caller rejects in both formulations (0 here, <= 0 or INT_MIN there; saturated INT_MAX here, INT_MIN there).
+// result the caller rejects in both formulations (0 here, <= 0 there; a huge p saturates to INT_MAX in both).
 __device__ __forceinline__ int kf_round_px(float p) {
   if (!(p >= 0.5f)) return 0;
   const float t = floorf(p);

@@ -139,6 +139,12 @@ void CameraPoseFinder::setCameraPose(const Mat44& t) {
   CudaDeviceDataMan::instance()->check(kf_set_pose(CudaDeviceDataMan::instance()->ctx(), &k));
 }
 bool CameraPoseFinder::enqueueCameraPose(const DepthFrameData& d) { return _inited && enqueueEstimate(d); }
+bool CameraPoseFinder::enqueueEstimate(const DepthFrameData& d) {   // default for two-virtual plugins (src/CameraPoseFinder.h:38-39)
+  ColorFrameData none;
+  if (!estimateCameraPose(d, none)) return false;
+  setCameraPose(_pose);                                              // publish pose + "tracked" to the device-resident state
+  return true;
+}
 bool CameraPoseFinder::requestPose() {
   return !CudaDeviceDataMan::instance()->check(kf_request_track_result(CudaDeviceDataMan::instance()->ctx()));
 }
@@ -303,6 +309,9 @@ bool HybKinectfu::enqueueFrame(const DepthFrameData& depth_frame, const ColorFra
   const AppParams* p = AppParams::instance();
   CudaDeviceDataMan* dm = CudaDeviceDataMan::instance();
   kf_ctx* ctx = dm->ctx();
+  // a finder that computes its pose on the host (file-driven, or a plugin with the reference's two virtuals) has no streaming
+  // form: the frame takes the reference's own sequence, which also handles a lost frame (no integrate, raycast with the old pose)
+  if (!_camera_pose_finder->deviceResident()) return processNewFrame(depth_frame, rgb_frame);
   copyFrameToGPU(depth_frame, rgb_frame);
   if (dm->check(kf_preprocess(ctx, p->_depth_prepocess_params.fMinTrunc, p->_depth_prepocess_params.fMaxTrunc, p->_depth_prepocess_params.fSigmaPixel,
                               p->_depth_prepocess_params.fSigmaDepth, &p->_depth_camera_params))) return false;      // :106-110

@@ -97,19 +97,25 @@ public:
   // overlaps with the host's wait.  deviceResident(): the verdict and the pose of this finder live on the device until read.
   bool requestPose();
   bool waitPose();
-  virtual bool deviceResident() const { return !_host_loop; }
+  // A tracker written against the reference's interface (src/CameraPoseFinder.h:38-39: TWO pure virtuals, initPoseFinder and
+  // estimateCameraPose) computes its pose on the host: not device resident.  The built-in ICP / SDF finders override this.
+  virtual bool deviceResident() const { return false; }
 protected:
   Mat44 _pose;
   bool _host_loop = false;
   virtual bool initPoseFinder() = 0;
   virtual bool estimateCameraPose(const DepthFrameData& depth_frame, const ColorFrameData& color_frame) = 0;
-  virtual bool enqueueEstimate(const DepthFrameData& depth_frame) = 0;
+  // NOT pure: the default estimates on the host and publishes the pose (+ "tracked") to the device, which is all a
+  // two-virtual plugin can do; the built-in finders override it with their device-resident loops.
+  virtual bool enqueueEstimate(const DepthFrameData& depth_frame);
 private:
   bool _inited;
 };
 
 // ---- src/CameraPoseFinderICP.h / .cpp --------------------------------------------------------------------------------------
 class CameraPoseFinderICP : public CameraPoseFinder {
+public:
+  bool deviceResident() const override { return !_host_loop; }
 protected:
   bool initPoseFinder() override;
   bool estimateCameraPose(const DepthFrameData& depth_frame, const ColorFrameData& color_frame) override;
@@ -123,6 +129,8 @@ private:
 
 // ---- src/CameraPoseFinderSDF.h / .cpp --------------------------------------------------------------------------------------
 class CameraPoseFinderSDF : public CameraPoseFinder {
+public:
+  bool deviceResident() const override { return !_host_loop; }
 protected:
   bool initPoseFinder() override;
   bool estimateCameraPose(const DepthFrameData& depth_frame, const ColorFrameData& color_frame) override;

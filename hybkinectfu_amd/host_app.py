@@ -7,7 +7,7 @@ import numpy as np
 
 from . import lib as K
 
-HOST_LIB = os.path.join(K.PKG_DIR, "libhybkf_host.so")
+HOST_LIB = os.environ.get("KF_HOST_LIB") or os.path.join(K.PKG_DIR, "libhybkf_host.so")     # KF_HOST_LIB: the sanitizer build (CPU tests)
 _h = None
 
 

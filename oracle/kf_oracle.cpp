@@ -54,9 +54,15 @@ inline f4 mat_vec(const float* m, f4 v) {
              m[12] * v.x + m[13] * v.y + m[14] * v.z + m[15] * v.w);
 }
 
-/* (int) of a double as x86-64 does it (cvttsd2si): out-of-range and NaN give INT_MIN */
+/* (int) of a double as the reference's CUDA path does it (cvt.rzi.s32.f64): truncation, SATURATING, NaN -> 0.  The north
+ * star names the CUDA path as the one to match; a host build of the same headers (x86-64 cvttsd2si) would return INT_MIN for
+ * NaN / out-of-range instead.  The two differ only for NaN (0 vs INT_MIN: findCorrs' `>= 0` bounds test,
+ * CalPointToPlaneErrSolverParams.cu:39-43, accepts pixel 0) and for +overflow (INT_MAX vs INT_MIN: rejected by every bounds
+ * test either way).  gfx950's v_cvt_i32_f32 / v_cvt_i32_f64 have the CUDA semantics natively (kf_internal.h: kf_to_int). */
 inline int to_int(double v) {
-  if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
+  if (v != v) return 0;
+  if (v >= 2147483648.0) return 2147483647;
+  if (v <= -2147483649.0) return (int)0x80000000;
   return (int)v;
 }
 inline int to_int_f(float v) { return to_int((double)v); }
@@ -754,6 +760,16 @@ int okf_interpolate_sdf(const okf_volume* vol, const float pos[3], float* dist) 
   if (ok) *dist = d;
   return ok ? 1 : 0;
 }
+
+/* helper arithmetic exposed for tests/test_oracle_vs_ref.py (pinned against the reference's headers) */
+int okf_interpolate_color(const okf_volume* vol, const float pos[3], uint8_t out[3]) {
+  return interpolate_color(vol, mk3(pos[0], pos[1], pos[2]), out) ? 1 : 0;
+}
+void okf_world_to_voxel(const okf_volume* vol, const float pos[3], int out[3]) {
+  i3 g = world_to_voxel(vol, mk3(pos[0], pos[1], pos[2])); out[0] = g.x; out[1] = g.y; out[2] = g.z;
+}
+float okf_norm(const float v[3]) { return norm3(mk3(v[0], v[1], v[2])); }
+int okf_to_int(double v) { return to_int(v); }
 
 /* a12: vertexInterp marchingcube.cu:5-26 */
 static okf_vertex vertex_interp(float iso, f3 p1, f3 p2, float d1, float d2, const uint8_t c1[3], const uint8_t c2[3]) {

@@ -93,6 +93,10 @@ uint32_t okf_marching_cubes(const okf_volume* vol, int z0, int z1, int has_color
                             okf_triangle* tris, uint32_t max_tris);
 /* tsdfVolume.h:98-122 exposed for pin tests: returns 1 and *dist when valid */
 int  okf_interpolate_sdf(const okf_volume* vol, const float pos[3], float* dist);
+int  okf_interpolate_color(const okf_volume* vol, const float pos[3], uint8_t out[3]);   /* tsdfVolume.h:123-148 */
+void okf_world_to_voxel(const okf_volume* vol, const float pos[3], int out[3]);          /* tsdfVolume.h:50-56 */
+float okf_norm(const float v[3]);                                                        /* cuda_declar.h norm() */
+int  okf_to_int(double v);                                                               /* the (int) conversion rule the oracle uses: CUDA's (saturating, NaN -> 0) */
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "libkforacle.so")
+ORACLE_SO = os.environ.get("KF_ORACLE_SO") or os.path.join(ORACLE_DIR, "libkforacle.so")     # KF_ORACLE_SO: the sanitizer build
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libkfref.so")
 
 
@@ -39,6 +39,8 @@ assert VOXEL_DTYPE.itemsize == 12 and TRI_DTYPE.itemsize == 72
 
 
 def build_oracle():
+    if os.environ.get("KF_ORACLE_SO"):
+        return ORACLE_SO
     if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(ORACLE_DIR, "kf_oracle.cpp")):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "libkforacle.so"], stdout=subprocess.DEVNULL)
     return ORACLE_SO
@@ -229,6 +231,27 @@ def interpolate_sdf(vol, pos):
     d = C.c_float(0)
     ok = lib().okf_interpolate_sdf(C.byref(vol.c), fp(np.ascontiguousarray(pos, np.float32)), C.byref(d))
     return bool(ok), d.value
+
+
+def interpolate_color(vol, pos):
+    out = np.zeros(3, np.uint8)
+    ok = lib().okf_interpolate_color(C.byref(vol.c), fp(np.ascontiguousarray(pos, np.float32)), fp(out))
+    return bool(ok), out
+
+
+def world_to_voxel(vol, pos):
+    out = np.zeros(3, np.int32)
+    lib().okf_world_to_voxel(C.byref(vol.c), fp(np.ascontiguousarray(pos, np.float32)), fp(out))
+    return out
+
+
+def norm(v):
+    lib().okf_norm.restype = C.c_float
+    return lib().okf_norm(fp(np.ascontiguousarray(v, np.float32)))
+
+
+def to_int(v):
+    return lib().okf_to_int(C.c_double(v))
 
 
 def set_threads(n):

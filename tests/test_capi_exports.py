@@ -48,3 +48,25 @@ def test_product_never_touches_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.lower().replace("the cpu oracle", "").replace("cpu oracle", ""), os.path.join(dirpath, f)
+
+
+def test_two_virtual_plugin_compiles_and_links(tmp_path):
+    """A tracker written against the reference's CameraPoseFinder (src/CameraPoseFinder.h:38-39: two pure virtuals) must build
+    against hybkf_host.hpp unchanged and link against libhybkf_host.so."""
+    import subprocess
+    host = os.path.join(ROOT, "hybkinectfu_amd", "host")
+    src = os.path.join(ROOT, "tests", "plugin", "two_virtual_finder.cpp")
+    out = str(tmp_path / "libplugin.so")
+    subprocess.check_call(["g++", "-std=c++17", "-fPIC", "-shared", "-I", host, "-I", os.path.join(ROOT, "include"), src, "-o", out,
+                           "-L", os.path.join(ROOT, "hybkinectfu_amd"), "-lhybkf_host", "-lhybkf",
+                           "-Wl,-rpath," + os.path.join(ROOT, "hybkinectfu_amd")])
+    K.load()
+    plug = C.CDLL(out)
+    assert plug.plugin_two_virtuals_instantiates() == 0            # a host-side tracker is not device resident
+
+
+def test_product_library_has_no_experiment_modes():
+    """The result-changing timing experiments (KF_*_EXP) exist only in the -DKF_EXPERIMENTS variant (libhybkf_exp.so)."""
+    data = open(K.LIB_PATH if not os.environ.get("KF_LIB") else os.path.join(K.PKG_DIR, "libhybkf.so"), "rb").read()
+    for name in (b"KF_INTEGRATE_EXP", b"KF_ICP_EXP", b"KF_RAYCAST_EXP"):
+        assert name not in data

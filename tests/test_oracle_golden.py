@@ -156,3 +156,12 @@ def test_pixel_rounding_floor_form_equals_reference_double_form():
     # below 0.5 both forms give a value < 1, which the bounds test rejects either way
     q = rng.uniform(-50, 0.5, 100000).astype(np.float32)
     assert np.all((q.astype(np.float64) + 0.5).astype(np.int64) < 1) and np.all(np.floor(q + np.float32(0.5)) < 1)
+
+
+def test_float_to_int_follows_the_cuda_path():
+    """(int) of NaN / out-of-range: the north star names the reference's CUDA path, whose cvt.rzi.s32 saturates and maps
+    NaN to 0 (x86-64 would give INT_MIN); gfx950's v_cvt_i32 does the same natively.  DESIGN.md section 2.3."""
+    assert O.to_int(float("nan")) == 0
+    assert O.to_int(1e20) == 2**31 - 1 and O.to_int(float("inf")) == 2**31 - 1
+    assert O.to_int(-1e20) == -2**31 and O.to_int(float("-inf")) == -2**31
+    assert O.to_int(-3.99) == -3 and O.to_int(3.99) == 3 and O.to_int(2147483647.5) == 2**31 - 1

@@ -190,3 +190,28 @@ def test_vector_helpers():
         r.ref_cross(O.fp(up), O.fp(rt), O.fp(cr))
         r.ref_normalize(O.fp(cr), O.fp(out))
         assert np.array_equal(bits(out), bits(n[y, x, :3]))
+
+
+def test_color_interpolation_world_to_voxel_and_norm():
+    """tsdfVolume.h:123-148 interpolateColor (validity + the truncating float->uchar result), :50-56 worldPosToVoxel and
+    cuda_declar.h norm(): the oracle's restatements against the reference's own headers, bit for bit."""
+    rng = np.random.default_rng(9)
+    r, h, vol = _vol_pair(rng, fill=0.97)
+    size = vol.size
+    n_ok = 0
+    for _ in range(4000):
+        p = rng.uniform(-0.1, size + 0.1, 3).astype(np.float32)
+        c_ref = (C.c_ubyte * 3)(0, 0, 0)
+        ok_ref = r.ref_vol_interp_color(h, O.fp(p), c_ref)
+        ok, c = O.interpolate_color(vol, p)
+        assert bool(ok_ref) == ok
+        if ok:
+            n_ok += 1
+            assert list(c_ref) == [int(x) for x in c]
+        g_ref = np.zeros(3, np.int32)
+        r.ref_vol_world_to_voxel(h, O.fp(p), O.fp(g_ref))
+        assert np.array_equal(g_ref, O.world_to_voxel(vol, p))
+        v = (rng.standard_normal(3) * rng.choice([1e-6, 1.0, 1e4])).astype(np.float32)
+        assert np.float32(r.ref_norm(O.fp(v))).view(np.uint32) == np.float32(O.norm(v)).view(np.uint32)
+    assert n_ok > 500
+    r.ref_vol_destroy(h)
