@@ -132,6 +132,7 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
     for (int l = 0; l < 2; ++l) n += (size_t)kf_div_up(c->cols, 8 << l) * kf_div_up(c->rows, 8 << l);
     TRY(dev_alloc(&c->tile_max_depth, n));
     TRY((int)hipMemsetAsync(c->tile_max_depth, 0, n * sizeof(float), c->stream));
+    c->n_tile_floats = (int)n; c->tiles_clear = 1;
   }
   c->max_triangles = cfg->max_triangles;
   if (c->max_triangles) TRY(dev_alloc(&c->triangles, (size_t)c->max_triangles));
@@ -308,6 +309,7 @@ extern "C" int kf_upload_map(kf_ctx* c, int id, uint32_t level, const void* src,
   if (!c || !src) return KF_ERR_ARG;
   void* p; size_t bytes; bool rgb;
   int st = map_ptr(c, id, level, &p, &bytes, &rgb);
+  if (id == KF_MAP_TRUNCED_DEPTH) c->trunc_serial++;             // the integrate tile maxima no longer describe this map
   if (st) return st;
   if (src_bytes != bytes) return KF_ERR_ARG;
   if (rgb) {
@@ -426,9 +428,9 @@ extern "C" int kf_get_volume_stats(kf_ctx* c, kf_volume_stats* out) {
   KF_CHECK(hipMemcpyAsync(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   KF_CHECK(hipStreamSynchronize(c->stream));
   unsigned long long last = 0, total = 0;
-  for (int i = 0; i < 64; ++i) { last += h.upd_shard[i * 16]; total += h.upd_total_shard[i]; }
+  for (int i = 0; i < 64; ++i) { last += h.upd_shard[c->last_parity][i * 16]; total += h.upd_shard[c->last_parity ^ 1][i * 16] + h.upd_total_shard[i]; }
   out->updated_last = last; out->weight_gt0 = h.weight_gt0;
-  out->bricks_active = h.n_active_bricks; out->bricks_total = c->n_stored_bricks;
+  out->bricks_active = h.n_active[c->last_parity]; out->bricks_total = c->n_stored_bricks;
   out->updated_total = total + last; out->frames_fused = h.frames_fused; out->frames_lost = h.frames_lost;
   return 0;
 }

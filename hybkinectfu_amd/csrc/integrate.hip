@@ -20,9 +20,9 @@ struct IntegrateArgs {
   const float* depth;            // trunced_depth
   const float4* normals;         // new_normals_pyramid[0]
   const uchar4* rgb;             // raw_rgb
-  const float* pose;             // device: camera -> world (null: use pose_val)
-  KfMat pose_val;                // host-supplied transform, passed by value
-  float* tinv;                   // device scratch: world -> camera (Mat44::getInverse)
+  const float* tinv;             // device: world -> camera = Mat44::getInverse of the pose (integrateVolume.cu:84), kept next to the
+                                 // device-resident pose by whoever commits it (KfTrackState::pose_inv); null: tinv_val
+  KfMat tinv_val;                // the inverse of a host-supplied transform, computed on the host with the same arithmetic
   float* tile_max;               // device: max of the depth gated by max_dist over 8-pixel and 16-pixel tiles (two tables, see tile_off)
   int tile_off[2], tile_w[2], tile_h[2];   // offset / width / height of each level's table inside tile_max
   int fine_tiles;                // 1: bricks are small on screen, the cull reads the 8-pixel table where the footprint allows
@@ -33,14 +33,28 @@ struct IntegrateArgs {
   int has_color, color_angled;
   float fr_slope[4], fr_norm[4]; // frustum side planes through the eye (left, right, top, bottom), widened by one pixel: slope and sqrt(1+slope^2)
   int exp_mode;                  // timing experiments only (KF_INTEGRATE_EXP): 1 = no store, 2 = no load/store
+  int parity;                    // which of the double-buffered counter sets (KfCounters) this call uses
+  int clear_tiles, n_tile_floats;   // the fusion pass zeroes the tile tables once the cull has read them
 };
+
+// Retire the OTHER parity's counters (nobody touches them during this launch) and clear the tile tables for the next frame's fused
+// preprocess kernel: run by workgroup 0 of the fusion pass, so a frame needs no bookkeeping launch.
+__device__ __forceinline__ void integrate_maintenance(const IntegrateArgs& a) {
+  const int o = a.parity ^ 1;
+  if (threadIdx.x < 64) {
+    a.cnt->upd_total_shard[threadIdx.x] += a.cnt->upd_shard[o][threadIdx.x * 16];
+    a.cnt->upd_shard[o][threadIdx.x * 16] = 0ull;
+  }
+  if (threadIdx.x == 0) a.cnt->n_active[o] = 0u;
+  if (a.clear_tiles) for (int i = threadIdx.x; i < a.n_tile_floats; i += blockDim.x) a.tile_max[i] = 0.f;
+}
 
 
 // pass 0: one workgroup per 16x16 pixel block -> max of the depth values that can integrate (0 < d < max_dist) over its four
 // 8x8 tiles and over the block: the cull tests a brick against the finest of the two tables in which its footprint spans at most
 // 4 x 4 tiles, so distant bricks (small footprints) get a much tighter maximum.  Coarser levels were tried (atomic maxima, or
 // built per cull workgroup in LDS): they only matter for the few bricks next to the eye and cost more than they save.
-// Workgroup 0 also inverts the pose and clears the counters.
+// (Fallback: normally the fused preprocess kernel has built the tables already -- preprocess.hip, KfTileAccum.)
 __global__ void __launch_bounds__(256) k_integrate_prepare(IntegrateArgs a) {
   __shared__ float s_q[4][2][2];                             // [wave][left / right half][unused pad]
   const int bw = a.tile_w[1];
@@ -62,10 +76,6 @@ __global__ void __launch_bounds__(256) k_integrate_prepare(IntegrateArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) { s_q[wave][0][0] = left; s_q[wave][1][0] = right; }
   __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x < 64) {                // fold the previous frame's sharded update count, then clear it
-    a.cnt->upd_total_shard[threadIdx.x] += a.cnt->upd_shard[threadIdx.x * 16];
-    a.cnt->upd_shard[threadIdx.x * 16] = 0ull;
-  }
   if (threadIdx.x < 4) {                                     // level 0: quadrant (qx, qy) = waves 2*qy and 2*qy + 1, half qx
     const int hx = threadIdx.x & 1, hy = threadIdx.x >> 1;
     const float q = fmaxf(s_q[2 * hy][hx][0], s_q[2 * hy + 1][hx][0]);
@@ -77,10 +87,6 @@ __global__ void __launch_bounds__(256) k_integrate_prepare(IntegrateArgs a) {
 #pragma unroll
     for (int w = 0; w < 4; ++w) m16 = fmaxf(m16, fmaxf(s_q[w][0][0], s_q[w][1][0]));
     a.tile_max[a.tile_off[1] + blockIdx.x] = m16;
-    if (blockIdx.x == 0) {
-      kf_mat44_inverse(a.pose ? a.pose : a.pose_val.m, a.tinv);   // integrateVolume.cu:84
-      a.cnt->n_active_bricks = 0u;
-    }
   }
 }
 
@@ -118,7 +124,7 @@ __global__ void __launch_bounds__(CULL_WAVES * 64) k_integrate_cull(IntegrateArg
   const int wave = blockIdx.x * CULL_WAVES + wid;
   const int n_macro = nmxy * nmxy * (mz1 - mz0);
   const int mx = wave % nmxy, my = (wave / nmxy) % nmxy, mz = wave / (nmxy * nmxy) + mz0;
-  const float* m = a.tinv;
+  const float* m = a.tinv ? a.tinv : a.tinv_val.m;
   const float cell = v.cell;
   float px, py, pz;
   const int bx = mx * 4 + (lane & 3), by = my * 4 + ((lane >> 2) & 3), bz = mz * 4 + (lane >> 4);
@@ -185,7 +191,7 @@ __global__ void __launch_bounds__(CULL_WAVES * 64) k_integrate_cull(IntegrateArg
     unsigned total = 0;
 #pragma unroll
     for (int w = 0; w < CULL_WAVES; ++w) { const unsigned n = s_cnt[w]; s_cnt[w] = total; total += n; }
-    s_base = total ? atomicAdd(&a.cnt->n_active_bricks, total) : 0u;
+    s_base = total ? atomicAdd(&a.cnt->n_active[a.parity], total) : 0u;
   }
   __syncthreads();
   if (keep) {
@@ -200,8 +206,9 @@ __global__ void __launch_bounds__(CULL_WAVES * 64) k_integrate_cull(IntegrateArg
 template <bool HAS_COLOR, int BR>
 __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
   const KfVolume& v = a.vol;
-  const unsigned n_active = a.cnt->n_active_bricks;
-  const float* m = a.tinv;
+  const unsigned n_active = a.cnt->n_active[a.parity];
+  if (blockIdx.x == 0) integrate_maintenance(a);
+  const float* m = a.tinv ? a.tinv : a.tinv_val.m;
   const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8], m9 = m[9], m10 = m[10], m11 = m[11];
   const float cell = v.cell;
   const int lx = (threadIdx.x & 3) * 2, ly = (threadIdx.x >> 2) & 7, lz = threadIdx.x >> 5;
@@ -318,7 +325,7 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
   float s = kf_wave_sum((float)upd_total);          // < 2^24 per wave: exact
   if ((threadIdx.x & 63) == 0 && s > 0.f) atomicAdd(&s_upd, (unsigned)s);
   __syncthreads();
-  if (threadIdx.x == 0 && s_upd) atomicAdd(&a.cnt->upd_shard[(blockIdx.x & 63) * 16], (unsigned long long)s_upd);
+  if (threadIdx.x == 0 && s_upd) atomicAdd(&a.cnt->upd_shard[a.parity][(blockIdx.x & 63) * 16], (unsigned long long)s_upd);
 }
 
 // ---- the same fusion pass with the lane's two x-adjacent voxels carried as one 2-vector ------------------------------------------
@@ -351,8 +358,9 @@ __device__ __forceinline__ kf_f2 kf_div2(kf_f2 a, const KfRecip2& k) {     // kf
 template <int BR>
 __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   const KfVolume& v = a.vol;
-  const unsigned n_active = a.cnt->n_active_bricks >> (KF_EXP_MODE(a) >= 8 ? KF_EXP_MODE(a) - 7 : 0);     // exp_mode 8 / 9: half / quarter of the queue (timing only)
-  const float* m = a.tinv;
+  const unsigned n_active = a.cnt->n_active[a.parity] >> (KF_EXP_MODE(a) >= 8 ? KF_EXP_MODE(a) - 7 : 0);     // exp_mode 8 / 9: half / quarter of the queue (timing only)
+  if (blockIdx.x == 0) integrate_maintenance(a);
+  const float* m = a.tinv ? a.tinv : a.tinv_val.m;
   const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8], m9 = m[9], m10 = m[10], m11 = m[11];
   const float cell = v.cell;
   const int lx = (threadIdx.x & 3) * 2, ly = (threadIdx.x >> 2) & 7, lz = threadIdx.x >> 5;
@@ -411,7 +419,7 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
     for (int b = 0; b < BR; ++b) {
       p[b] = reinterpret_cast<float4*>(v.tw + (size_t)slot[b] * KF_BRICK_VOX) + threadIdx.x;
       q[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (upd0[b] || upd1[b]) q[b] = *p[b];
+      if ((upd0[b] || upd1[b]) && KF_EXP_MODE(a) != 2) q[b] = *p[b];
     }
 #pragma unroll
     for (int b = 0; b < BR; ++b) {
@@ -427,7 +435,7 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
         float4 r = q[b];
         if (upd0[b]) { r.x = nt.x; r.y = nw0; }
         if (upd1[b]) { r.z = nt.y; r.w = nw1; }
-        *p[b] = r;
+        if (KF_EXP_MODE(a) == 0 || KF_EXP_MODE(a) >= 8 || r.x == 123.456f) *p[b] = r;     // experiments 1 / 2: no store
         upd_total += (upd0[b] ? 1u : 0u) + (upd1[b] ? 1u : 0u);
         flags = KF_FLAG_OBSERVED | (((upd0[b] && nt.x < 0.f) || (upd1[b] && nt.y < 0.f)) ? KF_FLAG_HASNEG : 0u);
       }
@@ -445,8 +453,41 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   float s = kf_wave_sum((float)upd_total);          // < 2^24 per wave: exact
   if ((threadIdx.x & 63) == 0 && s > 0.f) atomicAdd(&s_upd, (unsigned)s);
   __syncthreads();
-  if (threadIdx.x == 0 && s_upd) atomicAdd(&a.cnt->upd_shard[(blockIdx.x & 63) * 16], (unsigned long long)s_upd);
+  if (threadIdx.x == 0 && s_upd) atomicAdd(&a.cnt->upd_shard[a.parity][(blockIdx.x & 63) * 16], (unsigned long long)s_upd);
 }
+
+#ifdef KF_EXPERIMENTS
+// experiments 4-7: the memory side of the fusion pass alone -- every queued brick is read and / or written back (16 bytes per
+// lane, all lanes), no arithmetic: what the brick-queue access pattern can reach on this chip (tools/bench_integrate.py).
+// MODE 0: load + store; 1: non-temporal load + store; 2: read only (sum kept alive); 3: write only
+template <int BR, int MODE>
+__global__ void __launch_bounds__(256) k_exp_brick_rmw(IntegrateArgs a) {
+  const KfVolume& v = a.vol;
+  const unsigned n_active = a.cnt->n_active[a.parity];
+  if (blockIdx.x == 0) integrate_maintenance(a);
+  float acc = 0.f;
+  for (unsigned q0 = blockIdx.x * BR; q0 < n_active; q0 += gridDim.x * BR) {
+    float4* p[BR]; float4 q[BR];
+#pragma unroll
+    for (int b = 0; b < BR; ++b) {
+      const unsigned packed = (q0 + b < n_active) ? a.queue[q0 + b] : a.queue[q0];
+      const unsigned slot = ((packed >> 20) * (unsigned)v.nb + ((packed >> 10) & 1023u)) * (unsigned)v.nb + (packed & 1023u);
+      p[b] = reinterpret_cast<float4*>(v.tw + (size_t)slot * KF_BRICK_VOX) + threadIdx.x;
+      if (MODE == 1) { typedef float v4 __attribute__((ext_vector_type(4))); const v4 t = __builtin_nontemporal_load(reinterpret_cast<v4*>(p[b])); q[b] = make_float4(t.x, t.y, t.z, t.w); }
+      else if (MODE == 3) q[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+      else q[b] = *p[b];
+    }
+#pragma unroll
+    for (int b = 0; b < BR; ++b) {
+      q[b].y += 0.f;
+      if (MODE == 1) { typedef float v4 __attribute__((ext_vector_type(4))); v4 t = {q[b].x, q[b].y, q[b].z, q[b].w}; __builtin_nontemporal_store(t, reinterpret_cast<v4*>(p[b])); }
+      else if (MODE == 2) acc += q[b].x;
+      else *p[b] = q[b];
+    }
+  }
+  if (MODE == 2 && acc == 123.456f) a.tile_max[0] = acc;
+}
+#endif
 
 static inline KfCam to_cam(const kf_camera_params* p) {
   KfCam c; c.cols = (int)p->cols; c.rows = (int)p->rows; c.cx = p->cx; c.cy = p->cy; c.fx = p->fx; c.fy = p->fy; return c;
@@ -460,7 +501,7 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   IntegrateArgs a;
   a.vol = c->vol; a.dcam = to_cam(dcam); a.rcam = rcam ? to_cam(rcam) : a.dcam;
   a.depth = c->trunced_depth; a.normals = c->new_n[0]; a.rgb = c->raw_rgb;
-  a.tinv = c->scratch_mats + 16; a.tile_max = c->tile_max_depth; a.queue = c->active_bricks; a.cnt = c->counters;
+  a.tile_max = c->tile_max_depth; a.queue = c->active_bricks; a.cnt = c->counters;
   a.sdf_trunc = ip->sdf_truncation; a.max_dist = ip->max_integrate_dist;
   a.has_color = has_color; a.color_angled = use_angle_weight_color;
   for (int l = 0, off = 0; l < 2; ++l) {
@@ -475,13 +516,19 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   for (int i = 0; i < 4; ++i) a.fr_norm[i] = sqrtf(1.f + a.fr_slope[i] * a.fr_slope[i]);
   { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_INTEGRATE_EXP"); a.exp_mode = em; }
   if (transform) {
-    for (int i = 0; i < 16; ++i) a.pose_val.m[i] = transform->m[i];
-    a.pose = nullptr; a.track = nullptr;
+    kf_mat44_inverse(transform->m, a.tinv_val.m);        // integrateVolume.cu:84, same arithmetic as on the device
+    a.tinv = nullptr; a.track = nullptr;
   } else {
-    a.pose = c->track->pose; a.track = c->track;
+    a.tinv = c->track->pose_inv; a.track = c->track;     // kept current by whoever commits the device-resident pose
   }
+  a.parity = c->int_parity; c->last_parity = c->int_parity; c->int_parity ^= 1;
+  a.clear_tiles = 1; a.n_tile_floats = c->n_tile_floats;
   kf_evt_begin(c, KF_STAGE_INTEGRATE);
-  hipLaunchKernelGGL(k_integrate_prepare, dim3(a.tile_w[1] * a.tile_h[1]), dim3(256), 0, c->stream, a);
+  // tile maxima: normally left behind by the fused preprocess kernel for exactly this depth map and distance
+  const bool tiles_ready = c->tile_serial != 0 && c->tile_serial == c->trunc_serial && c->tile_built_dist == a.max_dist;
+  if (!tiles_ready) hipLaunchKernelGGL(k_integrate_prepare, dim3(a.tile_w[1] * a.tile_h[1]), dim3(256), 0, c->stream, a);
+  c->fuse_max_dist = a.max_dist;                         // what the next preprocess builds the tables for
+  c->tile_serial = 0; c->tiles_clear = 1;                // the fusion pass below clears the tables behind the cull
   {
     const int nmxy = (c->vol.nb + 3) >> 2, nmz = ((c->vol.bz1 + 3) >> 2) - (c->vol.bz0 >> 2);
     const unsigned n_macro = (unsigned)nmxy * nmxy * nmz;                      // one wave per macro cell, sixteen per workgroup
@@ -500,6 +547,13 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
     const int br = br_env ? br_env : (c->n_stored_bricks >= ((size_t)1 << 20) ? 4 : 2);
     static int pairs = -1;                               // 1 (default): the packed-pair kernel; 0: the scalar one (A/B and colour path)
     if (pairs < 0) { const char* e = getenv("KF_INTEGRATE_PAIRS"); pairs = e ? atoi(e) : 1; }
+#ifdef KF_EXPERIMENTS
+    if (a.exp_mode == 4) hipLaunchKernelGGL((k_exp_brick_rmw<4, 0>), dim3(grid), dim3(256), 0, c->stream, a);
+    else if (a.exp_mode == 5) hipLaunchKernelGGL((k_exp_brick_rmw<4, 1>), dim3(grid), dim3(256), 0, c->stream, a);
+    else if (a.exp_mode == 6) hipLaunchKernelGGL((k_exp_brick_rmw<4, 2>), dim3(grid), dim3(256), 0, c->stream, a);
+    else if (a.exp_mode == 7) hipLaunchKernelGGL((k_exp_brick_rmw<4, 3>), dim3(grid), dim3(256), 0, c->stream, a);
+    else
+#endif
     if (pairs) {
       if (br == 1) hipLaunchKernelGGL((k_integrate_pairs<1>), dim3(grid), dim3(256), 0, c->stream, a);
       else if (br == 2) hipLaunchKernelGGL((k_integrate_pairs<2>), dim3(grid), dim3(256), 0, c->stream, a);

@@ -66,6 +66,7 @@ struct KfTrackState {
   int   converged;       // SDF tracker: |x| < 1e-3 reached
   unsigned arrive;       // arrival counter of the persistent ICP loop's grid barrier (monotonic within a frame)
   unsigned pad_[3];
+  float pose_inv[16];    // pose.getInverse(), written wherever pose is committed: integrate reads it (integrateVolume.cu:84)
 };
 
 // software grid barrier of the persistent ICP loop: every word on its own 128-byte line
@@ -73,8 +74,8 @@ struct KfPaddedCounter { unsigned v; unsigned pad_[31]; };
 struct KfGridBarrier { KfPaddedCounter group[8]; KfPaddedCounter top; KfPaddedCounter gen; };
 
 struct KfCounters {
-  unsigned long long n_upd;       // voxels updated by the last integrate
-  unsigned n_active_bricks;       // bricks queued by the last cull
+  unsigned long long n_upd;       // (unused)
+  unsigned n_active_bricks;       // (unused: see n_active)
   unsigned n_triangles;           // MarchingcubeData::_ptr_num_triangles
   unsigned long long weight_gt0;
   unsigned scan_total;
@@ -84,8 +85,13 @@ struct KfCounters {
   unsigned pad_;
   // update counts are sharded over 64 cache lines: one address takes ~11 ns per atomic (MI355X_MICROARCH.md 'dequeue'),
   // so thousands of workgroups adding to ONE word would cost more than the fusion itself
-  unsigned long long upd_shard[64 * 16];     // this frame, slot s at [s*16]
-  unsigned long long upd_total_shard[64];    // folded sum of the earlier frames
+  // Per-integrate counters are double-buffered by the call's parity p (kf_ctx::int_parity): the cull adds to n_active[p], the
+  // fusion pass reads it and adds to upd_shard[p], and ITS workgroup 0 retires the other parity's set (folds upd_shard[1-p] into
+  // upd_total_shard, zeroes n_active[1-p]) -- nobody else touches that set during the launch, so no extra kernel is needed.
+  unsigned n_active[2];                      // bricks queued by the cull
+  unsigned pad2_[2];
+  unsigned long long upd_shard[2][64 * 16];  // this integrate's update count, slot s at [s*16]
+  unsigned long long upd_total_shard[64];    // folded sum of the earlier integrates
 };
 
 struct kf_ctx {
@@ -126,7 +132,14 @@ struct kf_ctx {
   KfVolume vol;
   size_t n_stored_vox, n_stored_bricks;
   unsigned* active_bricks;            // device: brick ids queued by the cull kernel
-  float* tile_max_depth;              // device: per 16x16-pixel tile max of gated depth
+  float* tile_max_depth;              // device: per 8x8- and 16x16-pixel tile max of the depth gated by the integration distance
+  int n_tile_floats;                  // entries of both tables together
+  // The tables are normally built by the fused preprocess kernel (atomic max into a CLEARED table) for the integration distance
+  // the last kf_integrate_volume used; integrate falls back to k_integrate_prepare when they do not describe the current trunced
+  // depth map (serials differ) or another distance is asked for.  The fusion pass clears them again once the cull has read them.
+  unsigned long long trunc_serial, tile_serial;   // bumped by every writer of trunced_depth / copied when the tables are built
+  float tile_built_dist, fuse_max_dist;
+  int tiles_clear, int_parity, last_parity;
   kf_triangle* triangles; uint32_t max_triangles;
   unsigned* mc_block_counts; size_t mc_blocks_cap;
   void* host_pinned;                  // small pinned staging buffer (4 KiB); byte KF_PINNED_STALL_WORD: the ICP loop's stall word

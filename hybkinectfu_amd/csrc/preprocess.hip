@@ -65,10 +65,17 @@ __global__ void __launch_bounds__(256) k_bilateral(const float* __restrict__ in,
 // R x R tap loop is fully unrolled and branch-free: a zero (invalid or out-of-image) tap gets weight 0 -- adding +0 leaves the
 // reference's running sums bit-identical -- and the reference's early `return` (any tap further than 5 sigma_d away keeps the
 // unfiltered value, :66-69) becomes a flag tested once at the end.
+// The kernel also leaves the TSDF integration's tile maxima behind (integrate.hip: the max, over every 8x8 and 16x16 pixel tile, of
+// the gated depth that can integrate, d < max_dist): the gated tile is in LDS anyway, a wave is one 64-pixel row, so three DPP
+// steps give the max of each 8-pixel group and one more that of each 16-pixel group, and the group leaders merge them into the
+// (cleared) tables with fire-and-forget integer atomic maxima -- non-negative floats order like their bit patterns.  That replaces
+// a launch of its own (k_integrate_prepare) in front of every integrate.  acc.tile == nullptr: tables not wanted.
+struct KfTileAccum { int* tile; int off0, w0, off1, w1; float max_dist; };
 template <int R>
 __global__ void __launch_bounds__(256) k_gate_bilateral(const uint16_t* __restrict__ mm, const float* __restrict__ raw_in,
                                                         float* __restrict__ raw_out, float* __restrict__ trunced, float* __restrict__ filtered,
-                                                        int cols, int rows, float tmin, float tmax, float ss_inv, float sd_inv, float sigma_depth) {
+                                                        int cols, int rows, float tmin, float tmax, float ss_inv, float sd_inv, float sigma_depth,
+                                                        KfTileAccum acc) {
   constexpr int TW = BIL_TX + 2 * R, TH = BIL_TY + 2 * R;
   __shared__ float tile[TW * TH];
   const int x0 = blockIdx.x * BIL_TX - R, y0 = blockIdx.y * BIL_TY - R;
@@ -86,8 +93,19 @@ __global__ void __launch_bounds__(256) k_gate_bilateral(const uint16_t* __restri
   __syncthreads();
   const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
   const int x = blockIdx.x * BIL_TX + lx, y = blockIdx.y * BIL_TY + ly;
-  if (x >= cols || y >= rows) return;
-  const float value = tile[(ly + R) * TW + lx + R];
+  const bool inside = x < cols && y < rows;
+  const float value = inside ? tile[(ly + R) * TW + lx + R] : 0.f;
+  if (acc.tile) {                                          // uniform; every lane of the wave takes part in the DPP steps
+    float d = (value < acc.max_dist) ? value : 0.f;
+    d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0xB1, 0xf, 0xf, true)));    // quad_perm:[1,0,3,2]
+    d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x4E, 0xf, 0xf, true)));    // quad_perm:[2,3,0,1]
+    d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x141, 0xf, 0xf, true)));   // row_half_mirror: 8-pixel groups
+    const float d16 = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x140, 0xf, 0xf, true)));   // row_mirror: 16-pixel groups
+    // a group whose leader lies outside the image holds no pixel at all (d == 0): the indices below stay inside the tables
+    if ((lx & 7) == 0 && d > 0.f) atomicMax(acc.tile + acc.off0 + (y >> 3) * acc.w0 + (x >> 3), __float_as_int(d));
+    if ((lx & 15) == 0 && d16 > 0.f) atomicMax(acc.tile + acc.off1 + (y >> 4) * acc.w1 + (x >> 4), __float_as_int(d16));
+  }
+  if (!inside) return;
   float result = value;
   if (value != 0.f) {
     float sum1 = 0.f, sum2 = 0.f;
@@ -253,6 +271,7 @@ extern "C" int kf_trunc_depth(kf_ctx* c, float tmin, float tmax) {
   if (st) return st;
   int n = c->cols * c->rows;
   hipLaunchKernelGGL(k_trunc_depth, dim3(kf_div_up(n, 256)), dim3(256), 0, c->stream, c->raw_depth, c->trunced_depth, n, tmin, tmax);
+  c->trunc_serial++;
   return (int)hipGetLastError();
 }
 
@@ -285,12 +304,18 @@ extern "C" int kf_calculate_new_normals(kf_ctx* c) {
 
 // the two fused launches of kf_preprocess on a given stream and buffer set
 static int launch_fused_preprocess(kf_ctx* c, hipStream_t stream, const uint16_t* mm, const float* raw_in, float* raw_out, float* trunced, float* filtered,
-                                   float4* v0, float4* n0, float tmin, float tmax, float sigma_pixel, float sigma_depth, const kf_camera_params* cam) {
+                                   float4* v0, float4* n0, float tmin, float tmax, float sigma_pixel, float sigma_depth, const kf_camera_params* cam,
+                                   bool build_tiles) {
   const float sd_inv = (float)(0.5 / (double)(sigma_depth * sigma_depth));
   const float ss_inv = (float)(0.5 / (double)(sigma_pixel * sigma_pixel));
   dim3 grid(kf_div_up(c->cols, BIL_TX), kf_div_up(c->rows, BIL_TY));
+  KfTileAccum acc; memset(&acc, 0, sizeof(acc));
+  if (build_tiles) {                                       // layout of the two tables: kf_integrate_volume (integrate.hip)
+    acc.tile = reinterpret_cast<int*>(c->tile_max_depth); acc.max_dist = c->fuse_max_dist;
+    acc.off0 = 0; acc.w0 = kf_div_up(c->cols, 8); acc.off1 = acc.w0 * kf_div_up(c->rows, 8); acc.w1 = kf_div_up(c->cols, 16);
+  }
   hipLaunchKernelGGL(k_gate_bilateral<4>, grid, dim3(256), 0, stream, mm, raw_in, raw_out, trunced, filtered, c->cols, c->rows, tmin, tmax,
-                     ss_inv, sd_inv, sigma_depth);
+                     ss_inv, sd_inv, sigma_depth, acc);
   dim3 grid2(kf_div_up(c->cols, 64), kf_div_up(c->rows, 4));
   hipLaunchKernelGGL(k_vertices_normals, grid2, dim3(256), 0, stream, filtered, v0, n0, to_cam(cam));
   return (int)hipGetLastError();
@@ -306,7 +331,7 @@ extern "C" int kf_preprocess(kf_ctx* c, float tmin, float tmax, float sigma_pixe
     // this very frame was preprocessed ahead of time on the side stream (kf_prefetch_frame): adopt its buffers
     float* t;
     t = c->raw_depth; c->raw_depth = c->alt_raw; c->alt_raw = t;
-    t = c->trunced_depth; c->trunced_depth = c->alt_trunced; c->alt_trunced = t;
+    t = c->trunced_depth; c->trunced_depth = c->alt_trunced; c->alt_trunced = t; c->trunc_serial++;
     t = c->filtered_depth; c->filtered_depth = c->alt_filtered; c->alt_filtered = t;
     float4* q;
     q = c->new_v[0]; c->new_v[0] = c->alt_v0; c->alt_v0 = q;
@@ -315,8 +340,12 @@ extern "C" int kf_preprocess(kf_ctx* c, float tmin, float tmax, float sigma_pixe
     c->pending_mm = nullptr; c->prefetch_valid = 0;
   } else if (radius == 4) {                                    // stock sigma_pixel = 2: two fused launches instead of five
     c->prefetch_valid = 0;
+    // the tile tables can ride along when they are clear (the last fusion pass cleared them) and an integration distance is known
+    const bool build_tiles = c->tiles_clear && c->fuse_max_dist > 0.f;
     st = launch_fused_preprocess(c, c->stream, c->pending_mm, c->raw_depth, c->raw_depth, c->trunced_depth, c->filtered_depth, c->new_v[0], c->new_n[0],
-                                 tmin, tmax, sigma_pixel, sigma_depth, cam);
+                                 tmin, tmax, sigma_pixel, sigma_depth, cam, build_tiles);
+    c->trunc_serial++;
+    if (build_tiles) { c->tile_serial = c->trunc_serial; c->tile_built_dist = c->fuse_max_dist; c->tiles_clear = 0; }
     c->pending_mm = nullptr;
     if (st == 0) st = kf_pending_depth_consumed(c);
   } else {
@@ -359,7 +388,7 @@ extern "C" int kf_prefetch_frame(kf_ctx* c, const uint16_t* dev_mm, uint32_t col
   // the alternate set was last read by the frame BEFORE the current one; all of that precedes the current frame's preprocess
   KF_CHECK(hipStreamWaitEvent(c->side_stream, c->ev_preprocessed, 0));
   int st = launch_fused_preprocess(c, c->side_stream, dev_mm, nullptr, c->alt_raw, c->alt_trunced, c->alt_filtered, c->alt_v0, c->alt_n0,
-                                   tmin, tmax, sigma_pixel, sigma_depth, cam);
+                                   tmin, tmax, sigma_pixel, sigma_depth, cam, false);
   if (st) return st;
   KF_CHECK(hipEventRecord(c->ev_prefetched, c->side_stream));
   c->prefetch_src = dev_mm;

@@ -327,7 +327,7 @@ __device__ __forceinline__ bool step_prologue(const TrackArgs& a, float* s_cur, 
       if (threadIdx.x < 16) st->cur[(a.step + 1) & 1][threadIdx.x] = s_cur[threadIdx.x];
       if (threadIdx.x == 0) st->iterations += 1;
     } else if (threadIdx.x == 0) {
-      if (code == STEP_CONVERGED) { st->converged = 1; for (int i = 0; i < 16; ++i) st->pose[i] = s_cur[i]; st->tracked = 1; }
+      if (code == STEP_CONVERGED) { st->converged = 1; for (int i = 0; i < 16; ++i) st->pose[i] = s_cur[i]; kf_mat44_inverse(s_cur, st->pose_inv); st->tracked = 1; }
       else { st->status = code; st->tracked = 0; }                          // KF_TRACK_LOST_* share the STEP_LOST_* values
     }
   }
@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     for (int it = 0; it < L.iters[l]; ++it, ++step) {
       KF_STAMP(0);
       if (step > 0) {
-        fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort);
+        fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, (KF_EXP_MODE(L) == 2 && n_prev > 16) ? 16 : n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort);
         if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; __hip_atomic_store(L.stall_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } return; }
         KF_STAMP(1);
         if (KF_EXP_MODE(L) == 1) { if (threadIdx.x == 0) s_code = STEP_APPLIED; __syncthreads(); } else     // timing only: skip the 6x6 solve
@@ -600,6 +600,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   if (threadIdx.x < 27 && KF_EXP_MODE(L) != 7) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
   if (s_code != STEP_APPLIED) { if (threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; } return; }
   if (threadIdx.x < 16) st->pose[threadIdx.x] = s_cur[threadIdx.x];
+  if (threadIdx.x == 64) kf_mat44_inverse(s_cur, st->pose_inv);               // a lane of another wave: the integrate pass reads it (integrateVolume.cu:84)
   if (threadIdx.x == 0) { st->tracked = 1; st->iterations = applied + 1; }
 }
 
@@ -699,6 +700,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_track_finish(TrackArgs a) {
   }
   if (!step_prologue(a, s_cur, s_linv, s_tot, &s_code)) return;            // lost or converged: already recorded
   if (threadIdx.x < 16) st->pose[threadIdx.x] = s_cur[threadIdx.x];
+  if (threadIdx.x == 64) kf_mat44_inverse(s_cur, st->pose_inv);
   if (threadIdx.x == 0) st->tracked = 1;
 }
 
@@ -716,7 +718,9 @@ extern "C" int kf_set_pose(kf_ctx* c, const kf_mat44* pose) {
   memcpy(c->host_pinned, pose->m, 64);
   const int one = 1;
   memcpy((char*)c->host_pinned + 64, &one, sizeof(one));
+  kf_mat44_inverse(pose->m, (float*)((char*)c->host_pinned + 128));          // same arithmetic as the device's commits
   KF_CHECK(hipMemcpyAsync(c->track->pose, c->host_pinned, 64, hipMemcpyHostToDevice, c->stream));
+  KF_CHECK(hipMemcpyAsync(c->track->pose_inv, (char*)c->host_pinned + 128, 64, hipMemcpyHostToDevice, c->stream));
   // a pose supplied by the caller counts as a successful localisation: the device-predicated integrate (transform == NULL) fuses with it
   KF_CHECK(hipMemcpyAsync(&c->track->tracked, (char*)c->host_pinned + 64, sizeof(one), hipMemcpyHostToDevice, c->stream));
   KF_CHECK(hipStreamSynchronize(c->stream));     // the pinned staging words are reused

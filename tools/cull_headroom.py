@@ -44,3 +44,22 @@ print("%s: voxels updated %d (library %d); bricks with >= 1 updating voxel %d; q
     cfg, n_upd, st["updated_last"], live_bricks, st["bricks_active"], 100.0 * (st["bricks_active"] / live_bricks - 1)))
 print("of the bricks that need fusing: %d hold <= 64 updating voxels, %d hold 65-256, %d hold 257-511, %d are full" % (
     h[1:65].sum(), h[65:257].sum(), h[257:512].sum(), h[512]))
+
+# ---- finer than a brick: would a second cull level pay?  4x4x4 octants (64 voxels) of the bricks that need fusing -------------------
+live_oct = 0; upd_in_live_oct = 0; oct_total = 0
+for z0 in range(0, res, 8):
+    z = ax[z0:z0 + 8].view(8, 1, 1); y = ax.view(1, res, 1); x = ax.view(1, 1, res)
+    pfx = Tinv[0, 0] * x + Tinv[0, 1] * y + Tinv[0, 2] * z + Tinv[0, 3]
+    pfy = Tinv[1, 0] * x + Tinv[1, 1] * y + Tinv[1, 2] * z + Tinv[1, 3]
+    pfz = Tinv[2, 0] * x + Tinv[2, 1] * y + Tinv[2, 2] * z + Tinv[2, 3]
+    ok = pfz > 0
+    sx = torch.floor(pfx * fx / pfz + cx + 0.5).long(); sy = torch.floor(pfy * fy / pfz + cy + 0.5).long()
+    ok &= (sx >= 1) & (sx < cols - 1) & (sy >= 1) & (sy < rows - 1)
+    d = depth[sy.clamp(0, rows - 1), sx.clamp(0, cols - 1)]
+    upd = ok & (d != 0) & (d < maxd) & ((d - pfz) > -trunc)
+    o = upd.view(2, 4, res // 4, 4, res // 4, 4).sum(dim=(1, 3, 5))          # [2, res/4, res/4] octant counts
+    brick_live = (o.view(2, res // 8, 2, res // 8, 2).sum(dim=(0, 2, 4)) > 0)  # [res/8, res/8]
+    bl = brick_live.view(1, res // 8, 1, res // 8, 1).expand(2, res // 8, 2, res // 8, 2).reshape(2, res // 4, res // 4)
+    oct_total += int(bl.sum()); live_oct += int(((o > 0) & bl).sum()); upd_in_live_oct += int(o[(o > 0) & bl].sum())
+print("octants (4^3) of those bricks: %d of %d hold an updating voxel (%.0f %%); %.1f of 64 voxels update in such an octant" % (
+    live_oct, oct_total, 100.0 * live_oct / oct_total, upd_in_live_oct / max(live_oct, 1)))

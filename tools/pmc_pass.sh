@@ -3,7 +3,7 @@
 TAG=$1; CFG=$2; CTRS=$3; KSUB=${4:-k_integrate_pairs}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $CTRS -d $OUT --output-format csv -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --config $CFG > $OUT/bench.log 2>&1 || { tail -5 $OUT/bench.log; exit 1; }
+rocprofv3 --pmc $CTRS -d $OUT --output-format csv -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-scaling-reference --config $CFG > $OUT/bench.log 2>&1 || { tail -5 $OUT/bench.log; exit 1; }
 python3 - "$OUT" "$KSUB" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/*/*counter_collection.csv")[0]
