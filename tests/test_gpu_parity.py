@@ -441,3 +441,49 @@ def test_reset_volume_equals_fresh_context():
     assert np.array_equal(bits(got[1]), bits(want[1])) and np.array_equal(bits(got[2]), bits(want[2]))
     assert len(got[3]) == len(want[3]) > 1000 and got[3].tobytes() == want[3].tobytes()
     a.close(); b.close()
+
+
+def test_tile_tables_follow_every_call_order():
+    """The integrate cull reads per-tile depth maxima that normally ride in the fused preprocess kernel (built for the distance the
+    previous integrate used) and are cleared by the fusion pass.  Whatever the call order -- a changed distance, two integrates of
+    one frame, two preprocesses before an integrate, the per-call wrappers, an uploaded depth map -- the update count must equal
+    the oracle's (the fallback rebuilds the tables whenever they do not describe the current depth map and distance)."""
+    size, res, cam = 3.0, 64, mid_cam()
+    ocam, kcam = O.Cam.make(*cam), K.camera(*cam)
+    ctx = K.Context(kcam, res, size, P["volume_max_weight"], levels=3)
+    ovol = O.OVolume(res, size, P["volume_max_weight"])
+    trunc = 0.1
+
+    def frame(k):
+        pose = S.trajectory_pose(2 * k, size).astype(np.float32)
+        mm = S.render_depth_mm(pose, cam, size)
+        tr, fl, v, n = oracle_preprocess(mm, ocam)[1:]
+        return pose, mm, tr, n
+
+    def both(pose, tr, n, dist):
+        n_o = O.integrate(ovol, tr, n, None, False, False, pose, trunc, dist, ocam, ocam)
+        ctx.integrate(pose, trunc, dist)
+        assert ctx.stats()["updated_last"] == n_o and n_o > 1000, (dist, n_o)
+
+    def pre(mm):
+        ctx.upload_depth_mm(mm)
+        ctx.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+
+    pose, mm, tr, n = frame(0); pre(mm); both(pose, tr, n, 2.5)            # first call: no distance known yet -> fallback
+    pose, mm, tr, n = frame(1); pre(mm); both(pose, tr, n, 2.5)            # tables built by the preprocess kernel
+    both(pose, tr, n, 2.5)                                                  # same frame again: tables were cleared -> fallback
+    pose, mm, tr, n = frame(2); pre(mm); both(pose, tr, n, 1.5)            # built for 2.5, asked for 1.5 -> fallback
+    pose, mm, tr, n = frame(3); pre(mm); both(pose, tr, n, 1.5)            # built for 1.5
+    pose, mm, tr, n = frame(4); pre(mm); pre(mm); both(pose, tr, n, 1.5)   # second preprocess finds the tables in use
+    pose, mm, tr, n = frame(5)
+    ctx.upload_depth_mm(mm); ctx.trunc_depth(P["depth_trunc_min"], P["depth_trunc_max"])   # per-call wrapper: no tables
+    both(pose, tr, n, 1.5)
+    pose, mm, tr, n = frame(6); pre(mm)
+    pose7, mm7, tr7, n7 = frame(7)
+    ctx.upload_map(K.MAP_TRUNCED_DEPTH, 0, tr7)                             # the depth map changes behind the tables' back
+    both(pose7, tr7, n7, 1.5)
+    t, w = ctx.download_volume()
+    assert np.array_equal(bits(t), bits(ovol.tsdf)) and np.array_equal(bits(w), bits(ovol.weight))
+    st = ctx.stats()
+    assert st["frames_fused"] == 8 and st["weight_gt0"] == O.count_weight_gt0(ovol)
+    ctx.close()
