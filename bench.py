@@ -177,6 +177,45 @@ def pcie_inclusive(wl, frames_mm, n_frames=100, warmup=10):
                 note="every frame uploaded from host memory over PCIe inside the timed region (kf_upload_depth_mm)")
 
 
+def roofline_extra(pipe, run, first_frame, res, size, n_frames=20):
+    """Raycast and marching cubes against the HBM roofline, as SURVEY.md section 8d defines their bytes.
+    raycast: what the REFERENCE's march would read -- 8 B per sample from t_min to the first crossing (or t_max) plus 64 voxels
+    x 8 B per evaluated hit -- counted on the device (kf_read_work_counters) over n_frames extra frames, / the kernel's own time.
+    The HIP kernel skips empty space through its bit tables, so its real traffic is far below this figure: the quotient says
+    how fast the reference's work is DONE, not how busy HBM is (the march is latency-bound).
+    marching cubes: TOUCHED bytes -- 256-cell blocks whose neighbourhood holds a negative voxel x 2 KiB + 72 B per triangle --
+    / the extraction's time (count + scan + emit)."""
+    c = pipe.ctx
+    c.stage_timers((1 << 7) | (1 << 6) | (1 << 16))
+    run(first_frame, n_frames)
+    pipe.sync()
+    ms, cnt = c.read_stage_ms()
+    steps, hits, _, _ = c.work_counters()
+    rc_ms = float(ms[7]) / max(int(cnt[7]), 1)
+    rc_bytes = (steps * 8.0 + hits * 64 * 8.0) / n_frames
+    out = dict(raycast=dict(kernel="k_raycast", bound="latency (L2 gathers)", ms=round(rc_ms, 5), reference_samples_per_frame=int(steps / n_frames),
+                            hits_per_frame=int(hits / n_frames), algorithmic_bytes_per_launch=int(rc_bytes),
+                            achieved=round(rc_bytes / (rc_ms * 1e-3) / 1e9, 2) if rc_ms > 0 else None, unit="GB/s",
+                            frac=round(rc_bytes / (rc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if rc_ms > 0 else None))
+    c.stage_timers((1 << 6) | (1 << 16))
+    c.clear_triangles()
+    c.marching_cubes(300.0 * size / res)
+    pipe.sync()
+    ms, cnt = c.read_stage_ms()
+    _, _, blocks, tris = c.work_counters()
+    mc_ms = float(ms[6]) / max(int(cnt[6]), 1)
+    mc_bytes = blocks * 2048.0 + tris * 72.0
+    out["marching_cubes"] = dict(kernels="k_mc_count + k_mc_scan + k_mc_emit", bound="hbm", ms=round(mc_ms, 5), blocks_visited=int(blocks),
+                                 blocks_total=int((res ** 3 + 255) // 256), triangles=int(tris), touched_bytes=int(mc_bytes),
+                                 dense_bytes=int(res ** 3 * 8 + tris * 72),
+                                 achieved=round(mc_bytes / (mc_ms * 1e-3) / 1e9, 2) if mc_ms > 0 else None, unit="GB/s",
+                                 frac=round(mc_bytes / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if mc_ms > 0 else None,
+                                 dense_equivalent_frac=round((res ** 3 * 8 + tris * 72) / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if mc_ms > 0 else None)
+    c.clear_triangles()
+    c.stage_timers(0)
+    return out
+
+
 STAGE_NAMES = ["upload", "preprocess", "track", "integrate", "raycast", "integrate_kernel", "mcubes", "raycast_kernel"]
 
 
@@ -248,7 +287,7 @@ def main():
     slab = not (world == 1 and not args.force_slab)
     if not slab:
         from hybkinectfu_amd.pipeline import SingleGpuPipeline as Pipe
-        pipe = Pipe(kcam, res, size, wl, device=device)
+        pipe = Pipe(kcam, res, size, wl, device=device, max_triangles=(4_000_000 if not args.no_extras else 0))
     else:
         from hybkinectfu_amd.pipeline import SlabPipeline as Pipe
         pipe = Pipe(kcam, res, size, wl, rank=rank, world=world, device=device, icp_mode=args.icp_mode)
@@ -352,6 +391,7 @@ def main():
         out["stage_us"] = {STAGE_NAMES[i]: round(1000.0 * float(sm[i]) / max(int(sc[i]), 1), 2) for i in (1, 2, 3, 4, 5)}
         out["stage_us"]["note"] = "mean device time per frame, HIP events around each stage, 50 frames after the timed region"
         pipe.stage_timers(0)
+        out["roofline_extra"] = roofline_extra(pipe, run, args.warmup + args.steps + 50, res, size)
     if world == 1 and args.config == "auto" and not args.force_slab and not args.no_scaling_reference:
         pipe.close()
         out["multi_gpu_workload_on_1_gpu"] = single_gpu_reference("c4")      # what --gpus 2/4/8 should be compared with

@@ -36,7 +36,7 @@ extern "C" int kf_destroy(kf_ctx* c) {
   if (c->own_stream) hipStreamSynchronize(c->own_stream);
   void* ptrs[] = {c->up_dev[0], c->up_dev[1], c->raw_depth, c->trunced_depth, c->filtered_depth, c->raw_rgb, c->raycast_rgb, c->icp_partials, c->icp_loop_slots,
                   c->track, c->counters, c->grid_barrier, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macro, c->vol.negbits, c->active_bricks,
-                  c->tile_max_depth, c->triangles, c->mc_block_counts};
+                  c->tile_max_depth, c->triangles, c->mc_block_counts, c->mc_list, c->mc_nbr_bits, c->mc_partials};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->up_stream) { hipStreamSynchronize(c->up_stream); hipStreamDestroy(c->up_stream); }
   for (int i = 0; i < 2; ++i) {
@@ -467,7 +467,25 @@ extern "C" int kf_stage_timers(kf_ctx* c, int enable) {
   for (int s = 0; s < 8; ++s) { evt_fold(c, s); c->ev_ms[s] = 0.0; c->ev_count[s] = 0; c->ev_seen[s] = 0; c->ev_open[s] = 0; }
   c->timers_enabled = enable & 0xFF;
   c->timers_period = ((enable >> 8) & 0xFF) > 1 ? (unsigned)((enable >> 8) & 0xFF) : 1u;
+  c->count_work = (enable >> 16) & 1;
+  if (c->count_work) KF_CHECK(hipMemsetAsync(c->counters->rc_steps, 0, 3 * 64 * 16 * sizeof(unsigned long long), c->stream));
   return 0;
+}
+// out[0] = raycast samples of the reference's march, out[1] = rays whose crossing was evaluated, out[2] = 256-cell marching-cubes
+// blocks visited, out[3] = triangles in the buffer -- accumulated since kf_stage_timers(... | 1 << 16).  Blocking.
+extern "C" int kf_read_work_counters(kf_ctx* c, uint64_t out[4]) {
+  if (!c || !out) return KF_ERR_ARG;
+  KfCounters* h = (KfCounters*)malloc(sizeof(KfCounters));
+  if (!h) return KF_ERR_ALLOC;
+  hipError_t e = hipMemcpyAsync(h, c->counters, sizeof(KfCounters), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) {
+    out[0] = out[1] = out[2] = 0;
+    for (int i = 0; i < 64; ++i) { out[0] += h->rc_steps[i * 16]; out[1] += h->rc_hits[i * 16]; out[2] += h->mc_blocks[i * 16]; }
+    out[3] = h->n_triangles;
+  }
+  free(h);
+  return (int)e;
 }
 // out_ms[s] = accumulated milliseconds of stage s; counts[s] (may be null) = number of timed intervals.  Blocking.
 extern "C" int kf_read_stage_ms(kf_ctx* c, float out_ms[8], uint32_t* counts) {

@@ -92,6 +92,11 @@ struct KfCounters {
   unsigned pad2_[2];
   unsigned long long upd_shard[2][64 * 16];  // this integrate's update count, slot s at [s*16]
   unsigned long long upd_total_shard[64];    // folded sum of the earlier integrates
+  // work counters of the measurement passes (kf_stage_timers bit 16 turns them on, kf_read_work_counters reads them): sharded like
+  // the update counts, one 128-byte line per shard
+  unsigned long long rc_steps[64 * 16];      // raycast: samples the reference's march takes (per ray: up to its first crossing or t_max)
+  unsigned long long rc_hits[64 * 16];       // raycast: rays whose crossing was evaluated (trilinear + gradient taps)
+  unsigned long long mc_blocks[64 * 16];     // marching cubes: 256-cell blocks that passed the has-negative neighbourhood test (count pass)
 };
 
 struct kf_ctx {
@@ -142,9 +147,11 @@ struct kf_ctx {
   int tiles_clear, int_parity, last_parity;
   kf_triangle* triangles; uint32_t max_triangles;
   unsigned* mc_block_counts; size_t mc_blocks_cap;
+  unsigned* mc_list; unsigned* mc_nbr_bits; unsigned* mc_partials;   // extraction scratch, allocated by the first kf_marching_cubes
   void* host_pinned;                  // small pinned staging buffer (4 KiB); byte KF_PINNED_STALL_WORD: the ICP loop's stall word
   // per-stage hipEvent timers (KF_STAGE_*): bit s of timers_enabled turns stage s on
   int timers_enabled;
+  int count_work;                     // kf_stage_timers bit 16: the raycast / marching-cubes work counters are maintained
   unsigned timers_period;             // time every timers_period-th interval of a stage (>= 1)
   unsigned ev_seen[8]; int ev_open[8];
   hipEvent_t ev[8][2][64];            // [stage][begin/end][ring]

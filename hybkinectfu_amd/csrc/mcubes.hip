@@ -2,9 +2,10 @@
 // src/cuda/marchingcube.cu:5-164; tables src/cuda/marchingcube_table.h; MarchingcubeData src/cuda/MarchingcubeData.h).
 //
 // The reference appends triangles with one global atomicAdd, so its output ORDER is nondeterministic (and its
-// check-then-add can overshoot the buffer, marchingcube.cu:29-32).  Here extraction is two deterministic passes:
-//   count  : one lane per cell, 256 consecutive cells (z, y, x order) per workgroup -> per-workgroup triangle count;
-//   scan   : exclusive prefix over workgroups;
+// check-then-add can overshoot the buffer, marchingcube.cu:29-32).  Here extraction is deterministic:
+//   mark   : which 256-cell blocks (z, y, x order) can hold surface at all -> an unordered list (brick flags only, no voxel read);
+//   count  : one lane per cell of the listed blocks -> per-block triangle count;
+//   scan   : exclusive prefix over ALL blocks in order (three parallel steps);
 //   emit   : the same cell logic again, intra-workgroup prefix, triangle k of cell (x,y,z) lands at a fixed index.
 // The canonical order is (z, y, x, k) -- identical for 1 GPU and for concatenated z-slabs.
 // Space skipping: a cell can only produce triangles if a corner SDF is negative, which needs a negative voxel in the
@@ -26,7 +27,13 @@ struct McArgs {
   unsigned n_blocks;
   kf_triangle* tris; unsigned max_tris;
   KfCounters* cnt;
+  int count_work;                // measurement passes: count the blocks that pass the neighbourhood test (kf_stage_timers bit 16)
+  unsigned* nbr_bits;            // one bit per stored brick: some brick of its 3x3x3 neighbourhood holds a negative voxel
+  unsigned* list;                // blocks that may hold surface, in no particular order (their output position comes from the scan)
+  unsigned* n_list;              // length of `list` (device)
+  unsigned* partials;            // per 4096-block chunk: sum of its block counts, then the exclusive prefix of those sums
 };
+#define MC_CHUNK 4096u             // block counts scanned by one workgroup (16 per lane)
 
 __device__ __forceinline__ float sel8(const float d[8], int k) {
   float r = d[0];
@@ -135,104 +142,179 @@ __device__ __forceinline__ kf_vertex edge_vertex(const McArgs& a, const CellEval
   return r;
 }
 
-// workgroup-level early out: 256 consecutive cells along x (then y) share at most (256/8 + 2) x 2 x 2 bricks
-__device__ __forceinline__ bool block_may_have_surface(const McArgs& a, size_t first_cell, int* s_any) {
-  const KfVolume& v = a.vol;
-  const int R = v.res;
-  if (threadIdx.x == 0) *s_any = 0;
-  __syncthreads();
-  // probe the cells at an 4-cell stride (+ the last one): every neighbourhood brick of every cell is covered
-  const size_t cell_i = first_cell + threadIdx.x;
-  const size_t n_cells = (size_t)(a.z1 - a.z0) * R * R;
-  if (cell_i < n_cells && ((threadIdx.x & 3) == 0 || threadIdx.x == 255)) {
-    const int x = (int)(cell_i % R), y = (int)((cell_i / R) % R), z = a.z0 + (int)(cell_i / ((size_t)R * R));
-    if (neighbourhood_has(v, x, y, z, KF_FLAG_HASNEG)) *s_any = 1;
+// ---- which blocks need visiting ------------------------------------------------------------------------------------------------
+// A cell can produce triangles only if a voxel within +-2 cells of it is negative, i.e. only if one of the 3x3x3 bricks around its
+// own brick carries KF_FLAG_HASNEG.  k_mc_dilate writes that as one bit per stored brick (from the packed has-negative bits, 27
+// cached word loads per brick); k_mc_mark tests each 256-cell block -- a run of cells in (z, y, x) order: one x-row segment at
+// 512^3, several short rows in a small volume -- against the bits of the bricks it crosses and appends the survivors to a list.
+// The list's order does not matter: a block's triangles land where the prefix sum of the block counts says.
+__global__ void __launch_bounds__(256) k_mc_dilate(KfVolume v, unsigned* __restrict__ nbr_bits, unsigned n_slots) {
+  const unsigned slot = blockIdx.x * 256u + threadIdx.x;
+  bool any = false;
+  if (slot < n_slots) {
+    const int nb = v.nb;
+    const int bx = (int)(slot % (unsigned)nb), by = (int)((slot / (unsigned)nb) % (unsigned)nb), bz = (int)(slot / ((unsigned)nb * nb)) + v.bz0;
+    for (int dz = -1; dz <= 1; ++dz) {
+      const int z = bz + dz;
+      if (z < v.bz0 || z >= v.bz1) continue;
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int y = by + dy;
+        if (y < 0 || y >= nb) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int x = bx + dx;
+          if (x < 0 || x >= nb) continue;
+          const size_t s2 = kf_brick_slot(v, x, y, z);
+          any = any || ((v.negbits[s2 >> 5] >> (s2 & 31u)) & 1u);
+        }
+      }
+    }
   }
-  __syncthreads();
-  return *s_any != 0;
+  const unsigned long long m = __ballot(any);                     // a wave = 64 consecutive slots = two whole words
+  if ((threadIdx.x & 63) == 0 && slot < n_slots) { nbr_bits[slot >> 5] = (unsigned)m; nbr_bits[(slot >> 5) + 1] = (unsigned)(m >> 32); }
 }
 
+__global__ void __launch_bounds__(256) k_mc_mark(McArgs a) {
+  const KfVolume& v = a.vol;
+  const unsigned R = (unsigned)v.res;
+  const unsigned blk = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
+  bool live = false;
+  if (blk < a.n_blocks) {
+    const size_t n_cells = (size_t)(a.z1 - a.z0) * R * R;
+    size_t c = (size_t)blk * 256, end = c + 256 < n_cells ? c + 256 : n_cells;
+    while (c < end && !live) {                                     // one iteration per x-row the block crosses
+      const unsigned x = (unsigned)(c % R), y = (unsigned)((c / R) % R), z = (unsigned)a.z0 + (unsigned)(c / ((size_t)R * R));
+      const unsigned run = (unsigned)((end - c) < (size_t)(R - x) ? (end - c) : (size_t)(R - x));
+      const size_t s0 = kf_brick_slot(v, (int)(x >> 3), (int)(y >> 3), (int)(z >> 3));
+      for (unsigned b = 0; b <= ((x + run - 1) >> 3) - (x >> 3); ++b) { const size_t s2 = s0 + b; live = live || ((a.nbr_bits[s2 >> 5] >> (s2 & 31u)) & 1u); }
+      c += run;
+    }
+  }
+  const unsigned long long m = __ballot(live);
+  unsigned base = 0;
+  if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(a.n_list, (unsigned)__popcll(m));
+  base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+  if (live) a.list[base + (unsigned)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = blk;
+}
+
+// count pass: one workgroup per listed block (grid-stride), one lane per cell
 __global__ void __launch_bounds__(256) k_mc_count(McArgs a) {
-  __shared__ int s_any; __shared__ unsigned s_sum[4];
+  __shared__ unsigned s_sum[4];
   const int R = a.vol.res;
-  const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;      // 2-D grid: a 2048^3 volume has more 256-cell blocks than one grid dimension may hold threads
-  if (blk >= a.n_blocks) return;
-  const size_t first = (size_t)blk * 256;
-  if (!block_may_have_surface(a, first, &s_any)) { if (threadIdx.x == 0) a.block_counts[blk] = 0; return; }
-  const size_t i = first + threadIdx.x;
   const size_t n_cells = (size_t)(a.z1 - a.z0) * R * R;
-  int n = 0;
-  if (i < n_cells) { CellEval e; n = eval_cell(a, (int)(i % R), (int)((i / R) % R), a.z0 + (int)(i / ((size_t)R * R)), e); }
-  float s = kf_wave_sum((float)n);
-  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = (unsigned)s;
-  __syncthreads();
-  if (threadIdx.x == 0) a.block_counts[blk] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+  const unsigned n_list = *a.n_list;
+  for (unsigned li = blockIdx.x; li < n_list; li += gridDim.x) {
+    const unsigned blk = a.list[li];
+    const size_t i = (size_t)blk * 256 + threadIdx.x;
+    int n = 0;
+    if (i < n_cells) { CellEval e; n = eval_cell(a, (int)(i % R), (int)((i / R) % R), a.z0 + (int)(i / ((size_t)R * R)), e); }
+    const float s = kf_wave_sum((float)n);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = (unsigned)s;
+    __syncthreads();
+    if (threadIdx.x == 0) a.block_counts[blk] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    __syncthreads();
+  }
 }
 
-// exclusive scan of block_counts[0..n) in place by ONE workgroup (chunks of 1024), total -> block_counts[n]
-__global__ void __launch_bounds__(256) k_mc_scan(unsigned* counts, unsigned n, KfCounters* cnt) {
+// ---- exclusive prefix sum of the block counts, in place, in three parallel steps ----------------------------------------------
+// (1) every workgroup sums its chunk of MC_CHUNK counts; (2) one workgroup turns the chunk sums into their exclusive prefix (a
+// few thousand values even at 2048^3); (3) every workgroup rescans its chunk on top of its offset.  total -> counts[n].
+__device__ __forceinline__ unsigned mc_block_excl_scan(unsigned local, unsigned* s_wave, unsigned& total) {
+  unsigned inc = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const unsigned t = __shfl_up(inc, off, 64); if ((threadIdx.x & 63) >= (unsigned)off) inc += t; }
+  if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  unsigned wave_off = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += s_wave[w];
+  total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  __syncthreads();
+  return wave_off + inc - local;
+}
+__global__ void __launch_bounds__(256) k_mc_scan_reduce(const unsigned* __restrict__ counts, unsigned n, unsigned* __restrict__ partials) {
+  __shared__ unsigned s_wave[4];
+  const unsigned i0 = blockIdx.x * MC_CHUNK + threadIdx.x * 16u;
+  unsigned local = 0;
+  if (i0 + 16u <= n) {
+    const uint4* p = reinterpret_cast<const uint4*>(counts + i0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint4 q = p[k]; local += q.x + q.y + q.z + q.w; }
+  } else for (unsigned k = 0; k < 16u; ++k) if (i0 + k < n) local += counts[i0 + k];
+  unsigned total;
+  mc_block_excl_scan(local, s_wave, total);
+  if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(256) k_mc_scan_partials(unsigned* partials, unsigned n_chunks, unsigned* counts, unsigned n, KfCounters* cnt) {
   __shared__ unsigned s_wave[4]; __shared__ unsigned s_carry;
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
-  for (unsigned base = 0; base < n; base += 1024) {
-    const unsigned i0 = base + threadIdx.x * 4;
+  for (unsigned base = 0; base < n_chunks; base += 1024u) {
+    const unsigned i0 = base + threadIdx.x * 4u;
     unsigned v[4]; unsigned local = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { v[k] = (i0 + k < n) ? counts[i0 + k] : 0u; local += v[k]; }
-    // wave inclusive scan of `local`
-    unsigned inc = local;
+    for (int k = 0; k < 4; ++k) { v[k] = (i0 + k < n_chunks) ? partials[i0 + k] : 0u; local += v[k]; }
+    unsigned total;
+    unsigned excl = s_carry + mc_block_excl_scan(local, s_wave, total);
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { unsigned t = __shfl_up(inc, off, 64); if ((threadIdx.x & 63) >= off) inc += t; }
-    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = inc;
+    for (int k = 0; k < 4; ++k) { if (i0 + k < n_chunks) partials[i0 + k] = excl; excl += v[k]; }
     __syncthreads();
-    unsigned wave_off = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += s_wave[w];
-    unsigned excl = s_carry + wave_off + inc - local;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { if (i0 + k < n) counts[i0 + k] = excl; excl += v[k]; }
-    __syncthreads();
-    if (threadIdx.x == 255) s_carry = excl;
+    if (threadIdx.x == 0) s_carry += total;
     __syncthreads();
   }
   if (threadIdx.x == 0) { counts[n] = s_carry; cnt->scan_total = s_carry; }
 }
+__global__ void __launch_bounds__(256) k_mc_scan_apply(unsigned* __restrict__ counts, unsigned n, const unsigned* __restrict__ partials) {
+  __shared__ unsigned s_wave[4];
+  const unsigned i0 = blockIdx.x * MC_CHUNK + threadIdx.x * 16u;
+  unsigned v[16]; unsigned local = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { v[k] = (i0 + k < n) ? counts[i0 + k] : 0u; local += v[k]; }
+  unsigned total;
+  unsigned excl = partials[blockIdx.x] + mc_block_excl_scan(local, s_wave, total);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { if (i0 + k < n) counts[i0 + k] = excl; excl += v[k]; }
+}
 
+// emit pass: the same cell logic again for the listed blocks that counted triangles, intra-workgroup prefix, fixed output index
 __global__ void __launch_bounds__(256) k_mc_emit(McArgs a) {
   __shared__ unsigned s_wave[4];
-  const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
-  if (blk >= a.n_blocks) return;
-  const unsigned my_base = a.block_counts[blk], my_count = a.block_counts[blk + 1] - my_base;
-  if (my_count == 0) return;
   const int R = a.vol.res;
-  const size_t i = (size_t)blk * 256 + threadIdx.x;
   const size_t n_cells = (size_t)(a.z1 - a.z0) * R * R;
-  CellEval e; e.ntri = 0;
-  int n = 0;
-  if (i < n_cells) n = eval_cell(a, (int)(i % R), (int)((i / R) % R), a.z0 + (int)(i / ((size_t)R * R)), e);
-  unsigned inc = (unsigned)n;
+  const unsigned n_list = *a.n_list;
+  for (unsigned li = blockIdx.x; li < n_list; li += gridDim.x) {
+    const unsigned blk = a.list[li];
+    const unsigned my_base = a.block_counts[blk], my_count = a.block_counts[blk + 1] - my_base;
+    if (my_count == 0) continue;                                                  // uniform
+    const size_t i = (size_t)blk * 256 + threadIdx.x;
+    CellEval e; e.ntri = 0;
+    int n = 0;
+    if (i < n_cells) n = eval_cell(a, (int)(i % R), (int)((i / R) % R), a.z0 + (int)(i / ((size_t)R * R)), e);
+    unsigned inc = (unsigned)n;
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) { unsigned t = __shfl_up(inc, off, 64); if ((threadIdx.x & 63) >= off) inc += t; }
-  if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = inc;
-  __syncthreads();
-  unsigned off0 = inc - (unsigned)n;
-  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off0 += s_wave[w];
-  // append after what the buffer already holds (the reference never clears its counter: MarchingcubeData.h:56,99)
-  const unsigned start = a.cnt->n_triangles + my_base + off0;
-  for (int t = 0; t < n; ++t) {
-    const unsigned dst = start + (unsigned)t;
-    if (dst >= a.max_tris) break;                                                // marchingcube.cu:29-31
-    kf_triangle tri;
-    tri.v0 = edge_vertex(a, e, (unsigned)((e.word >> (12 * t)) & 0xF));
-    tri.v1 = edge_vertex(a, e, (unsigned)((e.word >> (12 * t + 4)) & 0xF));
-    tri.v2 = edge_vertex(a, e, (unsigned)((e.word >> (12 * t + 8)) & 0xF));
-    a.tris[dst] = tri;
+    for (int off = 1; off < 64; off <<= 1) { unsigned t = __shfl_up(inc, off, 64); if ((threadIdx.x & 63) >= off) inc += t; }
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    unsigned off0 = inc - (unsigned)n;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off0 += s_wave[w];
+    __syncthreads();
+    // append after what the buffer already holds (the reference never clears its counter: MarchingcubeData.h:56,99)
+    const unsigned start = a.cnt->n_triangles + my_base + off0;
+    for (int t = 0; t < n; ++t) {
+      const unsigned dst = start + (unsigned)t;
+      if (dst >= a.max_tris) break;                                                // marchingcube.cu:29-31
+      kf_triangle tri;
+      tri.v0 = edge_vertex(a, e, (unsigned)((e.word >> (12 * t)) & 0xF));
+      tri.v1 = edge_vertex(a, e, (unsigned)((e.word >> (12 * t + 4)) & 0xF));
+      tri.v2 = edge_vertex(a, e, (unsigned)((e.word >> (12 * t + 8)) & 0xF));
+      a.tris[dst] = tri;
+    }
   }
 }
 
-__global__ void k_mc_finish(KfCounters* cnt, unsigned max_tris) {
+__global__ void k_mc_finish(KfCounters* cnt, unsigned max_tris, const unsigned* n_list, int count_work) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     unsigned long long t = (unsigned long long)cnt->n_triangles + cnt->scan_total;
     cnt->n_triangles = (unsigned)(t > max_tris ? max_tris : t);
+    if (count_work) cnt->mc_blocks[0] += *n_list;
   }
 }
 
@@ -245,12 +327,32 @@ extern "C" int kf_marching_cubes(kf_ctx* c, int has_color, float thr) {
   const size_t n_cells = (size_t)(a.z1 - a.z0) * c->vol.res * c->vol.res;
   a.n_blocks = (unsigned)((n_cells + 255) / 256);
   if (a.n_blocks > c->mc_blocks_cap) return KF_ERR_STATE;
+  const unsigned n_chunks = (a.n_blocks + MC_CHUNK - 1) / MC_CHUNK;
+  if (!c->mc_list) {                                       // extraction scratch: allocated by the first extraction, not by every context
+    KF_CHECK(hipSetDevice(c->cfg.device));
+    KF_CHECK(hipMalloc((void**)&c->mc_list, (c->mc_blocks_cap + 1) * sizeof(unsigned)));                 // [0] = length, then the block ids
+    KF_CHECK(hipMalloc((void**)&c->mc_nbr_bits, (c->n_stored_bricks / 32 + 4) * sizeof(unsigned)));
+    KF_CHECK(hipMalloc((void**)&c->mc_partials, ((c->mc_blocks_cap + MC_CHUNK - 1) / MC_CHUNK + 1) * sizeof(unsigned)));
+  }
   a.block_counts = c->mc_block_counts; a.tris = c->triangles; a.max_tris = c->max_triangles; a.cnt = c->counters;
-  const unsigned gx = a.n_blocks < (1u << 20) ? a.n_blocks : (1u << 20), gy = (a.n_blocks + gx - 1) / gx;
-  hipLaunchKernelGGL(k_mc_count, dim3(gx, gy), dim3(256), 0, c->stream, a);
-  hipLaunchKernelGGL(k_mc_scan, dim3(1), dim3(256), 0, c->stream, a.block_counts, a.n_blocks, c->counters);
-  hipLaunchKernelGGL(k_mc_emit, dim3(gx, gy), dim3(256), 0, c->stream, a);
-  hipLaunchKernelGGL(k_mc_finish, dim3(1), dim3(64), 0, c->stream, c->counters, c->max_triangles);
+  a.count_work = c->count_work;
+  a.nbr_bits = c->mc_nbr_bits; a.n_list = c->mc_list; a.list = c->mc_list + 1; a.partials = c->mc_partials;
+  kf_evt_begin(c, KF_STAGE_MCUBES);
+  KF_CHECK(hipMemsetAsync(c->mc_block_counts, 0, ((size_t)a.n_blocks + 1) * sizeof(unsigned), c->stream));
+  KF_CHECK(hipMemsetAsync(c->mc_list, 0, sizeof(unsigned), c->stream));
+  const unsigned n_slots = (unsigned)c->n_stored_bricks;
+  hipLaunchKernelGGL(k_mc_dilate, dim3((n_slots + 255) / 256), dim3(256), 0, c->stream, c->vol, c->mc_nbr_bits, n_slots);
+  const unsigned mark_wgs = (a.n_blocks + 255) / 256;
+  const unsigned mgx = mark_wgs < 65535u ? mark_wgs : 65535u, mgy = (mark_wgs + mgx - 1) / mgx;
+  hipLaunchKernelGGL(k_mc_mark, dim3(mgx, mgy), dim3(256), 0, c->stream, a);
+  const unsigned walk = (unsigned)c->num_cus * 8u;         // persistent workgroups walking the list
+  hipLaunchKernelGGL(k_mc_count, dim3(walk), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_mc_scan_reduce, dim3(n_chunks), dim3(256), 0, c->stream, a.block_counts, a.n_blocks, a.partials);
+  hipLaunchKernelGGL(k_mc_scan_partials, dim3(1), dim3(256), 0, c->stream, a.partials, n_chunks, a.block_counts, a.n_blocks, c->counters);
+  hipLaunchKernelGGL(k_mc_scan_apply, dim3(n_chunks), dim3(256), 0, c->stream, a.block_counts, a.n_blocks, a.partials);
+  hipLaunchKernelGGL(k_mc_emit, dim3(walk), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_mc_finish, dim3(1), dim3(64), 0, c->stream, c->counters, c->max_triangles, c->mc_list, c->count_work);
+  kf_evt_end(c, KF_STAGE_MCUBES);
   return (int)hipGetLastError();
 }
 

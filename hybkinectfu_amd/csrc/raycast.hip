@@ -25,6 +25,7 @@ struct RaycastArgs {
   int has_color;
   int neg_words;                 // words of vol.negbits to keep in LDS (0: the table does not fit -> brick flags are read from global memory)
   int exp_mode;                  // timing experiments only (KF_RAYCAST_EXP): 1 = stop at the crossing without evaluating it
+  KfCounters* work;              // measurement passes only (kf_stage_timers bit 16): count the reference march's samples and the hits
 };
 
 // gradientForPoint raycastingVolume.cu:16-42: bounds tested on the LAST sample's voxel, taps taken around the vertex.
@@ -129,6 +130,7 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
   float tmax = fminf(fminf(((dir.x > 0 ? S : 0.f) - org.x) / dir.x, ((dir.y > 0 ? S : 0.f) - org.y) / dir.y), ((dir.z > 0 ? S : 0.f) - org.z) / dir.z);
   tmin = fmaxf(tmin, a.near_plane / cam_dir.z);
   tmax = fminf(tmax, a.far_plane / cam_dir.z);
+  const float ref_tmin = tmin, ref_tmax = tmax;
 #ifdef KF_EXPERIMENTS
   unsigned long long st1 = __builtin_amdgcn_s_memtime(), st2 = st1;
 #endif
@@ -237,6 +239,18 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
   }
 #endif
   a.out_v[pix] = out_v; a.out_n[pix] = out_n;
+  if (a.work) {
+    // what the REFERENCE's march reads for this ray (raycastingVolume.cu:65-119): one voxel per sample from t_min up to the
+    // crossing (or t_max); a crossing is evaluated with 2 + 6 trilinear look-ups of 8 voxels each
+    const float t_stop = t_cross < __builtin_huge_valf() ? t_cross : ref_tmax;
+    const float n_s = (ref_tmin < ref_tmax) ? floorf((t_stop - ref_tmin) / a.inc) + 1.f : 0.f;
+    const float steps = kf_wave_sum(n_s), hits = kf_wave_sum(t_cross < __builtin_huge_valf() ? 1.f : 0.f);
+    if ((threadIdx.x & 63) == 0) {
+      const unsigned sh = ((blockIdx.y * gridDim.x + blockIdx.x) * 8u + (threadIdx.x >> 6)) & 63u;
+      atomicAdd(&a.work->rc_steps[sh * 16], (unsigned long long)steps);
+      atomicAdd(&a.work->rc_hits[sh * 16], (unsigned long long)hits);
+    }
+  }
   if (a.out_t) a.out_t[pix] = t_cross;
   if (a.has_color) a.out_rgb[pix] = out_c;
 }
@@ -254,12 +268,15 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
   a.out_v = out_v ? out_v : c->model_v[0]; a.out_n = out_n ? out_n : c->model_n[0]; a.out_rgb = c->raycast_rgb; a.out_t = out_t;
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
   { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_RAYCAST_EXP"); a.exp_mode = em; }
+  a.work = c->count_work ? c->counters : nullptr;
   const size_t macro_bytes = (((((size_t)c->vol.nm * c->vol.nm * c->vol.nm + 31) / 32) + 3) & ~(size_t)3) * 4, neg_bytes = kf_negbit_words(c->n_stored_bricks) * 4;
   a.neg_words = (macro_bytes + neg_bytes <= RAYCAST_LDS_BYTES) ? (int)(neg_bytes / 4) : 0;
   if (macro_bytes > RAYCAST_LDS_BYTES) return KF_ERR_STATE;
   dim3 grid(kf_div_up(c->cols, 32), kf_div_up(c->rows, 16));
   kf_evt_begin(c, KF_STAGE_RAYCAST);
+  kf_evt_begin(c, KF_STAGE_RAYCAST_KERNEL);
   hipLaunchKernelGGL(k_raycast, grid, dim3(RAYCAST_THREADS), macro_bytes + (size_t)a.neg_words * 4, c->stream, a);
+  kf_evt_end(c, KF_STAGE_RAYCAST_KERNEL);
   kf_evt_end(c, KF_STAGE_RAYCAST);
   return (int)hipGetLastError();
 }

@@ -83,7 +83,7 @@ SYMBOLS = [
     "kf_icp_track", "kf_sdf_track", "kf_read_track_result", "kf_request_track_result", "kf_wait_track_result", "kf_integrate_volume", "kf_raycast_volume",
     "kf_marching_cubes", "kf_clear_triangles", "kf_triangle_count", "kf_read_triangles", "kf_download_map",
     "kf_upload_map", "kf_download_volume", "kf_upload_volume", "kf_get_volume_stats", "kf_stored_z_range",
-    "kf_stage_timers", "kf_read_stage_ms", "kf_set_stream", "kf_raycast_volume_slab", "kf_slab_mask_candidates", "kf_set_model_maps_device", "kf_slab_pack_candidates", "kf_set_model_maps_packed", "kf_selftest_div",
+    "kf_stage_timers", "kf_read_stage_ms", "kf_read_work_counters", "kf_set_stream", "kf_raycast_volume_slab", "kf_slab_mask_candidates", "kf_set_model_maps_device", "kf_slab_pack_candidates", "kf_set_model_maps_packed", "kf_selftest_div",
     "kf_icp_partition_begin", "kf_icp_partition_steps", "kf_icp_partition_step", "kf_icp_partition_finish",
 ]
 
@@ -368,6 +368,12 @@ class Context:
         cnt = np.zeros(8, np.uint32)
         _chk(self.lib.kf_read_stage_ms(self.h, _p(ms), _p(cnt)), "kf_read_stage_ms")
         return ms, cnt
+
+    def work_counters(self):
+        """(raycast reference samples, rays evaluated, marching-cubes blocks visited, triangles) since stage_timers(mask | 1 << 16)"""
+        out = (C.c_uint64 * 4)()
+        _chk(self.lib.kf_read_work_counters(self.h, out), "kf_read_work_counters")
+        return tuple(int(v) for v in out)
 
     def selftest_div(self, n, seed, mode):
         m = C.c_uint32(0)
