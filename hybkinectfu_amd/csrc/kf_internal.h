@@ -147,7 +147,6 @@ struct kf_ctx {
   int tiles_clear, int_parity, last_parity;
   kf_triangle* triangles; uint32_t max_triangles;
   unsigned* mc_block_counts; size_t mc_blocks_cap;
-  unsigned* rc_tile_z; int rc_parity;   // raycast: per 8x8-pixel tile entry bound (k_raycast_bounds), allocated by the first raycast
   unsigned* mc_list; unsigned* mc_nbr_bits; unsigned* mc_partials;   // extraction scratch, allocated by the first kf_marching_cubes
   void* host_pinned;                  // small pinned staging buffer (4 KiB); byte KF_PINNED_STALL_WORD: the ICP loop's stall word
   // per-stage hipEvent timers (KF_STAGE_*): bit s of timers_enabled turns stage s on

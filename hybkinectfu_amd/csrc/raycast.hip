@@ -26,60 +26,7 @@ struct RaycastArgs {
   int neg_words;                 // words of vol.negbits to keep in LDS (0: the table does not fit -> brick flags are read from global memory)
   int exp_mode;                  // timing experiments only (KF_RAYCAST_EXP): 1 = stop at the crossing without evaluating it
   KfCounters* work;              // measurement passes only (kf_stage_timers bit 16): count the reference march's samples and the hits
-  // conservative entry depth per 16x16-pixel bound tile, written by k_raycast_bounds right before this launch: the smallest
-  // camera-space z of any has-negative brick whose projection touches the tile (+inf bits: none does); entry [n_btiles] holds the
-  // same bound for bricks too close to the eye to project.  Two such tables alternate by launch parity: tile_z is this launch's,
-  // tile_z_other the one this launch resets to +inf for the next bounds pass.
-  unsigned* tile_z; unsigned* tile_z_other; int btiles_w, n_btiles;
-  int tiles_w, n_tiles;          // 8x8-pixel ray tiles (one wave each)
-  const float* pose_inv; KfMat pose_inv_val;     // world -> camera of the same pose (device pointer, or by value)
 };
-
-// ---- where can a ray's first crossing be at the earliest? -----------------------------------------------------------------------
-// The negative sample of a +/- crossing lies in a brick flagged has-negative, hence in a flagged 32^3 macro cell.  One lane per
-// macro cell (a few thousand: the launch is as short as a launch gets; per-brick bounds cost 8 us and bought 1 us of march): a
-// flagged cell's box (the world positions whose nearest voxel lies in it, a hair wider) is taken to camera space, and its smallest z is merged
-// (atomic min on the float's bits, z > 0) into every 16x16-pixel tile its projected
-// bounding rectangle touches.  A point of the box
-// projects inside that rectangle, so for every ray of a tile no sample in front of the tile's bound can be such a negative sample:
-// k_raycast starts its march there -- by the reference's own repeated addition, so every later sample parameter keeps its bits --
-// and a tile no flagged brick touches is skipped outright.  Cost: one short launch over the packed has-negative bits.
-__global__ void __launch_bounds__(256) k_raycast_bounds(RaycastArgs a, unsigned n_slots) {
-  const KfVolume& v = a.vol;
-  const unsigned slot = blockIdx.x * 256u + threadIdx.x;
-  if (slot >= n_slots) return;
-  if (!((v.negbits[slot >> 5] >> (slot & 31u)) & 1u)) return;
-  const unsigned nb = (unsigned)v.nb;
-  const int bx = (int)(slot % nb), by = (int)((slot / nb) % nb), bz = (int)(slot / (nb * nb)) + v.bz0;
-  const float* m = a.pose_inv ? a.pose_inv : a.pose_inv_val.m;
-  const float cell = v.cell, mg = 0.05f * cell;
-  float zmin = __builtin_huge_valf(), umin = zmin, vmin = zmin, umax = -zmin, vmax = -zmin;
-  bool behind = false;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float wx = (float)(bx * 8 + ((k & 1) ? 8 : 0)) * cell + ((k & 1) ? mg : -mg);
-    const float wy = (float)(by * 8 + ((k & 2) ? 8 : 0)) * cell + ((k & 2) ? mg : -mg);
-    const float wz = (float)(bz * 8 + ((k & 4) ? 8 : 0)) * cell + ((k & 4) ? mg : -mg);
-    const float px = m[0] * wx + m[1] * wy + m[2] * wz + m[3], py = m[4] * wx + m[5] * wy + m[6] * wz + m[7], pz = m[8] * wx + m[9] * wy + m[10] * wz + m[11];
-    zmin = fminf(zmin, pz);
-    if (pz > 0.05f) {
-      const float rz = __builtin_amdgcn_rcpf(pz);                      // 1 ulp: the rectangle is widened by two pixels below
-      const float u = px * rz * a.cam.fx + a.cam.cx, w = py * rz * a.cam.fy + a.cam.cy;
-      umin = fminf(umin, u); umax = fmaxf(umax, u); vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
-    } else behind = true;
-  }
-  unsigned* glob = a.tile_z + a.n_btiles;
-  if (behind) { atomicMin(glob, 0u); return; }                       // too close to the eye to project: no ray may skip anything
-  zmin *= 0.9999f;                                                   // rounding of the transform and of the ray's own z
-  int ix0 = (int)floorf(umin) - 2, ix1 = (int)ceilf(umax) + 2, iy0 = (int)floorf(vmin) - 2, iy1 = (int)ceilf(vmax) + 2;
-  if (ix1 < 0 || iy1 < 0 || ix0 >= a.cam.cols || iy0 >= a.cam.rows) return;      // projects off the image: no ray goes through it
-  ix0 = max(ix0, 0); iy0 = max(iy0, 0); ix1 = min(ix1, a.cam.cols - 1); iy1 = min(iy1, a.cam.rows - 1);
-  const int tx0 = ix0 >> 4, tx1 = ix1 >> 4, ty0 = iy0 >> 4, ty1 = iy1 >> 4;
-  const unsigned zb = __float_as_uint(zmin);
-  if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 100) { atomicMin(glob, zb); return; }   // a brick filling the view: one bound for every tile
-  for (int ty = ty0; ty <= ty1; ++ty)
-    for (int tx = tx0; tx <= tx1; ++tx) atomicMin(a.tile_z + ty * a.btiles_w + tx, zb);
-}
 
 // gradientForPoint raycastingVolume.cu:16-42: bounds tested on the LAST sample's voxel, taps taken around the vertex.
 // The +/- taps of an axis are looked up as a pair (16 gathers in flight); the reference's early-outs are pure, so testing
@@ -159,17 +106,12 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
     }
     __syncthreads();
   }
-  for (int i = (int)(blockIdx.x * RAYCAST_THREADS + threadIdx.x); i <= a.n_btiles; i += (int)(gridDim.x * RAYCAST_THREADS)) a.tile_z_other[i] = 0x7f800000u;
   const bool neg_in_lds = a.neg_words != 0;
-  // A wave is an 8x8 pixel tile.  The eight tiles of a workgroup are taken from all over the image (tile = wave * #workgroups +
-  // workgroup), not from one 32x16 block: every wave of the launch is resident at once, so the launch lasts as long as its
-  // busiest CU, and slow tiles (silhouettes, grazing walls) come in spatial clusters -- scattered, every CU gets the same mix.
+  // a workgroup is a 32x16 pixel tile, a wave an 8x8 patch of it
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tile = wave * (int)gridDim.x + (int)blockIdx.x;
-  if (tile >= a.n_tiles) return;                                      // (after the barrier above)
-  const int x = (tile % a.tiles_w) * 8 + (lane & 7), y = (tile / a.tiles_w) * 8 + (lane >> 3);
+  const int x = blockIdx.x * 32 + (wave & 3) * 8 + (lane & 7), y = blockIdx.y * 16 + (wave >> 2) * 8 + (lane >> 3);
   if (x >= a.cam.cols || y >= a.cam.rows) return;
-  if (KF_EXP_MODE(a) == 2 && (blockIdx.x & 1)) return;      // timing experiment: half the rays (latency- or throughput-bound?)
+  if (KF_EXP_MODE(a) == 2 && ((blockIdx.x + blockIdx.y) & 1)) return;      // timing experiment: half the rays (latency- or throughput-bound?)
   const int pix = y * a.cam.cols + x;
   float4 out_v = make_float4(0.f, 0.f, 0.f, 0.f), out_n = make_float4(0.f, 0.f, 0.f, 0.f);
   uchar4 out_c = make_uchar4(0, 0, 0, 0);
@@ -189,9 +131,6 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
   tmin = fmaxf(tmin, a.near_plane / cam_dir.z);
   tmax = fminf(tmax, a.far_plane / cam_dir.z);
   const float ref_tmin = tmin, ref_tmax = tmax;
-  // this wave's bound (uniform: an 8x8 ray tile lies inside one 16x16 bound tile); +inf: no has-negative brick projects there
-  const float z_tile = __uint_as_float(min(a.tile_z[(y >> 4) * a.btiles_w + (x >> 4)], a.tile_z[a.n_btiles]));
-  if (!(z_tile < __builtin_huge_valf())) tmax = tmin;                  // nothing to find along these rays: the march is skipped
 #ifdef KF_EXPERIMENTS
   unsigned long long st1 = __builtin_amdgcn_s_memtime(), st2 = st1;
 #endif
@@ -213,12 +152,6 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
     // passage through them (one cell of margin on either side); the parameter still reaches the first such sample by the
     // reference's repeated addition, and the previous sample is fetched lazily like after any other skip
     float t_end = tmax;
-    {
-      // start where a crossing becomes possible: every sample in front of the tile's bound lies in front of every has-negative
-      // brick the ray can meet (a sample's camera-space z is t * cam_dir.z); one increment and two cells of slack
-      const float t_first = fminf(z_tile / cam_dir.z - a.inc - 2.f * v.cell, t_end);
-      if (t < t_first) { do { t_prev = t; t += a.inc; } while (t < t_first); have_last = false; }
-    }
     if (v.own_z0 > 0 || v.own_z1 < R) {
       const float za = ((float)(v.own_z0 - 1) * v.cell - org.z) * inv_dir.z, zb = ((float)(v.own_z1 + 1) * v.cell - org.z) * inv_dir.z;
       const float t_in = fminf(za, zb), t_out = fmaxf(za, zb);
@@ -313,7 +246,7 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
     const float n_s = (ref_tmin < ref_tmax) ? floorf((t_stop - ref_tmin) / a.inc) + 1.f : 0.f;
     const float steps = kf_wave_sum(n_s), hits = kf_wave_sum(t_cross < __builtin_huge_valf() ? 1.f : 0.f);
     if ((threadIdx.x & 63) == 0) {
-      const unsigned sh = (unsigned)tile & 63u;
+      const unsigned sh = ((blockIdx.y * gridDim.x + blockIdx.x) * 8u + (threadIdx.x >> 6)) & 63u;
       atomicAdd(&a.work->rc_steps[sh * 16], (unsigned long long)steps);
       atomicAdd(&a.work->rc_hits[sh * 16], (unsigned long long)hits);
     }
@@ -336,23 +269,11 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
   { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_RAYCAST_EXP"); a.exp_mode = em; }
   a.work = c->count_work ? c->counters : nullptr;
-  a.tiles_w = kf_div_up(c->cols, 8); a.n_tiles = a.tiles_w * kf_div_up(c->rows, 8);
-  a.btiles_w = kf_div_up(c->cols, 16); a.n_btiles = a.btiles_w * kf_div_up(c->rows, 16);
-  if (!c->rc_tile_z) {                                       // two tables, all +inf: allocated and initialised by the first raycast
-    KF_CHECK(hipSetDevice(c->cfg.device));
-    KF_CHECK(hipMalloc((void**)&c->rc_tile_z, 2 * ((size_t)a.n_btiles + 1) * sizeof(unsigned)));
-    KF_CHECK(hipMemsetD32Async((hipDeviceptr_t)c->rc_tile_z, 0x7f800000, 2 * ((size_t)a.n_btiles + 1), c->stream));
-  }
-  a.tile_z = c->rc_tile_z + (size_t)c->rc_parity * (a.n_btiles + 1); a.tile_z_other = c->rc_tile_z + (size_t)(c->rc_parity ^ 1) * (a.n_btiles + 1);
-  c->rc_parity ^= 1;
-  if (transform) { kf_mat44_inverse(transform->m, a.pose_inv_val.m); a.pose_inv = nullptr; }
-  else a.pose_inv = c->track->pose_inv;
   const size_t macro_bytes = (((((size_t)c->vol.nm * c->vol.nm * c->vol.nm + 31) / 32) + 3) & ~(size_t)3) * 4, neg_bytes = kf_negbit_words(c->n_stored_bricks) * 4;
   a.neg_words = (macro_bytes + neg_bytes <= RAYCAST_LDS_BYTES) ? (int)(neg_bytes / 4) : 0;
   if (macro_bytes > RAYCAST_LDS_BYTES) return KF_ERR_STATE;
-  dim3 grid(kf_div_up(a.n_tiles, RAYCAST_THREADS / 64));
+  dim3 grid(kf_div_up(c->cols, 32), kf_div_up(c->rows, 16));
   kf_evt_begin(c, KF_STAGE_RAYCAST);
-  hipLaunchKernelGGL(k_raycast_bounds, dim3(kf_div_up((int)c->n_stored_bricks, 256)), dim3(256), 0, c->stream, a, (unsigned)c->n_stored_bricks);
   kf_evt_begin(c, KF_STAGE_RAYCAST_KERNEL);
   hipLaunchKernelGGL(k_raycast, grid, dim3(RAYCAST_THREADS), macro_bytes + (size_t)a.neg_words * 4, c->stream, a);
   kf_evt_end(c, KF_STAGE_RAYCAST_KERNEL);

@@ -448,7 +448,7 @@ struct IcpLoopArgs {
 // reader needs no barrier and no flag: it polls the words it is about to add until their tags are current.  The adds run
 // in a fixed order (workgroup-major within a part, then the parts): every workgroup of the loop arrives at the same bits.  The
 // per-step launch form (k_icp_step) deals pixels to workgroups differently, so the two forms agree to tolerance, not bitwise.
-__device__ __forceinline__ void fold_partials_tagged(const unsigned long long* slots, int n_wg, unsigned tag, float* s_tot, int* s_abort) {
+__device__ __forceinline__ void fold_partials_tagged(const unsigned long long* slots, int n_wg, unsigned tag, float* s_tot, int* s_abort, int exp_mode = 0) {
   const int k = threadIdx.x & 31, part = threadIdx.x >> 5, parts = blockDim.x >> 5;
   float s = 0.f;
   if (k < 27) {
@@ -461,7 +461,7 @@ __device__ __forceinline__ void fold_partials_tagged(const unsigned long long* s
         for (int j = 0; j < ICP_FOLD_BATCH; ++j) {
           const int w = w0 + j * parts;
           v[j] = 0.f;
-          if (w < n_wg) {
+          if (w < n_wg && !(exp_mode == 3 && w >= 16 && k != 0)) {     // (experiment 3: wait for every workgroup, move 1/27 of the words)
             const unsigned long long u = __hip_atomic_load(&slots[w * 32 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             v[j] = __uint_as_float((unsigned)u);
             ok = ok && (unsigned)(u >> 32) == tag;
@@ -527,9 +527,12 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     for (int it = 0; it < L.iters[l]; ++it, ++step) {
       KF_STAMP(0);
       if (step > 0) {
-        fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, (KF_EXP_MODE(L) == 2 && n_prev > 16) ? 16 : n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort);
+        fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, (KF_EXP_MODE(L) == 2 && n_prev > 16) ? 16 : n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort, KF_EXP_MODE(L));
         if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; __hip_atomic_store(L.stall_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } return; }
         KF_STAMP(1);
+#ifdef KF_EXPERIMENTS
+        if (KF_EXP_MODE(L) == 8 && threadIdx.x == 0) L.slots[(size_t)24 * KF_ICP_LOOP_MAX_WG * 32 + (size_t)(step - 1) * 1024 + blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
         if (KF_EXP_MODE(L) == 1) { if (threadIdx.x == 0) s_code = STEP_APPLIED; __syncthreads(); } else     // timing only: skip the 6x6 solve
         apply_step(a, s_tot, s_cur, &s_code);
         if (s_code != STEP_APPLIED) {                                            // same verdict in every workgroup
@@ -588,6 +591,9 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
       }
       KF_STAMP(4);
       KF_STAMP(5);
+#ifdef KF_EXPERIMENTS
+      if (KF_EXP_MODE(L) == 8 && threadIdx.x == 0) L.slots[(size_t)24 * KF_ICP_LOOP_MAX_WG * 32 + (size_t)step * 1024 + blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
+#endif
       n_prev = grid_l;
     }
   }
@@ -880,6 +886,14 @@ extern "C" int kf_icp_partition_finish(kf_ctx* c, const kf_icp_params* icp, cons
   hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, a);
   return (int)hipGetLastError();
 }
+
+#ifdef KF_EXPERIMENTS
+extern "C" int kf_exp_read_icp_slots(kf_ctx* c, unsigned long long* dst, size_t first, size_t n) {
+  KF_CHECK(hipMemcpyAsync(dst, c->icp_loop_slots + first, n * 8, hipMemcpyDeviceToHost, c->stream));
+  KF_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+#endif
 
 extern "C" int kf_sdf_track(kf_ctx* c, uint32_t frame_id, const kf_sdf_tracker_params* sp, const kf_camera_params* cam) {
   if (!c || !sp || !cam) return KF_ERR_ARG;

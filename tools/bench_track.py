@@ -26,3 +26,21 @@ if os.environ.get("KF_ICP_EXP") == "7":
     r = ctx.read_solver_params()
     names = ["prefetch", "fold", "solve", "pixels", "wavesum+store", "barrier"]
     print("WG0 lane0 shader ticks per frame: " + ", ".join("%s=%.0f" % (n, r[20 + i]) for i, n in enumerate(names)), "(100 MHz ticks? see s_memtime)")
+if os.environ.get("KF_ICP_EXP") == "8":
+    # per-workgroup wall-clock stamps (s_memrealtime, 10 ns ticks): [step][wg] -> (published its partial, finished folding everyone's)
+    import ctypes as C
+    buf = np.zeros(19 * 1024, np.uint64)
+    ctx.lib.kf_exp_read_icp_slots(ctx.h, buf.ctypes.data_as(C.c_void_p), C.c_size_t(24 * 512 * 32), C.c_size_t(buf.size))
+    b = buf.reshape(19, 512, 2).astype(np.int64)
+    grids = [13] * 4 + [50] * 5 + [200] * 10
+    for s_, g in enumerate(grids):
+        pub, fold = b[s_, :g, 0], b[s_, :g, 1]
+        t0 = pub.min()
+        line = "step %2d (%3d wgs): publish first..last %5.2f us (median %5.2f)" % (s_, g, (pub.max() - t0) / 100.0, (np.median(pub) - t0) / 100.0)
+        if s_ < 18:
+            line += "; folded first..last %5.2f .. %5.2f us after the first publish" % ((fold.min() - t0) / 100.0, (fold.max() - t0) / 100.0)
+        if s_ > 0:
+            line += "; step length %5.2f us" % ((pub.min() - b[s_ - 1, :grids[s_ - 1], 0].min()) / 100.0)
+        print(line)
+    late = np.argsort(b[12, :200, 0])[-8:]
+    print("latest publishers of step 12:", late, (b[12, late, 0] - b[12, :200, 0].min()) / 100.0)
