@@ -358,7 +358,7 @@ __device__ __forceinline__ kf_f2 kf_div2(kf_f2 a, const KfRecip2& k) {     // kf
 template <int BR>
 __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   const KfVolume& v = a.vol;
-  const unsigned n_active = a.cnt->n_active[a.parity] >> (KF_EXP_MODE(a) >= 8 ? KF_EXP_MODE(a) - 7 : 0);     // exp_mode 8 / 9: half / quarter of the queue (timing only)
+  const unsigned n_active = a.cnt->n_active[a.parity] >> ((KF_EXP_MODE(a) == 8 || KF_EXP_MODE(a) == 9) ? KF_EXP_MODE(a) - 7 : 0);     // exp_mode 8 / 9: half / quarter of the queue (timing only)
   if (blockIdx.x == 0) integrate_maintenance(a);
   const float* m = a.tinv ? a.tinv : a.tinv_val.m;
   const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8], m9 = m[9], m10 = m[10], m11 = m[11];
