@@ -379,7 +379,9 @@ __device__ __forceinline__ bool icp_finish(const TrackArgs& a, float4 vg, float4
 
 // 512 lanes x ICP_PX (3) pixels per workgroup: 200 / 50 / 13 workgroups at VGA level 0 / 1 / 2 (few partials to fold, no register spills).
 #define ICP_THREADS 512
+#ifndef ICP_PX
 #define ICP_PX 3
+#endif
 __global__ void __launch_bounds__(ICP_THREADS) k_icp_step(TrackArgs a) {
   __shared__ float s_cur[16], s_linv[16];
   __shared__ float s_wave[27 * (ICP_THREADS / 16)], s_tot[(ICP_THREADS / 32) * 32];
