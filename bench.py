@@ -36,6 +36,11 @@ def workload(n_gpus, name="auto"):
     if name == "c2":
         return dict(name="C2", res=512, size=4.0, cam=S.vga_camera(), trunc_max=P["depth_trunc_max"], integ_dist=P["integrate_depth_trunc"],
                     desc="C2: synthetic 640x480 depth stream (Scene S), 512^3 @ 4 m TSDF, 3-level ICP 10/5/4, %dxMI355X" % n_gpus)
+    if name == "c5":
+        # C5: 1280x960 depth, 2048^3 @ 8 m (68.7 GB of voxels: one GPU holds it, N GPUs hold a z-slab each), mesh extraction at the end
+        return dict(name="C5", res=2048, size=8.0, cam=S.vga_camera(2), trunc_max=8.0, integ_dist=8.0, extract_mesh=True,
+                    desc="C5: synthetic 1280x960 depth (Scene S), 2048^3 @ 8 m TSDF + marching-cubes extract, " +
+                         ("whole volume on 1 GPU" if n_gpus == 1 else "z-slab per GPU, %d GPUs" % n_gpus))
     # C4: depth gates raised to the volume size so the whole 6 m volume is exercised
     return dict(name="C4", res=1024, size=6.0, cam=S.vga_camera(), trunc_max=6.0, integ_dist=6.0,
                 desc="C4: synthetic 640x480 depth (Scene S), 1024^3 @ 6 m TSDF, " +
@@ -227,8 +232,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs of the N=1 line (per-stage pass, raycast / marching-cubes rooflines, PCIe-inclusive rate)")
-    ap.add_argument("--config", default="auto", choices=["auto", "c2", "c4"],
-                    help="auto: C2 (512^3 @ 4 m) on 1 GPU, C4 (1024^3 @ 6 m, z-slabs) on N > 1, as BASELINE.json's metric states")
+    ap.add_argument("--config", default="auto", choices=["auto", "c2", "c4", "c5"],
+                    help="auto: C2 (512^3 @ 4 m) on 1 GPU, C4 (1024^3 @ 6 m, z-slabs) on N > 1, as BASELINE.json's metric states; "
+                         "c5: 2048^3 @ 8 m, 1280x960 depth, mesh extraction after the timed frames (BASELINE.json configs[4])")
     ap.add_argument("--icp-mode", default="replicated", choices=["replicated", "allreduce"],
                     help="multi-GPU tracking: every rank runs the whole ICP (default) or pixels are split and the 27-float system all-reduced")
     ap.add_argument("--no-scaling-reference", action="store_true",
@@ -288,10 +294,11 @@ def main():
     slab = not (world == 1 and not args.force_slab)
     if not slab:
         from hybkinectfu_amd.pipeline import SingleGpuPipeline as Pipe
-        pipe = Pipe(kcam, res, size, wl, device=device, max_triangles=(4_000_000 if not args.no_extras else 0))
+        pipe = Pipe(kcam, res, size, wl, device=device, max_triangles=(16_000_000 if wl.get("extract_mesh") else 4_000_000 if not args.no_extras else 0))
     else:
         from hybkinectfu_amd.pipeline import SlabPipeline as Pipe
-        pipe = Pipe(kcam, res, size, wl, rank=rank, world=world, device=device, icp_mode=args.icp_mode)
+        pipe = Pipe(kcam, res, size, wl, rank=rank, world=world, device=device, icp_mode=args.icp_mode,
+                    max_triangles=(16_000_000 // world + 1_000_000 if wl.get("extract_mesh") else 0))
 
     def run(first, count):
         # --prefetch: frame k+1 is preprocessed on the context's side stream while frame k is tracked (kf_prefetch_frame)
@@ -357,7 +364,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get(wl["name"])
-                traffic_source = tj.get("source", "profiles/integrate_traffic.json (builder's rocprofv3 --pmc run, not measured in this run)")
+                traffic_source = None if traffic is None else tj.get("source", "profiles/integrate_traffic.json (builder's rocprofv3 --pmc run, not measured in this run)")
             except Exception:
                 traffic = None
         roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
@@ -371,6 +378,24 @@ def main():
         roofline = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None, kernel="k_integrate_pairs",
                         launches_timed=int(launches), refused="fewer than 10 timed launches of the kernel: run with --steps >= 10")
 
+    mesh = None
+    if wl.get("extract_mesh"):
+        # C5: every rank extracts its own slab (slab-major concatenation = the single-GPU (z, y, x, k) order); outside the timed frames
+        import ctypes as C
+        barrier()
+        t0m = time.perf_counter()
+        pipe.ctx.marching_cubes(300.0 * size / res)
+        n_tri = C.c_uint32()
+        K._chk(pipe.ctx.lib.kf_triangle_count(pipe.ctx.h, C.byref(n_tri)), "kf_triangle_count")
+        barrier()
+        dtm = time.perf_counter() - t0m
+        total = n_tri.value
+        if dist is not None:
+            tt = torch.tensor([float(total)], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            total = int(tt.item())
+        mesh = dict(triangles=total, ms=round(1000.0 * dtm, 3), note="kf_marching_cubes on every rank's slab after the timed frames (wall time incl. the count read-back)")
+
     out = dict(metric="depth frames/sec into TSDF (integrate+ICP+raycast)", value=round(fps, 2), unit="frames/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(1000.0 * dt / args.steps, 4), higher_is_better=True,
                scaling="weak" if world == 1 else "strong", vs_baseline=None, dtype="f32", data="synthetic",
@@ -382,7 +407,9 @@ def main():
                            "z-slab x%d; %d halo layers per side RE-INTEGRATED by both neighbours (recomputed, not exchanged over xGMI); "
                            "raycast merge = MIN all-reduce (t, 1.2 MB) + integer SUM all-reduce (vertex+normal, 7.4 MB); ICP %s" % (world, pipe.halo, args.icp_mode)),
                roofline=roofline)
-    extras = world == 1 and not args.force_slab and not args.no_extras
+    if mesh is not None:
+        out["mesh_extraction"] = mesh
+    extras = world == 1 and not wl.get("extract_mesh") and not args.force_slab and not args.no_extras
     if extras:
         # per-stage device time (HIP events around every stage, 50 extra frames outside the timed region)
         pipe.stage_timers(0x1F | (1 << 5))
@@ -399,7 +426,7 @@ def main():
     if extras:
         pipe.close()
         out["pcie_inclusive"] = pcie_inclusive(wl, frames)
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not wl.get("extract_mesh"):      # (the oracle's 2048^3 volume would need 103 GB of host memory)
         pipe.close()
         out["cpu_baseline"] = cpu_baseline(wl, frames)
     if rank == 0:
