@@ -487,3 +487,28 @@ def test_tile_tables_follow_every_call_order():
     st = ctx.stats()
     assert st["frames_fused"] == 8 and st["weight_gt0"] == O.count_weight_gt0(ovol)
     ctx.close()
+
+
+def test_work_counters_match_the_oracle_march():
+    """kf_read_work_counters (the roofline accounting of SURVEY section 8d): the raycast counter equals the number of samples the
+    ORACLE's march takes (its per-pixel step counts), the hit counter the number of rays whose crossing was evaluated, and the
+    marching-cubes counters the blocks visited / triangles produced."""
+    res, size, cam, trunc = 128, 3.0, S.vga_camera(), 0.05          # 640x480 is a multiple of the raycast's 32x16 tile
+    ctx, ovol, pose, ocam = _fuse_sequence(res, size, cam, 3, trunc, 2.5)
+    inc = 0.7 * trunc
+    ov, on, _, steps = O.raycast(ovol, False, pose, inc, ocam, P["depth_trunc_min"], P["depth_trunc_max"], want_steps=True)
+    ctx.stage_timers((1 << 7) | (1 << 6) | (1 << 16))
+    ctx.raycast(pose, inc, P["depth_trunc_min"], P["depth_trunc_max"])
+    ctx.clear_triangles()
+    ctx.marching_cubes(300 * size / res)
+    n_steps, n_hits, n_blocks, n_tris = ctx.work_counters()
+    total = int(np.asarray(steps, np.int64).sum())
+    assert total > 1_000_000
+    assert abs(n_steps - total) <= 0.001 * total + cam[0] * cam[1]      # the device derives the count from t: +-1 per ray at most
+    assert n_tris == len(O.marching_cubes(ovol, False, 300 * size / res, 400000)) > 1000
+    assert 0 < n_blocks <= (res ** 3 + 255) // 256
+    assert n_hits >= int((ov[..., 3] != 0).sum()) > 10000              # hits = crossings evaluated (some of them fail their taps)
+    ms, cnt = ctx.read_stage_ms()
+    assert cnt[7] == 1 and cnt[6] == 1 and ms[7] > 0 and ms[6] > 0
+    ctx.stage_timers(0)
+    ctx.close()
