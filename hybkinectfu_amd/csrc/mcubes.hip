@@ -207,6 +207,19 @@ __global__ void __launch_bounds__(256) k_mc_mark(McArgs a) {
   if (live) a.list[base + (unsigned)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = blk;
 }
 
+// cell (x, y, z) of lane `tid` in the 256-cell block `blk`: the block's first cell is decoded once (wave-uniform), the lane's offset
+// is added with carries -- three 64-bit divisions per LANE here cost as much as the cell's whole evaluation
+__device__ __forceinline__ bool mc_cell_of(const McArgs& a, unsigned blk, unsigned tid, size_t n_cells, int& x, int& y, int& z) {
+  const unsigned R = (unsigned)a.vol.res;
+  const size_t f = (size_t)blk * 256;
+  if (f + tid >= n_cells) return false;
+  const unsigned row = (unsigned)(f / R);                           // uniform
+  unsigned cx = (unsigned)(f - (size_t)row * R) + tid, cy = row % R, cz = row / R;
+  while (cx >= R) { cx -= R; if (++cy == R) { cy = 0; ++cz; } }      // at most 256 / R turns (none when R is a multiple of 256)
+  x = (int)cx; y = (int)cy; z = a.z0 + (int)cz;
+  return true;
+}
+
 // count pass: one workgroup per listed block (grid-stride), one lane per cell
 __global__ void __launch_bounds__(256) k_mc_count(McArgs a) {
   __shared__ unsigned s_sum[4];
@@ -217,7 +230,8 @@ __global__ void __launch_bounds__(256) k_mc_count(McArgs a) {
     const unsigned blk = a.list[li];
     const size_t i = (size_t)blk * 256 + threadIdx.x;
     int n = 0;
-    if (i < n_cells) { CellEval e; n = eval_cell(a, (int)(i % R), (int)((i / R) % R), a.z0 + (int)(i / ((size_t)R * R)), e); }
+    int cx, cy, cz;
+    if (mc_cell_of(a, blk, threadIdx.x, n_cells, cx, cy, cz)) { CellEval e; n = eval_cell(a, cx, cy, cz, e); }
     const float s = kf_wave_sum((float)n);
     if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = (unsigned)s;
     __syncthreads();
@@ -298,7 +312,8 @@ __global__ void __launch_bounds__(256) k_mc_emit(McArgs a) {
     const size_t i = (size_t)blk * 256 + threadIdx.x;
     CellEval e; e.ntri = 0;
     int n = 0;
-    if (i < n_cells) n = eval_cell(a, (int)(i % R), (int)((i / R) % R), a.z0 + (int)(i / ((size_t)R * R)), e);
+    int cx, cy, cz;
+    if (mc_cell_of(a, blk, threadIdx.x, n_cells, cx, cy, cz)) n = eval_cell(a, cx, cy, cz, e);
     unsigned inc = (unsigned)n;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { unsigned t = __shfl_up(inc, off, 64); if ((threadIdx.x & 63) >= off) inc += t; }
