@@ -77,24 +77,44 @@ __device__ __forceinline__ int eval_cell(const McArgs& a, int x, int y, int z, C
   const float cell = v.cell;
   e.wp = kf3(((float)x + 0.5f) * cell, ((float)y + 0.5f) * cell, ((float)z + 0.5f) * cell);     // tsdfVolume.h:38-49
   const float P = cell * 0.5f, M = cell * (-0.5f);
-  // The eight corner lookups two at a time (16 voxel gathers in flight, quotients through the shared reciprocals: kf_div is the
-  // exact IEEE quotient); the reference's early returns are pure, so testing each pair in its order gives the same outcome.
-  // (Staging the block's 258 x 3 x 3 voxel neighbourhood in LDS was tried: 0.96 -> 1.53 ms at 512^3 -- most visited blocks
-  // hold only a few cells that get as far as a voxel read, and the fill is paid for all of them.)
+  // The eight corner lookups (tsdfVolume.h:98-122 + :151-172 each).  A lookup's voxel index and weight are computed per AXIS
+  // from that axis' coordinate alone, and the corners' coordinates take only two values per axis (centre -/+ half a cell): six
+  // axis evaluations instead of twenty-four, same arithmetic, same bits.  The voxel gathers then go out two corners at a time;
+  // the reference's early returns are pure, so testing the corners in its order afterwards gives the same outcome.
+  // (Staging the block's 258 x 3 x 3 voxel neighbourhood in LDS was tried: 0.96 -> 1.53 ms at 512^3.)
   const KfRecip rS = kf_recip(v.size), rcell = kf_recip(cell);
+  struct Axis { bool ok; int g; float w; };
+  const float rf = (float)v.res;
+  const int R = v.res;
+  auto axis = [&](float pos) {
+    Axis r; r.w = 0.f;
+    int g = kf_f2i(kf_div(pos * rf, rS));                                   // tsdfVolume.h:50-56
+    r.ok = !(g <= 0 || g >= R - 1);                                         // :153-155
+    g = (pos < ((float)g + 0.5f) * cell) ? (g - 1) : g;                     // :160-162
+    r.g = g;
+    r.w = kf_div(pos - ((float)g + 0.5f) * cell, rcell);                    // :164-166
+    return r;
+  };
+  const Axis ax[2] = {axis(e.wp.x + M), axis(e.wp.x + P)}, ay[2] = {axis(e.wp.y + M), axis(e.wp.y + P)}, az[2] = {axis(e.wp.z + M), axis(e.wp.z + P)};
+  auto corner = [&](int b) {
+    const Axis &X = ax[b & 1], &Y = ay[(b >> 1) & 1], &Z = az[(b >> 2) & 1];
+    KfInterp it; it.g = make_int3(X.g, Y.g, Z.g); it.a = X.w; it.b = Y.w; it.c = Z.w;
+    it.ok = X.ok && Y.ok && Z.ok && kf_z_stored(v, Z.g) && kf_z_stored(v, Z.g + 1);
+    return it;
+  };
 #pragma unroll
   for (int k = 0; k < 8; k += 2) {
     const int b0 = corner_bits(k), b1 = corner_bits(k + 1);
-    const float3 p0 = kf_add(e.wp, kf3((b0 & 1) ? P : M, (b0 & 2) ? P : M, (b0 & 4) ? P : M));
-    const float3 p1 = kf_add(e.wp, kf3((b1 & 1) ? P : M, (b1 & 2) ? P : M, (b1 & 4) ? P : M));
-    bool ok0, ok1;
-    kf_interpolate_sdf_pair(v, p0, p1, rS, rcell, ok0, e.d[k], ok1, e.d[k + 1]);
-    if (!ok0) return 0;
+    const KfInterp i0 = corner(b0), i1 = corner(b1);
+    float2 q0[8], q1[8];
+    kf_interp_load(v, i0, q0); kf_interp_load(v, i1, q1);          // (per-axis address shares kept in registers were tried: 0.89 -> 1.21 ms)
+    e.d[k] = 0.f; e.d[k + 1] = 0.f;
+    if (!kf_interp_finish(i0, q0, e.d[k])) return 0;
     e.c[k] = make_uchar4(0, 0, 0, 0);
-    if (a.has_color) kf_interpolate_color(v, p0, e.c[k]);
-    if (!ok1) return 0;
+    if (a.has_color) kf_interpolate_color(v, kf_add(e.wp, kf3((b0 & 1) ? P : M, (b0 & 2) ? P : M, (b0 & 4) ? P : M)), e.c[k]);
+    if (!kf_interp_finish(i1, q1, e.d[k + 1])) return 0;
     e.c[k + 1] = make_uchar4(0, 0, 0, 0);
-    if (a.has_color) kf_interpolate_color(v, p1, e.c[k + 1]);
+    if (a.has_color) kf_interpolate_color(v, kf_add(e.wp, kf3((b1 & 1) ? P : M, (b1 & 2) ? P : M, (b1 & 4) ? P : M)), e.c[k + 1]);
   }
   // :77-85  cube index bit order 010,110,100,000,011,111,101,001  (k: 0=000 1=100 2=010 3=001 4=110 5=011 6=101 7=111)
   unsigned ci = 0;
