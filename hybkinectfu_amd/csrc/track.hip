@@ -479,13 +479,17 @@ __device__ __forceinline__ void fold_partials_tagged(const unsigned long long* s
   }
   s_tot[part * 32 + k] = s;
   __syncthreads();
+  // the parts' sums: four lanes per total add a quarter of the parts each, two DPP shifts combine them (fixed order, the same in
+  // every workgroup) -- a chain of parts/4 + 2 dependent adds instead of parts
   float t = 0.f;
-  if (threadIdx.x < 27) {
-    t = s_tot[threadIdx.x];
-    for (int p = 1; p < parts; ++p) t += s_tot[p * 32 + threadIdx.x];
+  if (threadIdx.x < 27 * 4) {
+    const int kk = threadIdx.x >> 2, quarter = threadIdx.x & 3, per = (parts + 3) >> 2;
+    for (int p = quarter * per; p < min(parts, (quarter + 1) * per); ++p) t += s_tot[p * 32 + kk];
+    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x111, 0xf, 0xf, true));   // row_shr:1
+    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x112, 0xf, 0xf, true));   // row_shr:2
   }
   __syncthreads();
-  if (threadIdx.x < 27) s_tot[threadIdx.x] = t;
+  if (threadIdx.x < 27 * 4 && (threadIdx.x & 3) == 3) s_tot[threadIdx.x >> 2] = t;
   __syncthreads();
 }
 
