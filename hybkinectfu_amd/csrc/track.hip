@@ -537,6 +537,10 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
         if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; __hip_atomic_store(L.stall_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } return; }
         KF_STAMP(1);
 #ifdef KF_EXPERIMENTS
+        if (KF_EXP_MODE(L) == 9 && blockIdx.x == 5 && (threadIdx.x & 63) == 0)     // per-wave: fold of the previous step done
+          L.slots[(size_t)25 * KF_ICP_LOOP_MAX_WG * 32 + (size_t)step * 32 + 16 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef KF_EXPERIMENTS
         if (KF_EXP_MODE(L) == 8 && threadIdx.x == 0) L.slots[(size_t)24 * KF_ICP_LOOP_MAX_WG * 32 + (size_t)(step - 1) * 1024 + blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
         if (KF_EXP_MODE(L) == 1) { if (threadIdx.x == 0) s_code = STEP_APPLIED; __syncthreads(); } else     // timing only: skip the 6x6 solve
@@ -571,6 +575,10 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
             for (int c = r; c < 7; ++c) acc[s++] += row[r] * row[c];
         }
         KF_STAMP(3);
+#ifdef KF_EXPERIMENTS
+        if (KF_EXP_MODE(L) == 9 && blockIdx.x == 5 && (threadIdx.x & 63) == 0)     // per-wave: pixel phase done (workgroup 5)
+          L.slots[(size_t)25 * KF_ICP_LOOP_MAX_WG * 32 + (size_t)step * 32 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime();
+#endif
         // workgroup partial, stored write-through (sc1) for the other CUs
         // 16-lane row totals by DPP, one LDS word per (sum, row), then 27 lanes add the 32 row totals in a fixed order
         const int row = threadIdx.x >> 4;
@@ -597,6 +605,10 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
       }
       KF_STAMP(4);
       KF_STAMP(5);
+#ifdef KF_EXPERIMENTS
+      if (KF_EXP_MODE(L) == 9 && blockIdx.x == 5 && (threadIdx.x & 63) == 0)       // per-wave: partial published / wave idle again
+        L.slots[(size_t)25 * KF_ICP_LOOP_MAX_WG * 32 + (size_t)step * 32 + 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef KF_EXPERIMENTS
       if (KF_EXP_MODE(L) == 8 && threadIdx.x == 0) L.slots[(size_t)24 * KF_ICP_LOOP_MAX_WG * 32 + (size_t)step * 1024 + blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
 #endif

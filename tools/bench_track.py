@@ -44,3 +44,13 @@ if os.environ.get("KF_ICP_EXP") == "8":
         print(line)
     late = np.argsort(b[12, :200, 0])[-8:]
     print("latest publishers of step 12:", late, (b[12, late, 0] - b[12, :200, 0].min()) / 100.0)
+if os.environ.get("KF_ICP_EXP") == "9":
+    # workgroup 5, per wave and step (s_memrealtime, 10 ns ticks): fold done [16..23], pixel phase done [0..7], published [8..15]
+    import ctypes as C
+    buf = np.zeros(19 * 32, np.uint64)
+    ctx.lib.kf_exp_read_icp_slots(ctx.h, buf.ctypes.data_as(C.c_void_p), C.c_size_t(25 * 512 * 32), C.c_size_t(buf.size))
+    b = buf.reshape(19, 32).astype(np.int64)
+    for s_ in range(1, 19):
+        t0 = b[s_, 16:24].min()
+        print("step %2d: fold done %s | solve+pixels done at %s | published at %s (us after the first wave left the fold)" % (
+            s_, np.round((b[s_, 16:24] - t0) / 100.0, 2), np.round((b[s_, 0:8] - t0) / 100.0, 2), np.round((b[s_, 8:16] - t0) / 100.0, 2)))
