@@ -188,8 +188,8 @@ def roofline_extra(pipe, run, first_frame, res, size, n_frames=20):
     x 8 B per evaluated hit -- counted on the device (kf_read_work_counters) over n_frames extra frames, / the kernel's own time.
     The HIP kernel skips empty space through its bit tables, so its real traffic is far below this figure: the quotient says
     how fast the reference's work is DONE, not how busy HBM is (the march is latency-bound).
-    marching cubes: TOUCHED bytes -- 256-cell blocks whose neighbourhood holds a negative voxel x 2 KiB + 72 B per triangle --
-    / the extraction's time (mark + count + scan + emit)."""
+    marching cubes: TOUCHED bytes -- bricks whose 3x3x3 brick neighbourhood holds a negative voxel x 4 KiB (what the extraction
+    reads, once) + 72 B per triangle -- / the extraction's time (all its kernels: dilate ... emit)."""
     c = pipe.ctx
     c.stage_timers((1 << 7) | (1 << 6) | (1 << 16))
     run(first_frame, n_frames)
@@ -208,11 +208,11 @@ def roofline_extra(pipe, run, first_frame, res, size, n_frames=20):
     c.marching_cubes(300.0 * size / res)
     pipe.sync()
     ms, cnt = c.read_stage_ms()
-    _, _, blocks, tris = c.work_counters()
+    _, _, bricks, tris = c.work_counters()
     mc_ms = float(ms[6]) / max(int(cnt[6]), 1)
-    mc_bytes = blocks * 2048.0 + tris * 72.0
-    out["marching_cubes"] = dict(kernels="k_mc_dilate + k_mc_mark + k_mc_count + k_mc_scan_* + k_mc_emit", bound="hbm", ms=round(mc_ms, 5), blocks_visited=int(blocks),
-                                 blocks_total=int((res ** 3 + 255) // 256), triangles=int(tris), touched_bytes=int(mc_bytes),
+    mc_bytes = bricks * 4096.0 + tris * 72.0       # bricks whose 3x3x3 brick neighbourhood holds a negative voxel x 4 KiB + the triangles
+    out["marching_cubes"] = dict(kernels="k_mc_dilate + k_mc_codes + k_mc_sift + k_mc_list + k_mc_count + k_mc_scan_* + k_mc_emit_recs", bound="latency / launch (11 short kernels)",
+                                 ms=round(mc_ms, 5), bricks_read=int(bricks), bricks_total=int((res // 8) ** 3), triangles=int(tris), touched_bytes=int(mc_bytes),
                                  dense_bytes=int(res ** 3 * 8 + tris * 72),
                                  achieved=round(mc_bytes / (mc_ms * 1e-3) / 1e9, 2) if mc_ms > 0 else None, unit="GB/s",
                                  frac=round(mc_bytes / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if mc_ms > 0 else None,
@@ -428,7 +428,7 @@ def main():
         out["pcie_inclusive"] = pcie_inclusive(wl, frames)
     if world == 1 and not args.no_cpu_baseline and not wl.get("extract_mesh"):      # (the oracle's 2048^3 volume would need 103 GB of host memory)
         pipe.close()
-        out["cpu_baseline"] = cpu_baseline(wl, frames)
+        out["cpu_baseline"] = cpu_baseline(wl, frames, n_sample=150 if wl["res"] <= 512 else 40)      # 10-20 s of CPU work either way
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

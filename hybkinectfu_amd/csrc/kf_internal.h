@@ -96,7 +96,7 @@ struct KfCounters {
   // the update counts, one 128-byte line per shard
   unsigned long long rc_steps[64 * 16];      // raycast: samples the reference's march takes (per ray: up to its first crossing or t_max)
   unsigned long long rc_hits[64 * 16];       // raycast: rays whose crossing was evaluated (trilinear + gradient taps)
-  unsigned long long mc_blocks[64 * 16];     // marching cubes: 256-cell blocks that passed the has-negative neighbourhood test (count pass)
+  unsigned long long mc_blocks[64 * 16];     // marching cubes: 4-KiB bricks the extraction reads (those with a negative voxel in their 3x3x3 brick neighbourhood)
 };
 
 struct kf_ctx {
@@ -148,6 +148,8 @@ struct kf_ctx {
   kf_triangle* triangles; uint32_t max_triangles;
   unsigned* mc_block_counts; size_t mc_blocks_cap;
   unsigned* mc_list; unsigned* mc_nbr_bits; unsigned* mc_partials;   // extraction scratch, allocated by the first kf_marching_cubes
+  unsigned short* mc_codes; unsigned char* mc_surv; unsigned* mc_block_bits; uint2* mc_recs; unsigned* mc_d1_list;   // voxel classes, sieve bits, cell records, brick list (mcubes.hip), same scratch
+  unsigned vol_flags_serial, mc_zero_serial;   // bumped when brick flags may have been CLEARED (reset, upload) / the serial the class tables were last zeroed for
   void* host_pinned;                  // small pinned staging buffer (4 KiB); byte KF_PINNED_STALL_WORD: the ICP loop's stall word
   // per-stage hipEvent timers (KF_STAGE_*): bit s of timers_enabled turns stage s on
   int timers_enabled;

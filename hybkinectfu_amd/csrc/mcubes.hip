@@ -2,16 +2,20 @@
 // src/cuda/marchingcube.cu:5-164; tables src/cuda/marchingcube_table.h; MarchingcubeData src/cuda/MarchingcubeData.h).
 //
 // The reference appends triangles with one global atomicAdd, so its output ORDER is nondeterministic (and its
-// check-then-add can overshoot the buffer, marchingcube.cu:29-32).  Here extraction is deterministic:
-//   mark   : which 256-cell blocks (z, y, x order) can hold surface at all -> an unordered list (brick flags only, no voxel read);
-//   count  : one lane per cell of the listed blocks -> per-block triangle count;
+// check-then-add can overshoot the buffer, marchingcube.cu:29-32).  Here extraction is deterministic and reads voxels only where
+// the surface can be:
+//   dilate : the bricks with a negative voxel in their 3x3x3 brick neighbourhood (brick flags only) -> a bit per brick and a list;
+//   codes  : a 2-bit class per voxel (unobserved / not negative / negative) of the listed bricks, one coalesced pass over them;
+//   sift   : a cell whose 27 voxels are all of one class -- or hold an unobserved one -- cannot produce a triangle: one lane
+//            decides that for the eight cells of a brick x-row from 27 cached 16-bit loads -> a bit per cell, a bit per 256-cell block;
+//   list   : the 256-cell blocks (z, y, x order) that hold a surviving cell, unordered;
+//   count  : the surviving cells of the listed blocks, queued into dense waves, evaluated as the reference evaluates a cell
+//            (eight trilinear corner lookups) -> per-block triangle count, and a record per cell that holds triangles;
 //   scan   : exclusive prefix over ALL blocks in order (three parallel steps);
-//   emit   : the same cell logic again, intra-workgroup prefix, triangle k of cell (x,y,z) lands at a fixed index.
+//   emit   : one lane per record: the cell again, its triangles land at block prefix + offset in the block: a fixed index.
 // The canonical order is (z, y, x, k) -- identical for 1 GPU and for concatenated z-slabs.
-// Space skipping: a cell can only produce triangles if a corner SDF is negative, which needs a negative voxel in the
-// cell's +-2 neighbourhood (trilinear weights are convex), so workgroups and cells whose neighbourhood bricks carry no
-// KF_FLAG_HASNEG are dropped before any voxel is read.  The triangle table is packed into 256 x 64-bit words (16
-// nibbles per case) instead of the reference's 16 KiB int table; the 12-bit edge mask is derived from it.
+// The triangle table is packed into 256 x 64-bit words (16 nibbles per case) instead of the reference's 16 KiB int table; the
+// 12-bit edge mask is derived from it.
 #include "kf_internal.h"
 
 __constant__ unsigned long long c_tri_words[256] = {
@@ -32,6 +36,15 @@ struct McArgs {
   unsigned* list;                // blocks that may hold surface, in no particular order (their output position comes from the scan)
   unsigned* n_list;              // length of `list` (device)
   unsigned* partials;            // per 4096-block chunk: sum of its block counts, then the exclusive prefix of those sums
+  unsigned short* codes;         // [stored brick slot][brick row (z&7)<<3 | (y&7)]: eight voxels x 2 bits (k_mc_codes)
+  unsigned char* surv;           // [stored brick slot][brick row]: bit i = cell 8 bx + i of that row survives the sieve (k_mc_sift)
+  unsigned* block_bits;          // one bit per 256-cell block: some cell of it survives (set by k_mc_sift, listed by k_mc_list)
+  unsigned* d1_list;             // stored brick slots with a negative voxel in their 3x3x3 brick neighbourhood, unordered (k_mc_dilate)
+  unsigned* n_d1;
+  uint2* recs;                   // cells with triangles: {block, lane | triangles << 8 | offset inside the block << 12} (k_mc_count)
+  unsigned* n_recs;              // records appended (may exceed recs_cap: then *recs_overflow is set and k_mc_emit walks the blocks instead)
+  unsigned* recs_overflow;
+  unsigned recs_cap;
 };
 #define MC_CHUNK 4096u             // block counts scanned by one workgroup (16 per lane)
 
@@ -70,10 +83,10 @@ __device__ __forceinline__ bool neighbourhood_has(const KfVolume& v, int x, int 
 }
 
 // extractIsoSurfaceAtPosition marchingcube.cu:41-113 up to the table lookup; returns the triangle count of the cell
+// (the caller has already dropped the cells mc_pretest rules out)
 __device__ __forceinline__ int eval_cell(const McArgs& a, int x, int y, int z, CellEval& e) {
   const KfVolume& v = a.vol;
   e.ntri = 0;
-  if (!neighbourhood_has(v, x, y, z, KF_FLAG_HASNEG)) return 0;
   const float cell = v.cell;
   e.wp = kf3(((float)x + 0.5f) * cell, ((float)y + 0.5f) * cell, ((float)z + 0.5f) * cell);     // tsdfVolume.h:38-49
   const float P = cell * 0.5f, M = cell * (-0.5f);
@@ -173,13 +186,119 @@ __device__ __forceinline__ kf_vertex edge_vertex(const McArgs& a, const CellEval
   return r;
 }
 
+// ---- the voxel classes and the cell sieve --------------------------------------------------------------------------------------
+// class of a voxel: 0 unobserved (weight == 0), 1 observed and not negative, 2 observed and tsdf in [-1e18, -1e-18], 3 any other
+// observed negative.  Bricks outside the dilated has-negative set (k_mc_dilate) keep class 0 throughout without ever being read
+// or written (the table is cleared when it is allocated and whenever the volume is reset or uploaded; between those the set only
+// grows): a cell that touches such a brick has no negative voxel among its 27 (the bricks a cell touches are mutual neighbours),
+// so "unobserved" and "no negative anywhere" lead to the same verdict below.
+#define MC_NEG_LO (-1.0e18f)
+#define MC_NEG_HI (-1.0e-18f)
+__global__ void __launch_bounds__(256) k_mc_codes(McArgs a) {
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned n_d1 = *a.n_d1;
+  for (unsigned i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n_d1; i += gridDim.x * 4u) {                 // a wave per brick, a lane per x-row
+    const unsigned slot = a.d1_list[i];
+    unsigned code = 0;
+    const float4* p = reinterpret_cast<const float4*>(a.vol.tw + (size_t)slot * KF_BRICK_VOX + lane * 8u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 q = p[k];                                                                                // two voxels: (tsdf, weight) x 2
+      const unsigned c0 = q.y == 0.f ? 0u : !(q.x < 0.f) ? 1u : (q.x <= MC_NEG_HI && q.x >= MC_NEG_LO) ? 2u : 3u;
+      const unsigned c1 = q.w == 0.f ? 0u : !(q.z < 0.f) ? 1u : (q.z <= MC_NEG_HI && q.z >= MC_NEG_LO) ? 2u : 3u;
+      code |= (c0 | (c1 << 2)) << (4 * k);
+    }
+    a.codes[(size_t)slot * 64u + lane] = (unsigned short)code;
+  }
+}
+// Which cells can produce a triangle at all?  A cell's eight corner lookups read exactly the voxels x-1..x+1, y-1..y+1, z-1..z+1
+// (corner = cell centre -/+ half a cell; tsdfVolume.h:151-172 picks the voxel pair around it), each with weights in [0, 1] of
+// which the larger per axis is >= 0.5, summed as eight products (:98-122).  Hence, exactly as the full evaluation would find:
+//   an unobserved voxel among the 27        -> some corner lookup fails                      -> no triangle (marchingcube.cu:60-75)
+//   all 27 observed and none negative       -> every corner sum >= 0: cube index 0           -> no triangle
+//   all 27 in [-1e18, -1e-18]               -> every corner sum < 0 (one product <= -1e-18/8, no overflow, no NaN): index 255
+// Every other cell survives and is evaluated in full; so is every cell on the volume's or the slab's rim (its 27 voxels are not
+// all there) if a brick near it holds a negative voxel.  One lane sieves the eight cells of a brick x-row with bit-parallel
+// operations on the 2-bit classes of the 10 x 3 x 3 voxels around them: 27 cached 16-bit loads for eight cells.
+// Out: surv[slot][row] = one byte, bit i = cell (8 bx + i, y, z) survives; block_bits: the 256-cell blocks with a surviving cell.
+__global__ void __launch_bounds__(256) k_mc_sift(McArgs a) {
+  const KfVolume& v = a.vol;
+  const unsigned lane = threadIdx.x & 63u;
+  const int R = v.res, nb = v.nb;
+  const unsigned n_d1 = *a.n_d1;
+  for (unsigned i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n_d1; i += gridDim.x * 4u) {
+    const unsigned slot = a.d1_list[i];
+    unsigned mask8 = 0;
+    {
+      const int bx = (int)(slot % (unsigned)nb), by = (int)((slot / (unsigned)nb) % (unsigned)nb), bz = (int)(slot / ((unsigned)nb * nb)) + v.bz0;
+      const int y = by * 8 + (int)(lane & 7u), z = bz * 8 + (int)(lane >> 3);
+      const bool rim_row = y < 1 || y > R - 2 || z < 1 || z > R - 2 || !kf_z_stored(v, z - 1) || !kf_z_stored(v, z + 1);
+      if (!rim_row) {
+        unsigned all_nz = 0x5555u, all_and = 0xFFFFu, all_or = 0u;
+#pragma unroll
+        for (int dz = -1; dz <= 1; ++dz) {
+          const unsigned zz = (unsigned)(z + dz);
+#pragma unroll
+          for (int dy = -1; dy <= 1; ++dy) {
+            const unsigned yy = (unsigned)(y + dy);
+            const size_t rowbase = (((size_t)((zz >> 3) - (unsigned)v.bz0) * nb + (yy >> 3)) * nb) * 64u + (((zz & 7u) << 3) | (yy & 7u));
+            const unsigned mid = a.codes[rowbase + (size_t)bx * 64u];
+            const unsigned left = bx > 0 ? a.codes[rowbase + (size_t)(bx - 1) * 64u] : 0u;
+            const unsigned right = bx < nb - 1 ? a.codes[rowbase + (size_t)(bx + 1) * 64u] : 0u;
+            const unsigned w = (left >> 14) | (mid << 2) | ((right & 3u) << 18);        // classes of voxels 8 bx - 1 .. 8 bx + 8
+            const unsigned nz = (w | (w >> 1)) & 0x55555u;                               // bit 2i: voxel i of the window is observed
+            all_nz &= nz & (nz >> 2) & (nz >> 4);                                        // bit 2i: so are the three voxels of cell i
+            all_and &= w & (w >> 2) & (w >> 4);                                          // bits 2i, 2i+1: AND / OR of the three classes
+            all_or |= w | (w >> 2) | (w >> 4);
+          }
+        }
+        const unsigned eq = ~(all_and ^ all_or);
+        const unsigned same = eq & (eq >> 1) & 0x5555u;                                  // all 27 classes equal ...
+        const unsigned one_or_two = (all_and ^ (all_and >> 1)) & 0x5555u;                // ... and that class is 1 or 2
+        unsigned s = all_nz & ~(same & one_or_two) & 0x5555u;
+        s = (s | (s >> 1)) & 0x3333u; s = (s | (s >> 2)) & 0x0F0Fu; s = (s | (s >> 4)) & 0x00FFu;          // even bits -> a byte
+        mask8 = s;
+        if (bx == 0) mask8 = (mask8 & ~1u) | (neighbourhood_has(v, 0, y, z, KF_FLAG_HASNEG) ? 1u : 0u);
+        if (bx == nb - 1) mask8 = (mask8 & ~0x80u) | (neighbourhood_has(v, R - 1, y, z, KF_FLAG_HASNEG) ? 0x80u : 0u);
+      } else {
+        for (int i = 0; i < 8; ++i) if (neighbourhood_has(v, bx * 8 + i, y, z, KF_FLAG_HASNEG)) mask8 |= 1u << i;
+      }
+    }
+    a.surv[(size_t)slot * 64u + lane] = (unsigned char)mask8;
+    // the 256-cell block these eight cells lie in (R is a multiple of 8) -> its bit.  The eight rows of one z share a word (two at
+    // 2048^3): the first lane of each run of equal words ORs the run's bits together and issues the one atomic.
+    unsigned word = 0xFFFFFFFFu, bit = 0u;
+    {
+      const int bx = (int)(slot % (unsigned)nb), by = (int)((slot / (unsigned)nb) % (unsigned)nb), bz = (int)(slot / ((unsigned)nb * nb)) + v.bz0;
+      const int y = by * 8 + (int)(lane & 7u), z = bz * 8 + (int)(lane >> 3);
+      if (z >= a.z0 && z < a.z1) {
+        const unsigned blk = (unsigned)((((size_t)(z - a.z0) * R + y) * R + (size_t)bx * 8u) >> 8);
+        word = blk >> 5; bit = mask8 ? 1u << (blk & 31u) : 0u;
+      }
+    }
+    const unsigned prev_word = (unsigned)__shfl_up((int)word, 1, 8);
+    unsigned bits = bit;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      const unsigned wj = (unsigned)__shfl_down((int)word, j, 8), bj = (unsigned)__shfl_down((int)bit, j, 8);
+      if ((lane & 7u) + (unsigned)j < 8u && wj == word) bits |= bj;
+    }
+    if (bits && ((lane & 7u) == 0u || prev_word != word) && (a.block_bits[word] & bits) != bits) atomicOr(&a.block_bits[word], bits);
+  }
+}
+__device__ __forceinline__ bool mc_survives(const McArgs& a, int x, int y, int z) {
+  const size_t slot = kf_brick_slot(a.vol, x >> 3, y >> 3, z >> 3);
+  return (a.surv[slot * 64u + (size_t)(((z & 7) << 3) | (y & 7))] >> (x & 7)) & 1u;
+}
+
 // ---- which blocks need visiting ------------------------------------------------------------------------------------------------
 // A cell can produce triangles only if a voxel within +-2 cells of it is negative, i.e. only if one of the 3x3x3 bricks around its
 // own brick carries KF_FLAG_HASNEG.  k_mc_dilate writes that as one bit per stored brick (from the packed has-negative bits, 27
-// cached word loads per brick); k_mc_mark tests each 256-cell block -- a run of cells in (z, y, x) order: one x-row segment at
-// 512^3, several short rows in a small volume -- against the bits of the bricks it crosses and appends the survivors to a list.
-// The list's order does not matter: a block's triangles land where the prefix sum of the block counts says.
-__global__ void __launch_bounds__(256) k_mc_dilate(KfVolume v, unsigned* __restrict__ nbr_bits, unsigned n_slots) {
+// cached word loads per brick) and lists those bricks; the sieve runs over that list and sets one bit per 256-cell block -- a run
+// of cells in (z, y, x) order: one x-row segment at 512^3, several short rows in a small volume -- that holds a surviving cell;
+// k_mc_list turns the bits into a list.  The list's order does not matter: a block's triangles land where the prefix sum of the
+// block counts says.
+__global__ void __launch_bounds__(256) k_mc_dilate(KfVolume v, unsigned* __restrict__ nbr_bits, unsigned n_slots, unsigned* __restrict__ d1_list, unsigned* n_d1, KfCounters* work) {
   const unsigned slot = blockIdx.x * 256u + threadIdx.x;
   bool any = false;
   if (slot < n_slots) {
@@ -201,30 +320,29 @@ __global__ void __launch_bounds__(256) k_mc_dilate(KfVolume v, unsigned* __restr
     }
   }
   const unsigned long long m = __ballot(any);                     // a wave = 64 consecutive slots = two whole words
-  if ((threadIdx.x & 63) == 0 && slot < n_slots) { nbr_bits[slot >> 5] = (unsigned)m; nbr_bits[(slot >> 5) + 1] = (unsigned)(m >> 32); }
+  unsigned at = 0;
+  if ((threadIdx.x & 63) == 0 && slot < n_slots) {
+    nbr_bits[slot >> 5] = (unsigned)m; nbr_bits[(slot >> 5) + 1] = (unsigned)(m >> 32);
+    if (m) at = atomicAdd(n_d1, (unsigned)__popcll(m));
+    if (work && m) atomicAdd(&work->mc_blocks[(blockIdx.x & 63u) * 16u], (unsigned long long)__popcll(m));       // bricks the extraction reads
+  }
+  at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+  if (any) d1_list[at + (unsigned)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = slot;
 }
 
-__global__ void __launch_bounds__(256) k_mc_mark(McArgs a) {
-  const KfVolume& v = a.vol;
-  const unsigned R = (unsigned)v.res;
-  const unsigned blk = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
-  bool live = false;
-  if (blk < a.n_blocks) {
-    const size_t n_cells = (size_t)(a.z1 - a.z0) * R * R;
-    size_t c = (size_t)blk * 256, end = c + 256 < n_cells ? c + 256 : n_cells;
-    while (c < end && !live) {                                     // one iteration per x-row the block crosses
-      const unsigned x = (unsigned)(c % R), y = (unsigned)((c / R) % R), z = (unsigned)a.z0 + (unsigned)(c / ((size_t)R * R));
-      const unsigned run = (unsigned)((end - c) < (size_t)(R - x) ? (end - c) : (size_t)(R - x));
-      const size_t s0 = kf_brick_slot(v, (int)(x >> 3), (int)(y >> 3), (int)(z >> 3));
-      for (unsigned b = 0; b <= ((x + run - 1) >> 3) - (x >> 3); ++b) { const size_t s2 = s0 + b; live = live || ((a.nbr_bits[s2 >> 5] >> (s2 & 31u)) & 1u); }
-      c += run;
-    }
-  }
-  const unsigned long long m = __ballot(live);
+__global__ void __launch_bounds__(256) k_mc_list(McArgs a) {
+  const unsigned n_words = (a.n_blocks + 31u) / 32u;
+  const unsigned w = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
+  const unsigned bits = w < n_words ? a.block_bits[w] : 0u;
+  const unsigned mine = (unsigned)__popc(bits);
+  unsigned pre = mine;                                              // wave prefix of the popcounts, one atomic per wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const unsigned t = __shfl_up(pre, off, 64); if ((threadIdx.x & 63) >= (unsigned)off) pre += t; }
+  const unsigned wave_total = (unsigned)__shfl(pre, 63, 64);
   unsigned base = 0;
-  if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(a.n_list, (unsigned)__popcll(m));
-  base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-  if (live) a.list[base + (unsigned)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = blk;
+  if ((threadIdx.x & 63) == 63 && wave_total) base = atomicAdd(a.n_list, wave_total);
+  base = (unsigned)__shfl(base, 63, 64) + pre - mine;
+  for (unsigned m = bits; m; m &= m - 1u) a.list[base++] = w * 32u + (unsigned)__builtin_ctz(m);
 }
 
 // cell (x, y, z) of lane `tid` in the 256-cell block `blk`: the block's first cell is decoded once (wave-uniform), the lane's offset
@@ -240,29 +358,7 @@ __device__ __forceinline__ bool mc_cell_of(const McArgs& a, unsigned blk, unsign
   return true;
 }
 
-// count pass: one workgroup per listed block (grid-stride), one lane per cell
-__global__ void __launch_bounds__(256) k_mc_count(McArgs a) {
-  __shared__ unsigned s_sum[4];
-  const int R = a.vol.res;
-  const size_t n_cells = (size_t)(a.z1 - a.z0) * R * R;
-  const unsigned n_list = *a.n_list;
-  for (unsigned li = blockIdx.x; li < n_list; li += gridDim.x) {
-    const unsigned blk = a.list[li];
-    const size_t i = (size_t)blk * 256 + threadIdx.x;
-    int n = 0;
-    int cx, cy, cz;
-    if (mc_cell_of(a, blk, threadIdx.x, n_cells, cx, cy, cz)) { CellEval e; n = eval_cell(a, cx, cy, cz, e); }
-    const float s = kf_wave_sum((float)n);
-    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = (unsigned)s;
-    __syncthreads();
-    if (threadIdx.x == 0) a.block_counts[blk] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-    __syncthreads();
-  }
-}
-
-// ---- exclusive prefix sum of the block counts, in place, in three parallel steps ----------------------------------------------
-// (1) every workgroup sums its chunk of MC_CHUNK counts; (2) one workgroup turns the chunk sums into their exclusive prefix (a
-// few thousand values even at 2048^3); (3) every workgroup rescans its chunk on top of its offset.  total -> counts[n].
+// workgroup-wide exclusive prefix of one value per lane (256 lanes); s_wave: 4 words; the trailing barrier frees s_wave again
 __device__ __forceinline__ unsigned mc_block_excl_scan(unsigned local, unsigned* s_wave, unsigned& total) {
   unsigned inc = local;
 #pragma unroll
@@ -275,6 +371,85 @@ __device__ __forceinline__ unsigned mc_block_excl_scan(unsigned local, unsigned*
   __syncthreads();
   return wave_off + inc - local;
 }
+
+// count pass: persistent workgroups take MC_BATCH listed blocks at a time.  The surviving cells of the whole batch -- a few per
+// block where the surface crosses the x-rows, all 256 where it runs along them -- are queued in LDS in (block, x) order, one lane
+// per sieve BYTE (eight cells) doing the queueing, and evaluated by dense waves; a prefix over the queue gives every cell with
+// triangles its offset inside its block, and the cell is appended -- in no particular order -- to a global record list {block,
+// lane, triangles, offset}: the emit pass then needs no workgroup structure at all.  Out: block_counts[blk] = triangles of the block.
+#ifndef MC_BATCH
+#define MC_BATCH 64
+#endif
+#ifndef MC_COUNT_ATTR
+#define MC_COUNT_ATTR
+#endif
+__global__ void __launch_bounds__(256) MC_COUNT_ATTR k_mc_count(McArgs a) {
+  __shared__ unsigned s_cnt[MC_BATCH], s_qstart[MC_BATCH], s_bstart[MC_BATCH], s_wave[4];
+  __shared__ unsigned short s_q[MC_BATCH * 256];
+  const int R = a.vol.res;
+  const size_t n_cells = (size_t)(a.z1 - a.z0) * R * R;
+  const unsigned n_list = *a.n_list;
+  const unsigned lane = threadIdx.x & 63u;
+  for (unsigned base = blockIdx.x * MC_BATCH; base < n_list; base += gridDim.x * MC_BATCH) {
+    const unsigned nbat = n_list - base < MC_BATCH ? n_list - base : MC_BATCH;
+    // the batch's sieve bytes: pass p, lane (b_local, k) -> byte k (cells 8k .. 8k+7) of block p * 8 + b_local; all loads first
+    unsigned sv[MC_BATCH / 8];
+#pragma unroll
+    for (unsigned p = 0; p < MC_BATCH / 8; ++p) {
+      const unsigned b = p * 8u + (threadIdx.x >> 5), k = threadIdx.x & 31u;
+      sv[p] = 0;
+      int cx, cy, cz;
+      if (b < nbat && mc_cell_of(a, a.list[base + b], 8u * k, n_cells, cx, cy, cz))
+        sv[p] = a.surv[kf_brick_slot(a.vol, cx >> 3, cy >> 3, cz >> 3) * 64u + (size_t)(((cz & 7) << 3) | (cy & 7))];
+    }
+    if (threadIdx.x < MC_BATCH) s_cnt[threadIdx.x] = 0;
+    unsigned nq = 0;
+#pragma unroll
+    for (unsigned p = 0; p < MC_BATCH / 8; ++p) {                                // queue positions: blocks in batch order, cells in x order
+      unsigned total;
+      unsigned at = nq + mc_block_excl_scan((unsigned)__popc(sv[p]), s_wave, total);
+      if ((threadIdx.x & 31u) == 0) s_qstart[p * 8u + (threadIdx.x >> 5)] = at;
+      const unsigned q0 = ((p * 8u + (threadIdx.x >> 5)) << 8) | (8u * (threadIdx.x & 31u));
+      for (unsigned m = sv[p]; m; m &= m - 1u) s_q[at++] = (unsigned short)(q0 + (unsigned)__builtin_ctz(m));
+      nq += total;
+    }
+    __syncthreads();
+    unsigned carry = 0;
+    for (unsigned c0 = 0; c0 < nq; c0 += 256u) {
+      const unsigned i = c0 + threadIdx.x;
+      unsigned b = 0, t = 0, blk = 0; int n = 0;
+      if (i < nq) {
+        const unsigned q = s_q[i];
+        b = q >> 8; t = q & 255u; blk = a.list[base + b];
+        int cx, cy, cz;
+        mc_cell_of(a, blk, t, n_cells, cx, cy, cz);
+        CellEval e;
+        n = eval_cell(a, cx, cy, cz, e);
+      }
+      unsigned total;
+      const unsigned excl = carry + mc_block_excl_scan((unsigned)n, s_wave, total);
+      if (i < nq && i == s_qstart[b]) s_bstart[b] = excl;                        // the prefix at the block's first queued cell
+      __syncthreads();
+      const unsigned long long m = __ballot(n > 0);
+      unsigned at = 0;
+      if (lane == 0 && m) at = atomicAdd(a.n_recs, (unsigned)__popcll(m));
+      at = (unsigned)__builtin_amdgcn_readfirstlane((int)at) + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+      if (n > 0) {
+        atomicAdd(&s_cnt[b], (unsigned)n);
+        if (at < a.recs_cap) a.recs[at] = make_uint2(blk, t | ((unsigned)n << 8) | ((excl - s_bstart[b]) << 12));
+        else *a.recs_overflow = 1u;
+      }
+      carry += total;
+    }
+    __syncthreads();
+    if (threadIdx.x < nbat) a.block_counts[a.list[base + threadIdx.x]] = s_cnt[threadIdx.x];
+    __syncthreads();
+  }
+}
+
+// ---- exclusive prefix sum of the block counts, in place, in three parallel steps ----------------------------------------------
+// (1) every workgroup sums its chunk of MC_CHUNK counts; (2) one workgroup turns the chunk sums into their exclusive prefix (a
+// few thousand values even at 2048^3); (3) every workgroup rescans its chunk on top of its offset.  total -> counts[n].
 __global__ void __launch_bounds__(256) k_mc_scan_reduce(const unsigned* __restrict__ counts, unsigned n, unsigned* __restrict__ partials) {
   __shared__ unsigned s_wave[4];
   const unsigned i0 = blockIdx.x * MC_CHUNK + threadIdx.x * 16u;
@@ -319,9 +494,43 @@ __global__ void __launch_bounds__(256) k_mc_scan_apply(unsigned* __restrict__ co
   for (int k = 0; k < 16; ++k) { if (i0 + k < n) counts[i0 + k] = excl; excl += v[k]; }
 }
 
-// emit pass: the same cell logic again for the listed blocks that counted triangles, intra-workgroup prefix, fixed output index
+// triangles of an evaluated cell -> fixed positions start, start + 1, ... (marchingcube.cu:28-38, :129-136)
+__device__ __forceinline__ void mc_write_triangles(const McArgs& a, const CellEval& e, int n, unsigned start) {
+  for (int t = 0; t < n; ++t) {
+    const unsigned dst = start + (unsigned)t;
+    if (dst >= a.max_tris) break;                                                  // marchingcube.cu:29-31
+    kf_triangle tri;
+    tri.v0 = edge_vertex(a, e, (unsigned)((e.word >> (12 * t)) & 0xF));
+    tri.v1 = edge_vertex(a, e, (unsigned)((e.word >> (12 * t + 4)) & 0xF));
+    tri.v2 = edge_vertex(a, e, (unsigned)((e.word >> (12 * t + 8)) & 0xF));
+    a.tris[dst] = tri;
+  }
+}
+// emit pass: one lane per recorded cell, in whatever order the records were appended: the cell is evaluated again and its
+// triangles land at  (what the buffer already held) + (exclusive prefix of the block counts) + (the cell's offset in its block)
+// -- the reference never clears its counter (MarchingcubeData.h:56,99), so an extraction appends.
+__global__ void __launch_bounds__(256) k_mc_emit_recs(McArgs a) {
+  if (*a.recs_overflow) return;
+  const unsigned n_recs = *a.n_recs;
+  const int R = a.vol.res;
+  const size_t n_cells = (size_t)(a.z1 - a.z0) * R * R;
+  const unsigned held = a.cnt->n_triangles;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n_recs; i += gridDim.x * 256u) {
+    const uint2 r = a.recs[i];
+    int cx, cy, cz;
+    mc_cell_of(a, r.x, r.y & 255u, n_cells, cx, cy, cz);
+    CellEval e;
+    const int n = eval_cell(a, cx, cy, cz, e);
+    mc_write_triangles(a, e, n, held + a.block_counts[r.x] + (r.y >> 12));
+  }
+}
+// the same from the block counts alone, for an extraction whose cells with triangles outnumber the record list (more cells than
+// the triangle buffer holds triangles): the listed blocks that counted triangles, one at a time; ORDER-PRESERVING compaction of the
+// surviving cells, evaluation by the first waves, intra-workgroup prefix of the triangle counts.
 __global__ void __launch_bounds__(256) k_mc_emit(McArgs a) {
-  __shared__ unsigned s_wave[4];
+  __shared__ unsigned s_wave[4], s_wc[4];
+  __shared__ unsigned char s_q[256];
+  if (!*a.recs_overflow) return;
   const int R = a.vol.res;
   const size_t n_cells = (size_t)(a.z1 - a.z0) * R * R;
   const unsigned n_list = *a.n_list;
@@ -329,38 +538,32 @@ __global__ void __launch_bounds__(256) k_mc_emit(McArgs a) {
     const unsigned blk = a.list[li];
     const unsigned my_base = a.block_counts[blk], my_count = a.block_counts[blk + 1] - my_base;
     if (my_count == 0) continue;                                                  // uniform
-    const size_t i = (size_t)blk * 256 + threadIdx.x;
+    int cx, cy, cz;
+    const bool pass = mc_cell_of(a, blk, threadIdx.x, n_cells, cx, cy, cz) && mc_survives(a, cx, cy, cz);
+    const unsigned long long m = __ballot(pass);
+    if ((threadIdx.x & 63) == 0) s_wc[threadIdx.x >> 6] = (unsigned)__popcll(m);
+    __syncthreads();
+    unsigned at = (unsigned)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+    for (unsigned w = 0; w < (threadIdx.x >> 6); ++w) at += s_wc[w];
+    const unsigned n_pass = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+    if (pass) s_q[at] = (unsigned char)threadIdx.x;
+    __syncthreads();
     CellEval e; e.ntri = 0;
     int n = 0;
-    int cx, cy, cz;
-    if (mc_cell_of(a, blk, threadIdx.x, n_cells, cx, cy, cz)) n = eval_cell(a, cx, cy, cz, e);
-    unsigned inc = (unsigned)n;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { unsigned t = __shfl_up(inc, off, 64); if ((threadIdx.x & 63) >= off) inc += t; }
-    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    unsigned off0 = inc - (unsigned)n;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off0 += s_wave[w];
-    __syncthreads();
-    // append after what the buffer already holds (the reference never clears its counter: MarchingcubeData.h:56,99)
-    const unsigned start = a.cnt->n_triangles + my_base + off0;
-    for (int t = 0; t < n; ++t) {
-      const unsigned dst = start + (unsigned)t;
-      if (dst >= a.max_tris) break;                                                // marchingcube.cu:29-31
-      kf_triangle tri;
-      tri.v0 = edge_vertex(a, e, (unsigned)((e.word >> (12 * t)) & 0xF));
-      tri.v1 = edge_vertex(a, e, (unsigned)((e.word >> (12 * t + 4)) & 0xF));
-      tri.v2 = edge_vertex(a, e, (unsigned)((e.word >> (12 * t + 8)) & 0xF));
-      a.tris[dst] = tri;
+    if (threadIdx.x < n_pass) {
+      mc_cell_of(a, blk, s_q[threadIdx.x], n_cells, cx, cy, cz);
+      n = eval_cell(a, cx, cy, cz, e);
     }
+    unsigned total;
+    const unsigned off0 = mc_block_excl_scan((unsigned)n, s_wave, total);
+    mc_write_triangles(a, e, n, a.cnt->n_triangles + my_base + off0);
   }
 }
 
-__global__ void k_mc_finish(KfCounters* cnt, unsigned max_tris, const unsigned* n_list, int count_work) {
+__global__ void k_mc_finish(KfCounters* cnt, unsigned max_tris) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     unsigned long long t = (unsigned long long)cnt->n_triangles + cnt->scan_total;
     cnt->n_triangles = (unsigned)(t > max_tris ? max_tris : t);
-    if (count_work) cnt->mc_blocks[0] += *n_list;
   }
 }
 
@@ -375,29 +578,46 @@ extern "C" int kf_marching_cubes(kf_ctx* c, int has_color, float thr) {
   if (a.n_blocks > c->mc_blocks_cap) return KF_ERR_STATE;
   const unsigned n_chunks = (a.n_blocks + MC_CHUNK - 1) / MC_CHUNK;
   if (!c->mc_list) {                                       // extraction scratch: allocated by the first extraction, not by every context
-    KF_CHECK(hipSetDevice(c->cfg.device));
-    KF_CHECK(hipMalloc((void**)&c->mc_list, (c->mc_blocks_cap + 1) * sizeof(unsigned)));                 // [0] = length, then the block ids
+    KF_CHECK(hipSetDevice(c->cfg.device));                 // (per 4-KiB brick: 128 B of voxel classes + 64 B of sieve bits + 8 B of row bits)
+    KF_CHECK(hipMalloc((void**)&c->mc_list, (c->mc_blocks_cap + 4) * sizeof(unsigned)));                 // [0] list length, [1] records, [2] overflow; then the block ids
     KF_CHECK(hipMalloc((void**)&c->mc_nbr_bits, (c->n_stored_bricks / 32 + 4) * sizeof(unsigned)));
     KF_CHECK(hipMalloc((void**)&c->mc_partials, ((c->mc_blocks_cap + MC_CHUNK - 1) / MC_CHUNK + 1) * sizeof(unsigned)));
+    KF_CHECK(hipMalloc((void**)&c->mc_codes, c->n_stored_bricks * 64 * sizeof(unsigned short)));
+    KF_CHECK(hipMalloc((void**)&c->mc_surv, c->n_stored_bricks * 64));
+    KF_CHECK(hipMalloc((void**)&c->mc_d1_list, c->n_stored_bricks * sizeof(unsigned)));
+    c->mc_zero_serial = c->vol_flags_serial - 1;
+    KF_CHECK(hipMalloc((void**)&c->mc_block_bits, (c->mc_blocks_cap / 32 + 2) * sizeof(unsigned)));
+    KF_CHECK(hipMalloc((void**)&c->mc_recs, (size_t)c->max_triangles * sizeof(uint2)));                  // a recorded cell holds >= 1 triangle
   }
   a.block_counts = c->mc_block_counts; a.tris = c->triangles; a.max_tris = c->max_triangles; a.cnt = c->counters;
   a.count_work = c->count_work;
-  a.nbr_bits = c->mc_nbr_bits; a.n_list = c->mc_list; a.list = c->mc_list + 1; a.partials = c->mc_partials;
+  a.nbr_bits = c->mc_nbr_bits; a.n_list = c->mc_list; a.n_recs = c->mc_list + 1; a.recs_overflow = c->mc_list + 2; a.list = c->mc_list + 4;
+  a.partials = c->mc_partials; a.codes = c->mc_codes; a.surv = c->mc_surv; a.block_bits = c->mc_block_bits;
+  a.recs = c->mc_recs; a.recs_cap = c->max_triangles; a.d1_list = c->mc_d1_list; a.n_d1 = c->mc_list + 3;
   kf_evt_begin(c, KF_STAGE_MCUBES);
+  if (c->mc_zero_serial != c->vol_flags_serial) {          // bricks outside the has-negative neighbourhood set must read as class 0 / no survivor
+    KF_CHECK(hipMemsetAsync(c->mc_codes, 0, c->n_stored_bricks * 64 * sizeof(unsigned short), c->stream));
+    KF_CHECK(hipMemsetAsync(c->mc_surv, 0, c->n_stored_bricks * 64, c->stream));
+    c->mc_zero_serial = c->vol_flags_serial;
+  }
   KF_CHECK(hipMemsetAsync(c->mc_block_counts, 0, ((size_t)a.n_blocks + 1) * sizeof(unsigned), c->stream));
-  KF_CHECK(hipMemsetAsync(c->mc_list, 0, sizeof(unsigned), c->stream));
+  KF_CHECK(hipMemsetAsync(c->mc_list, 0, 4 * sizeof(unsigned), c->stream));
+  KF_CHECK(hipMemsetAsync(c->mc_block_bits, 0, ((size_t)a.n_blocks / 32 + 1) * sizeof(unsigned), c->stream));
   const unsigned n_slots = (unsigned)c->n_stored_bricks;
-  hipLaunchKernelGGL(k_mc_dilate, dim3((n_slots + 255) / 256), dim3(256), 0, c->stream, c->vol, c->mc_nbr_bits, n_slots);
-  const unsigned mark_wgs = (a.n_blocks + 255) / 256;
-  const unsigned mgx = mark_wgs < 65535u ? mark_wgs : 65535u, mgy = (mark_wgs + mgx - 1) / mgx;
-  hipLaunchKernelGGL(k_mc_mark, dim3(mgx, mgy), dim3(256), 0, c->stream, a);
-  const unsigned walk = (unsigned)c->num_cus * 8u;         // persistent workgroups walking the list
+  hipLaunchKernelGGL(k_mc_dilate, dim3((n_slots + 255) / 256), dim3(256), 0, c->stream, c->vol, c->mc_nbr_bits, n_slots, a.d1_list, a.n_d1, c->count_work ? c->counters : nullptr);
+  const unsigned walk = (unsigned)c->num_cus * 8u;         // persistent workgroups walking the brick list / the block list / the records
+  hipLaunchKernelGGL(k_mc_codes, dim3(walk), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_mc_sift, dim3(walk), dim3(256), 0, c->stream, a);
+  const unsigned list_wgs = ((a.n_blocks + 31u) / 32u + 255u) / 256u;
+  const unsigned lgx = list_wgs < 65535u ? list_wgs : 65535u, lgy = (list_wgs + lgx - 1) / lgx;
+  hipLaunchKernelGGL(k_mc_list, dim3(lgx, lgy), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(k_mc_count, dim3(walk), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(k_mc_scan_reduce, dim3(n_chunks), dim3(256), 0, c->stream, a.block_counts, a.n_blocks, a.partials);
   hipLaunchKernelGGL(k_mc_scan_partials, dim3(1), dim3(256), 0, c->stream, a.partials, n_chunks, a.block_counts, a.n_blocks, c->counters);
   hipLaunchKernelGGL(k_mc_scan_apply, dim3(n_chunks), dim3(256), 0, c->stream, a.block_counts, a.n_blocks, a.partials);
-  hipLaunchKernelGGL(k_mc_emit, dim3(walk), dim3(256), 0, c->stream, a);
-  hipLaunchKernelGGL(k_mc_finish, dim3(1), dim3(64), 0, c->stream, c->counters, c->max_triangles, c->mc_list, c->count_work);
+  hipLaunchKernelGGL(k_mc_emit_recs, dim3(walk), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_mc_emit, dim3(walk), dim3(256), 0, c->stream, a);              // returns at once unless the record list overflowed
+  hipLaunchKernelGGL(k_mc_finish, dim3(1), dim3(64), 0, c->stream, c->counters, c->max_triangles);
   kf_evt_end(c, KF_STAGE_MCUBES);
   return (int)hipGetLastError();
 }

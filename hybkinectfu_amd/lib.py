@@ -370,7 +370,7 @@ class Context:
         return ms, cnt
 
     def work_counters(self):
-        """(raycast reference samples, rays evaluated, marching-cubes blocks visited, triangles) since stage_timers(mask | 1 << 16)"""
+        """(raycast reference samples, rays evaluated, bricks read by marching cubes, triangles) since stage_timers(mask | 1 << 16)"""
         out = (C.c_uint64 * 4)()
         _chk(self.lib.kf_read_work_counters(self.h, out), "kf_read_work_counters")
         return tuple(int(v) for v in out)

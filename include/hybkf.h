@@ -217,7 +217,8 @@ int kf_read_stage_ms(kf_ctx* ctx, float out_ms[8], uint32_t counts[8]);
 /* Work counters for roofline accounting, maintained only while bit 16 of `stage_mask` is set (they cost a
  * few atomics per wave) and reset by kf_stage_timers: out[0] = voxel samples the reference's ray march takes (per ray from t_min
  * to its first crossing or t_max, src/cuda/raycastingVolume.cu:65-119), out[1] = rays whose crossing was evaluated,
- * out[2] = 256-cell marching-cubes blocks that had to be visited, out[3] = triangles in the buffer.  Blocking. */
+ * out[2] = 4-KiB bricks the marching-cubes extractions read (those with a negative voxel in their 3x3x3 brick neighbourhood),
+ * out[3] = triangles in the buffer.  Blocking. */
 int kf_read_work_counters(kf_ctx* ctx, uint64_t out[4]);
 
 #ifdef __cplusplus

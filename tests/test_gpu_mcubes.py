@@ -1,0 +1,135 @@
+"""Marching cubes through the C ABI against the CPU oracle on volumes built to stress the cell sieve (mcubes.hip: voxel classes ->
+cells that cannot hold a triangle are dropped before any corner is interpolated): unobserved holes, values that are negative but
+round to nothing (-1e-20, -1e-38, denormals), -0.0 / +0.0, regions that are negative throughout, surface on the volume's rim,
+and volumes that change between extractions.  Bit-exact triangle sequence in the canonical (z, y, x, k) order every time."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from hybkinectfu_amd import lib as K
+from hybkinectfu_amd import scene as S
+
+pytestmark = pytest.mark.gpu
+
+P = S.STOCK
+CAM = (64, 48, 31.5, 23.5, 52.5, 52.5)
+
+
+def smooth_field(res, rng, waves=4):
+    """A band-limited random field in [-1, 1]: sign changes everywhere, including on the rim."""
+    z, y, x = np.meshgrid(*(np.arange(res, dtype=np.float32),) * 3, indexing="ij")
+    f = np.zeros((res, res, res), np.float32)
+    for _ in range(waves):
+        k = rng.uniform(0.15, 0.9, 3).astype(np.float32)
+        ph = rng.uniform(0, 6.28, 3).astype(np.float32)
+        f += np.sin(k[0] * x + ph[0]) * np.sin(k[1] * y + ph[1]) * np.sin(k[2] * z + ph[2])
+    return (f / waves).astype(np.float32)
+
+
+def stress_volume(res, seed):
+    rng = np.random.default_rng(seed)
+    t = smooth_field(res, rng)
+    w = np.ones_like(t) * 3.0
+    q = res // 4
+    w[rng.random(t.shape) < 0.02] = 0.0                                   # scattered unobserved voxels
+    w[q:q + 5, 2:9, :] = 0.0                                              # an unobserved slab
+    t[:q, :q, :q] = -0.25                                                 # negative throughout: no surface inside, surface at its faces
+    t[:3, q:2 * q, q:2 * q] = -1e-20                                      # negative, but the corner sums may underflow
+    t[3:6, q:2 * q, q:2 * q] = -1e-38
+    t[6:8, q:2 * q, q:2 * q] = np.float32(-1e-45)                         # a denormal
+    t[2 * q:2 * q + 4, :q, :] = np.where(rng.random((4, q, res)) < 0.5, np.float32(-0.0), np.float32(0.0))
+    t[-q:, -q:, -q:] = np.abs(t[-q:, -q:, -q:]) + 0.01                    # positive throughout
+    tiny = rng.random(t.shape) < 0.01
+    t[tiny] = (rng.choice(np.array([-1e-19, -3e-18, -1e-17, 1e-19], np.float32), int(tiny.sum())))
+    return t.astype(np.float32), w.astype(np.float32)
+
+
+def oracle_volume(res, size, t, w):
+    ov = O.OVolume(res, size, P["volume_max_weight"])
+    ov.tsdf[...] = t
+    ov.weight[...] = w
+    return ov
+
+
+def same_triangles(g, o):
+    return len(g) == len(o) and np.array_equal(g["v"]["pos"].view(np.uint32), o["v"]["pos"].view(np.uint32))
+
+
+@pytest.mark.parametrize("res,seed", [(32, 1), (64, 2), (40, 3), (128, 4)])
+def test_sieve_keeps_every_cell_the_reference_triangulates(res, seed):
+    size = 3.0
+    thr = 1.0e9                                                            # no threshold: every sign change counts
+    ctx = K.Context(K.camera(*CAM), res, size, P["volume_max_weight"], levels=3, max_triangles=3_000_000)
+    for round_ in range(2):                                                # the second volume replaces the first: stale classes must not survive
+        t, w = stress_volume(res, seed + 10 * round_)
+        if round_ == 1:
+            t = -t
+        ctx.upload_volume(t, w)
+        o = O.marching_cubes(oracle_volume(res, size, t, w), False, thr, 3_000_000)
+        ctx.clear_triangles()
+        ctx.marching_cubes(thr)
+        g = ctx.triangles()
+        assert len(o) > 2000
+        assert same_triangles(g, o), (res, seed, round_, len(g), len(o))
+        small_thr = 0.05                                                   # with the reference's |d| > thr rejection active as well
+        o2 = O.marching_cubes(oracle_volume(res, size, t, w), False, small_thr, 3_000_000)
+        ctx.clear_triangles()
+        ctx.marching_cubes(small_thr)
+        assert same_triangles(ctx.triangles(), o2) and len(o2) < len(o)
+    ctx.close()
+
+
+def test_record_list_overflow_takes_the_block_walk():
+    """More cells with triangles than the triangle buffer has room for: the per-cell record list overflows and the extraction falls
+    back to walking the listed blocks; the first `cap` triangles of the canonical order are delivered either way."""
+    res, size = 64, 3.0
+    t, w = stress_volume(res, 7)
+    o = O.marching_cubes(oracle_volume(res, size, t, w), False, 1.0e9, 3_000_000)
+    for cap in (len(o) // 7, 100, 1):
+        ctx = K.Context(K.camera(*CAM), res, size, P["volume_max_weight"], levels=3, max_triangles=cap)
+        ctx.upload_volume(t, w)
+        ctx.marching_cubes(1.0e9)
+        g = ctx.triangles()
+        assert len(g) == cap and np.array_equal(g["v"]["pos"].view(np.uint32), o[:cap]["v"]["pos"].view(np.uint32))
+        ctx.close()
+
+
+def test_extraction_follows_a_growing_volume():
+    """Fuse, extract, fuse more, extract again: the bricks near negative voxels only grow in number between resets, and the class
+    tables of the new ones must be filled; after a reset everything starts from nothing."""
+    res, size, trunc = 64, 3.0, 0.1
+    cam = (160, 120, 79.5, 59.5, 131.25, 131.25)
+    ocam = O.Cam.make(*cam)
+    ovol = O.OVolume(res, size, P["volume_max_weight"])
+    ctx = K.Context(K.camera(*cam), res, size, P["volume_max_weight"], levels=3, max_triangles=400000)
+    thr = 300 * size / res
+
+    def fuse(k):
+        pose = S.trajectory_pose(k, size).astype(np.float32)
+        mm = S.render_depth_mm(pose, cam, size)
+        tr = O.trunc_depth(O.depth_mm_to_m(mm), P["depth_trunc_min"], P["depth_trunc_max"])
+        n = O.vertices_to_normals(O.depth_to_vertices(O.bilateral(tr, P["filter_sigma_pixel"], P["filter_sigma_depth"]), ocam))
+        O.integrate(ovol, tr, n, None, False, False, pose, trunc, 2.5, ocam, ocam)
+        ctx.upload_depth_mm(mm)
+        ctx.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+        ctx.integrate(pose, trunc, 2.5)
+
+    counts = []
+    for frames in ((0,), (40, 80), (120, 160, 200)):
+        for k in frames:
+            fuse(k)
+        ctx.clear_triangles()
+        ctx.marching_cubes(thr)
+        o = O.marching_cubes(ovol, False, thr, 400000)
+        assert same_triangles(ctx.triangles(), o)
+        counts.append(len(o))
+    assert counts[0] > 500 and counts[-1] != counts[0]
+    ctx.reset_volume()
+    ctx.clear_triangles()
+    ctx.marching_cubes(thr)
+    assert len(ctx.triangles()) == 0
+    ovol.vox[...] = 0
+    fuse(300)
+    ctx.marching_cubes(thr)
+    assert same_triangles(ctx.triangles(), O.marching_cubes(ovol, False, thr, 400000))
+    ctx.close()

@@ -492,7 +492,7 @@ def test_tile_tables_follow_every_call_order():
 def test_work_counters_match_the_oracle_march():
     """kf_read_work_counters (the roofline accounting of SURVEY section 8d): the raycast counter equals the number of samples the
     ORACLE's march takes (its per-pixel step counts), the hit counter the number of rays whose crossing was evaluated, and the
-    marching-cubes counters the blocks visited / triangles produced."""
+    marching-cubes counters the bricks read / triangles produced."""
     res, size, cam, trunc = 128, 3.0, S.vga_camera(), 0.05          # 640x480 is a multiple of the raycast's 32x16 tile
     ctx, ovol, pose, ocam = _fuse_sequence(res, size, cam, 3, trunc, 2.5)
     inc = 0.7 * trunc
@@ -501,12 +501,12 @@ def test_work_counters_match_the_oracle_march():
     ctx.raycast(pose, inc, P["depth_trunc_min"], P["depth_trunc_max"])
     ctx.clear_triangles()
     ctx.marching_cubes(300 * size / res)
-    n_steps, n_hits, n_blocks, n_tris = ctx.work_counters()
+    n_steps, n_hits, n_bricks, n_tris = ctx.work_counters()
     total = int(np.asarray(steps, np.int64).sum())
     assert total > 1_000_000
     assert abs(n_steps - total) <= 0.001 * total + cam[0] * cam[1]      # the device derives the count from t: +-1 per ray at most
     assert n_tris == len(O.marching_cubes(ovol, False, 300 * size / res, 400000)) > 1000
-    assert 0 < n_blocks <= (res ** 3 + 255) // 256
+    assert 0 < n_bricks <= (res // 8) ** 3
     assert n_hits >= int((ov[..., 3] != 0).sum()) > 10000              # hits = crossings evaluated (some of them fail their taps)
     ms, cnt = ctx.read_stage_ms()
     assert cnt[7] == 1 and cnt[6] == 1 and ms[7] > 0 and ms[6] > 0

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Marching cubes alone: fuse a few frames of Scene S, then extract repeatedly (GPU).  usage: tools/bench_mcubes.py [c2|c4] [reps]
-Touched bytes (as VERDICT r1 #7 defines them for a flag-skipping extraction): 256-cell blocks whose
-neighbourhood holds a negative voxel x 2 KiB + 72 B per triangle."""
+Touched bytes (as VERDICT r1 #7 defines them for a flag-skipping extraction): bricks whose 3x3x3 brick
+neighbourhood holds a negative voxel x 4 KiB + 72 B per triangle."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -25,9 +25,9 @@ for _ in range(reps):
     ctx.clear_triangles()
     ctx.marching_cubes(thr)
 ms, cnt = ctx.read_stage_ms()
-_, _, blocks, tris = ctx.work_counters()
-blocks //= reps
+_, _, bricks, tris = ctx.work_counters()
+bricks //= reps
 t = ms[6] / cnt[6]
-touched = blocks * 2048 + tris * 72
-print("%s: %d^3, %d triangles, %d of %d blocks visited, extraction %.4f ms; touched %.1f MB -> %.1f GB/s (%.2f%% of 8 TB/s); dense-equivalent %.1f GB/s" % (
-    cfg, res, tris, blocks, (res ** 3 + 255) // 256, t, touched / 1e6, touched / t / 1e6, touched / t / 1e6 / 80, (res ** 3 * 8 + tris * 72) / t / 1e6))
+touched = bricks * 4096 + tris * 72
+print("%s: %d^3, %d triangles, %d of %d bricks read, extraction %.4f ms; touched %.1f MB -> %.1f GB/s (%.2f%% of 8 TB/s); dense-equivalent %.1f GB/s" % (
+    cfg, res, tris, bricks, (res // 8) ** 3, t, touched / 1e6, touched / t / 1e6, touched / t / 1e6 / 80, (res ** 3 * 8 + tris * 72) / t / 1e6))
