@@ -330,6 +330,44 @@ __global__ void __launch_bounds__(256) k_mc_dilate(KfVolume v, unsigned* __restr
   if (any) d1_list[at + (unsigned)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = slot;
 }
 
+// the same dilation 32 bricks at a time, for volumes whose brick rows are whole words of the packed has-negative bits (res a multiple
+// of 256): a lane ORs the 3 x 3 neighbouring rows' words, each widened by one bit to either side
+__global__ void __launch_bounds__(256) k_mc_dilate_words(KfVolume v, unsigned* __restrict__ nbr_bits, unsigned n_words, unsigned* __restrict__ d1_list, unsigned* n_d1,
+                                                         KfCounters* work) {
+  const unsigned w = blockIdx.x * 256u + threadIdx.x;
+  unsigned bits = 0;
+  if (w < n_words) {
+    const unsigned nb = (unsigned)v.nb, wpr = nb >> 5, nbz = (unsigned)(v.bz1 - v.bz0);
+    const unsigned xw = w % wpr, row = w / wpr;
+    const int by = (int)(row % nb), bzl = (int)(row / nb);
+    for (int dz = -1; dz <= 1; ++dz) {
+      const int zz = bzl + dz;
+      if (zz < 0 || zz >= (int)nbz) continue;
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = by + dy;
+        if (yy < 0 || yy >= (int)nb) continue;
+        const size_t base = ((size_t)zz * nb + (size_t)yy) * wpr;
+        const unsigned c = v.negbits[base + xw];
+        const unsigned l = xw > 0 ? v.negbits[base + xw - 1] : 0u, r = xw + 1 < wpr ? v.negbits[base + xw + 1] : 0u;
+        bits |= c | (c << 1) | (c >> 1) | (l >> 31) | (r << 31);
+      }
+    }
+    nbr_bits[w] = bits;
+  }
+  const unsigned mine = (unsigned)__popc(bits);
+  unsigned pre = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const unsigned t = __shfl_up(pre, off, 64); if ((threadIdx.x & 63) >= (unsigned)off) pre += t; }
+  const unsigned wave_total = (unsigned)__shfl(pre, 63, 64);
+  unsigned base = 0;
+  if ((threadIdx.x & 63) == 63 && wave_total) {
+    base = atomicAdd(n_d1, wave_total);
+    if (work) atomicAdd(&work->mc_blocks[(blockIdx.x & 63u) * 16u], (unsigned long long)wave_total);
+  }
+  base = (unsigned)__shfl(base, 63, 64) + pre - mine;
+  for (unsigned m = bits; m; m &= m - 1u) d1_list[base++] = w * 32u + (unsigned)__builtin_ctz(m);
+}
+
 __global__ void __launch_bounds__(256) k_mc_list(McArgs a) {
   const unsigned n_words = (a.n_blocks + 31u) / 32u;
   const unsigned w = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
@@ -604,7 +642,10 @@ extern "C" int kf_marching_cubes(kf_ctx* c, int has_color, float thr) {
   KF_CHECK(hipMemsetAsync(c->mc_list, 0, 4 * sizeof(unsigned), c->stream));
   KF_CHECK(hipMemsetAsync(c->mc_block_bits, 0, ((size_t)a.n_blocks / 32 + 1) * sizeof(unsigned), c->stream));
   const unsigned n_slots = (unsigned)c->n_stored_bricks;
-  hipLaunchKernelGGL(k_mc_dilate, dim3((n_slots + 255) / 256), dim3(256), 0, c->stream, c->vol, c->mc_nbr_bits, n_slots, a.d1_list, a.n_d1, c->count_work ? c->counters : nullptr);
+  if (c->vol.nb % 32 == 0)
+    hipLaunchKernelGGL(k_mc_dilate_words, dim3((n_slots / 32 + 255) / 256), dim3(256), 0, c->stream, c->vol, c->mc_nbr_bits, n_slots / 32, a.d1_list, a.n_d1, c->count_work ? c->counters : nullptr);
+  else
+    hipLaunchKernelGGL(k_mc_dilate, dim3((n_slots + 255) / 256), dim3(256), 0, c->stream, c->vol, c->mc_nbr_bits, n_slots, a.d1_list, a.n_d1, c->count_work ? c->counters : nullptr);
   const unsigned walk = (unsigned)c->num_cus * 8u;         // persistent workgroups walking the brick list / the block list / the records
   hipLaunchKernelGGL(k_mc_codes, dim3(walk), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(k_mc_sift, dim3(walk), dim3(256), 0, c->stream, a);

@@ -79,6 +79,19 @@ def test_sieve_keeps_every_cell_the_reference_triangulates(res, seed):
     ctx.close()
 
 
+def test_word_parallel_brick_dilation_at_256_cubed():
+    """res a multiple of 256: the brick dilation runs 32 bricks per lane on the packed has-negative words (k_mc_dilate_words);
+    surface right at the volume's faces and across word boundaries of the brick rows."""
+    res, size = 256, 3.0
+    t, w = stress_volume(res, 21)
+    o = O.marching_cubes(oracle_volume(res, size, t, w), False, 0.05, 6_000_000)
+    ctx = K.Context(K.camera(*CAM), res, size, P["volume_max_weight"], levels=3, max_triangles=6_000_000)
+    ctx.upload_volume(t, w)
+    ctx.marching_cubes(0.05)
+    assert 20000 < len(o) < 6_000_000 and same_triangles(ctx.triangles(), o)
+    ctx.close()
+
+
 def test_record_list_overflow_takes_the_block_walk():
     """More cells with triangles than the triangle buffer has room for: the per-cell record list overflows and the extraction falls
     back to walking the listed blocks; the first `cap` triangles of the canonical order are delivered either way."""
