@@ -438,7 +438,23 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
         if (KF_EXP_MODE(a) == 0 || KF_EXP_MODE(a) >= 8 || r.x == 123.456f) *p[b] = r;     // experiments 1 / 2: no store
         upd_total += (upd0[b] ? 1u : 0u) + (upd1[b] ? 1u : 0u);
         flags = KF_FLAG_OBSERVED | (((upd0[b] && nt.x < 0.f) || (upd1[b] && nt.y < 0.f)) ? KF_FLAG_HASNEG : 0u);
+#ifdef KF_EXPERIMENTS
+        if (KF_EXP_MODE(a) == 10) {                                                        // how many waves write back exactly what they read?
+          const bool same = __float_as_uint(r.x) == __float_as_uint(q[b].x) && __float_as_uint(r.y) == __float_as_uint(q[b].y) &&
+                            __float_as_uint(r.z) == __float_as_uint(q[b].z) && __float_as_uint(r.w) == __float_as_uint(q[b].w);
+          if (!same) flags |= 0x80u;
+        }
+#endif
       }
+#ifdef KF_EXPERIMENTS
+      if (KF_EXP_MODE(a) == 10) {
+        const unsigned long long anyupd = __ballot(flags & KF_FLAG_OBSERVED), changed = __ballot(flags & 0x80u);
+        if ((threadIdx.x & 63) == 0 && anyupd) {
+          // low word: waves that touched memory; high word: those of them that changed nothing (read back as the marching-cubes counter)
+          atomicAdd(&a.cnt->mc_blocks[(blockIdx.x & 63) * 16], 1ull + (changed ? 0ull : (1ull << 32)));
+        }
+      }
+#endif
       // brick flags: see k_integrate_bricks
       const unsigned wflags = ((__ballot(flags & KF_FLAG_OBSERVED) ? KF_FLAG_OBSERVED : 0u) | (__ballot(flags & KF_FLAG_HASNEG) ? KF_FLAG_HASNEG : 0u)) & ~fold[b];
       if (wflags && (threadIdx.x & 63) == 0) {
