@@ -157,7 +157,7 @@ extern "C" int kf_reset_volume(kf_ctx* c) {
   KF_CHECK(hipMemsetAsync(c->vol.macro, 0, (size_t)c->vol.nm * c->vol.nm * c->vol.nm, c->stream));
   KF_CHECK(hipMemsetAsync(c->vol.negbits, 0, kf_negbit_words(c->n_stored_bricks) * sizeof(unsigned), c->stream));
   KF_CHECK(hipMemsetAsync(c->counters, 0, sizeof(KfCounters), c->stream));
-  ++c->vol_flags_serial;
+  ++c->vol_flags_serial; c->fuse_calls = 0;
   return 0;
 }
 
@@ -407,7 +407,7 @@ extern "C" int kf_download_volume(kf_ctx* c, uint32_t z0, uint32_t z1, float* ts
   return volume_xfer(c, z0, z1, tsdf, weight, color, true);
 }
 extern "C" int kf_upload_volume(kf_ctx* c, uint32_t z0, uint32_t z1, const float* tsdf, const float* weight, const uint8_t* color) {
-  if (c) ++c->vol_flags_serial;                            // the upload rebuilds the brick flags: some may be cleared
+  if (c) { ++c->vol_flags_serial; c->fuse_calls = 0; }     // the upload rebuilds the brick flags: some may be cleared
   return volume_xfer(c, z0, z1, (float*)tsdf, (float*)weight, (uint8_t*)color, false);
 }
 

@@ -319,6 +319,10 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
           atomicOr(&v.negbits[slot[b] >> 5], 1u << (slot[b] & 31u));
         }
       }
+      // this kernel does not keep the saturation bits of k_integrate_pairs<.., true> current: a wave that writes drops its quarter's bit
+      const unsigned satbit = KF_FLAG_SAT0 << (threadIdx.x >> 6);
+      if ((fold[b] & satbit) && __ballot(flags & KF_FLAG_OBSERVED) && (threadIdx.x & 63) == 0)
+        atomicAnd(reinterpret_cast<unsigned*>(v.flags) + (slot[b] >> 2), ~(satbit << (8u * (slot[b] & 3u))));
     }
   }
   // N_upd: wave sum -> LDS -> ONE atomic per workgroup, spread over 64 counter lines
@@ -355,7 +359,14 @@ __device__ __forceinline__ kf_f2 kf_div2(kf_f2 a, const KfRecip2& k) {     // kf
   return f2_fma(e2, k.r, q1);
 }
 
-template <int BR>
+// SAT (used once max_weight frames have been fused since the last reset / upload -- before that no voxel can be saturated): free
+// space the camera keeps looking through ends up as (tsdf 1, weight max_weight), and one more free-space observation of such a voxel
+// is the identity bit for bit: (1 * w + 1) / (w + 1) == 1, min(w + 1, max) == w.  A per-brick flag bit per wave (KF_FLAG_SAT0 << wave)
+// says "these 128 voxels are all in that state"; a wave whose updating voxels all observe tsdf 1 again then neither reads nor writes
+// them -- it only counts them.  The bit is set by a wave that updated (hence read) all its 128 voxels and left nothing else behind,
+// and cleared by any wave that writes something else.  After 128 frames of the benchmark stream about half (512^3) to three quarters
+// (1024^3) of the waves that would touch memory are of this kind (tools/exp_noop_waves.py).
+template <int BR, bool SAT>
 __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   const KfVolume& v = a.vol;
   const unsigned n_active = a.cnt->n_active[a.parity] >> ((KF_EXP_MODE(a) == 8 || KF_EXP_MODE(a) == 9) ? KF_EXP_MODE(a) - 7 : 0);     // exp_mode 8 / 9: half / quarter of the queue (timing only)
@@ -367,6 +378,8 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   const KfRecip rt = kf_recip(a.sdf_trunc);
   KfRecip2 rtrunc; rtrunc.den = f2_splat(rt.den); rtrunc.r = f2_splat(rt.r);
   const unsigned xlim = (unsigned)(a.dcam.cols - 2), ylim = (unsigned)(a.dcam.rows - 2);
+  const unsigned satbit = KF_FLAG_SAT0 << (threadIdx.x >> 6);           // this wave's quarter of the brick (z layers 2w, 2w + 1)
+  const unsigned sat_w = __float_as_uint(v.max_weight), one_f = __float_as_uint(1.0f);
   __shared__ unsigned s_upd;
   unsigned upd_total = 0;
   if (threadIdx.x == 0) s_upd = 0;
@@ -413,24 +426,40 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
       upd0[b] = ok0[b] && d[b].x != 0.f && d[b].x < a.max_dist && sdf[b].x > -a.sdf_trunc;
       upd1[b] = ok1[b] && d[b].y != 0.f && d[b].y < a.max_dist && sdf[b].y > -a.sdf_trunc;
     }
+    // SAT: the observed tsdf first (it does not need the voxel); a wave whose quarter is saturated free space and whose updating
+    // voxels all observe tsdf 1 again skips the memory side altogether (wave-uniform)
+    kf_f2 tsdf_obs[BR]; bool skip[BR];
+#pragma unroll
+    for (int b = 0; b < BR; ++b) {
+      skip[b] = false;
+      if (SAT) {
+        tsdf_obs[b] = kf_div2(sdf[b], rtrunc);
+        tsdf_obs[b].x = fminf(1.0f, tsdf_obs[b].x); tsdf_obs[b].y = fminf(1.0f, tsdf_obs[b].y);
+        const bool changes = (upd0[b] && tsdf_obs[b].x != 1.0f) || (upd1[b] && tsdf_obs[b].y != 1.0f);
+        skip[b] = (fold[b] & satbit) != 0u && __ballot(changes) == 0ull;
+      }
+    }
     // one 16-byte read-modify-write per lane and brick, only where a voxel of the pair passed; the loads go out together
     float4* p[BR]; float4 q[BR];
 #pragma unroll
     for (int b = 0; b < BR; ++b) {
       p[b] = reinterpret_cast<float4*>(v.tw + (size_t)slot[b] * KF_BRICK_VOX) + threadIdx.x;
       q[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((upd0[b] || upd1[b]) && KF_EXP_MODE(a) != 2) q[b] = *p[b];
+      if ((upd0[b] || upd1[b]) && !skip[b] && KF_EXP_MODE(a) != 2) q[b] = *p[b];
     }
 #pragma unroll
     for (int b = 0; b < BR; ++b) {
+      if (SAT && skip[b]) { upd_total += (upd0[b] ? 1u : 0u) + (upd1[b] ? 1u : 0u); continue; }       // uniform: counted, nothing else to do
       // tsdfVolume.h:63-66 on both voxels; a voxel that failed the predicate keeps its stored value
-      kf_f2 tsdf = kf_div2(sdf[b], rtrunc);
-      tsdf.x = fminf(1.0f, tsdf.x); tsdf.y = fminf(1.0f, tsdf.y);
+      kf_f2 tsdf;
+      if (SAT) tsdf = tsdf_obs[b];
+      else { tsdf = kf_div2(sdf[b], rtrunc); tsdf.x = fminf(1.0f, tsdf.x); tsdf.y = fminf(1.0f, tsdf.y); }
       const kf_f2 ot = {q[b].x, q[b].z}, ow = {q[b].y, q[b].w};
       const kf_f2 ow1 = ow + f2_splat(1.f);
       const kf_f2 nt = kf_div2(ot * ow + tsdf, kf_recip2(ow1));               // `tsdf * 1.f` is the identity, bit for bit
       const float nw0 = fminf(ow1.x, v.max_weight), nw1 = fminf(ow1.y, v.max_weight);
       unsigned flags = 0;
+      bool lane_sat = false;
       if (upd0[b] || upd1[b]) {
         float4 r = q[b];
         if (upd0[b]) { r.x = nt.x; r.y = nw0; }
@@ -438,6 +467,7 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
         if (KF_EXP_MODE(a) == 0 || KF_EXP_MODE(a) >= 8 || r.x == 123.456f) *p[b] = r;     // experiments 1 / 2: no store
         upd_total += (upd0[b] ? 1u : 0u) + (upd1[b] ? 1u : 0u);
         flags = KF_FLAG_OBSERVED | (((upd0[b] && nt.x < 0.f) || (upd1[b] && nt.y < 0.f)) ? KF_FLAG_HASNEG : 0u);
+        if (SAT) lane_sat = __float_as_uint(r.x) == one_f && __float_as_uint(r.z) == one_f && __float_as_uint(r.y) == sat_w && __float_as_uint(r.w) == sat_w;
 #ifdef KF_EXPERIMENTS
         if (KF_EXP_MODE(a) == 10) {                                                        // how many waves write back exactly what they read?
           const bool same = __float_as_uint(r.x) == __float_as_uint(q[b].x) && __float_as_uint(r.y) == __float_as_uint(q[b].y) &&
@@ -456,12 +486,20 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
       }
 #endif
       // brick flags: see k_integrate_bricks
-      const unsigned wflags = ((__ballot(flags & KF_FLAG_OBSERVED) ? KF_FLAG_OBSERVED : 0u) | (__ballot(flags & KF_FLAG_HASNEG) ? KF_FLAG_HASNEG : 0u)) & ~fold[b];
+      const unsigned long long wrote = __ballot(flags & KF_FLAG_OBSERVED);
+      const unsigned wflags = ((wrote ? KF_FLAG_OBSERVED : 0u) | (__ballot(flags & KF_FLAG_HASNEG) ? KF_FLAG_HASNEG : 0u)) & ~fold[b];
       if (wflags && (threadIdx.x & 63) == 0) {
         atomicOr(reinterpret_cast<unsigned*>(v.flags) + (slot[b] >> 2), wflags << (8u * (slot[b] & 3u)));
         if (wflags & KF_FLAG_HASNEG) {
           v.macro[((size_t)(bz[b] >> 2) * v.nm + (by[b] >> 2)) * v.nm + (bx[b] >> 2)] = 1;
           atomicOr(&v.negbits[slot[b] >> 5], 1u << (slot[b] & 31u));
+        }
+      }
+      if (SAT && wrote) {                                                  // the quarter's saturation bit follows what this wave left behind
+        const bool now_sat = __ballot(lane_sat) == ~0ull, was_sat = (fold[b] & satbit) != 0u;      // all 64 lanes wrote: all 128 voxels known
+        if (now_sat != was_sat && (threadIdx.x & 63) == 0) {
+          unsigned* w = reinterpret_cast<unsigned*>(v.flags) + (slot[b] >> 2);
+          if (now_sat) atomicOr(w, satbit << (8u * (slot[b] & 3u))); else atomicAnd(w, ~(satbit << (8u * (slot[b] & 3u))));
         }
       }
     }
@@ -571,15 +609,24 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
     else
 #endif
     if (pairs) {
-      if (br == 1) hipLaunchKernelGGL((k_integrate_pairs<1>), dim3(grid), dim3(256), 0, c->stream, a);
-      else if (br == 2) hipLaunchKernelGGL((k_integrate_pairs<2>), dim3(grid), dim3(256), 0, c->stream, a);
-      else hipLaunchKernelGGL((k_integrate_pairs<4>), dim3(grid), dim3(256), 0, c->stream, a);
+      // saturated free space can only exist once max_weight frames have been fused since the volume was last reset or uploaded
+      static int sat_env = -1;
+      if (sat_env < 0) { const char* e = getenv("KF_INTEGRATE_SAT"); sat_env = e ? atoi(e) : 1; }
+      const bool sat = sat_env == 2 || (sat_env == 1 && (float)c->fuse_calls >= c->vol.max_weight);
+      if (sat) {
+        if (br == 1) hipLaunchKernelGGL((k_integrate_pairs<1, true>), dim3(grid), dim3(256), 0, c->stream, a);
+        else if (br == 2) hipLaunchKernelGGL((k_integrate_pairs<2, true>), dim3(grid), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_integrate_pairs<4, true>), dim3(grid), dim3(256), 0, c->stream, a);
+      } else if (br == 1) hipLaunchKernelGGL((k_integrate_pairs<1, false>), dim3(grid), dim3(256), 0, c->stream, a);
+      else if (br == 2) hipLaunchKernelGGL((k_integrate_pairs<2, false>), dim3(grid), dim3(256), 0, c->stream, a);
+      else hipLaunchKernelGGL((k_integrate_pairs<4, false>), dim3(grid), dim3(256), 0, c->stream, a);
     } else if (br == 1) hipLaunchKernelGGL((k_integrate_bricks<false, 1>), dim3(grid), dim3(256), 0, c->stream, a);
     else if (br == 2) hipLaunchKernelGGL((k_integrate_bricks<false, 2>), dim3(grid), dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL((k_integrate_bricks<false, 4>), dim3(grid), dim3(256), 0, c->stream, a);
   }
   kf_evt_end(c, KF_STAGE_INTEGRATE_KERNEL);
   kf_evt_end(c, KF_STAGE_INTEGRATE);
+  if (c->fuse_calls != 0xFFFFFFFFu) ++c->fuse_calls;
   return (int)hipGetLastError();
 }
 

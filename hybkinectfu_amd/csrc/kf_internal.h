@@ -13,6 +13,8 @@
 #define KF_BRICK_VOX 512           // voxels per brick: 4 KiB of (tsdf, weight) pairs, contiguous in HBM
 #define KF_FLAG_OBSERVED 1u        // some voxel of the brick has weight > 0
 #define KF_FLAG_HASNEG 2u          // some voxel of the brick has (or once had) tsdf < 0
+#define KF_FLAG_SAT0 16u           // bits 4..7: z-layer pair q (voxels of layers 2q, 2q+1) holds nothing but (tsdf 1, weight max_weight):
+                                  // free space that further free-space observations cannot change (integrate.hip)
 #define KF_MACRO 32                // voxels per macro-cell edge (raycast empty-space skipping)
 #define KF_MAX_LEVELS 3
 #define KF_ICP_MAX_WG 2048             // workgroups of one ICP / SDF step launch (1536 pixels each: up to 3.1 M pixels)
@@ -149,6 +151,7 @@ struct kf_ctx {
   unsigned* mc_block_counts; size_t mc_blocks_cap;
   unsigned* mc_list; unsigned* mc_nbr_bits; unsigned* mc_partials;   // extraction scratch, allocated by the first kf_marching_cubes
   unsigned short* mc_codes; unsigned char* mc_surv; unsigned* mc_block_bits; uint2* mc_recs; unsigned* mc_d1_list;   // voxel classes, sieve bits, cell records, brick list (mcubes.hip), same scratch
+  unsigned fuse_calls;           // integrate calls since the volume was last reset or uploaded (saturation can only exist after max_weight of them)
   unsigned vol_flags_serial, mc_zero_serial;   // bumped when brick flags may have been CLEARED (reset, upload) / the serial the class tables were last zeroed for
   void* host_pinned;                  // small pinned staging buffer (4 KiB); byte KF_PINNED_STALL_WORD: the ICP loop's stall word
   // per-stage hipEvent timers (KF_STAGE_*): bit s of timers_enabled turns stage s on
