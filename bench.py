@@ -102,6 +102,44 @@ def single_gpu_reference(name, n_frames=50, warmup=10):
                 ms_per_step=round(1000.0 * dt / (n_frames - warmup), 4), frames_lost=int(lost))
 
 
+def steady_state(name, n_timed=100):
+    """The same stream after max_weight frames: free space the camera keeps looking through has saturated at (tsdf 1, weight
+    max_weight), one more free-space observation of it is the identity, and the fusion pass no longer reads or writes it
+    (integrate.hip, k_integrate_pairs<.., SAT>).  Reported next to -- never instead of -- the early-regime numbers: frames/s, the
+    fusion kernel's time, and the reference's bytes (N_upd x 16 B + the depth image) over that time."""
+    import torch
+    from hybkinectfu_amd.pipeline import SingleGpuPipeline
+    wl = workload(1, name)
+    cam = wl["cam"]
+    frames, _ = S.make_stream(100, cam, wl["size"])
+    dev = torch.from_numpy(frames.astype(np.int16)).cuda()
+    fb = cam[0] * cam[1] * 2
+    pipe = SingleGpuPipeline(K.camera(*cam), wl["res"], wl["size"], wl, device=torch.cuda.current_device())
+    n_pre = int(P["volume_max_weight"]) + 32
+    for k in range(n_pre):
+        pipe.process_frame_device(dev.data_ptr() + (k % 100) * fb, k)
+    pipe.sync(); torch.cuda.synchronize()
+    s0 = pipe.stats()
+    pipe.stage_timers((1 << 5) | (1 << 3) | (4 << 8))
+    t0 = time.perf_counter()
+    for k in range(n_pre, n_pre + n_timed):
+        pipe.process_frame_device(dev.data_ptr() + (k % 100) * fb, k)
+    pipe.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, cnt = pipe.read_stage_ms()
+    s1 = pipe.stats()
+    pipe.close()
+    n_upd = (s1["updated_total"] - s0["updated_total"]) / n_timed
+    alg = n_upd * 16.0 + cam[0] * cam[1] * 4.0
+    k_ms = float(ms[5]) / max(int(cnt[5]), 1)
+    return dict(workload=wl["desc"], frames_fused_before=n_pre, steps=n_timed, value=round(n_timed / dt, 2), unit="frames/s",
+                frames_lost=int(s1["frames_lost"] - s0["frames_lost"]), kernel="k_integrate_pairs<.., SAT>", kernel_ms=round(k_ms, 5),
+                launches_timed=int(cnt[5]), reference_bytes_per_launch=int(alg),
+                reference_bytes_rate=round(alg / (k_ms * 1e-3) / 1e9, 2) if k_ms > 0 else None, unit_rate="GB/s",
+                frac_of_hbm_peak=round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
+                note="bytes the REFERENCE's update moves for these frames / kernel time; the kernel itself moves fewer: saturated free space is counted, not touched")
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process is only a parent.  It has made no GPU call
     (no torch.cuda, no libhybkf) and starts N fresh rank processes -- `python -m torch.distributed.run`, one per GPU, rendezvous on
@@ -426,6 +464,7 @@ def main():
     if extras:
         pipe.close()
         out["pcie_inclusive"] = pcie_inclusive(wl, frames)
+        out["steady_state"] = {"C2": steady_state("c2"), "C4": steady_state("c4")}
     if world == 1 and not args.no_cpu_baseline and not wl.get("extract_mesh"):      # (the oracle's 2048^3 volume would need 103 GB of host memory)
         pipe.close()
         out["cpu_baseline"] = cpu_baseline(wl, frames, n_sample=150 if wl["res"] <= 512 else 40)      # 10-20 s of CPU work either way

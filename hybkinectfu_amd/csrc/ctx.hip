@@ -130,8 +130,9 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
   {                                                          // tile maxima over 8- and 16-pixel tiles, see integrate.hip
     size_t n = 0;
     for (int l = 0; l < 2; ++l) n += (size_t)kf_div_up(c->cols, 8 << l) * kf_div_up(c->rows, 8 << l);
-    TRY(dev_alloc(&c->tile_max_depth, n));
+    TRY(dev_alloc(&c->tile_max_depth, 2 * n));             // [maxima | minima]: the second half holds the tile MINIMA (same layout)
     TRY((int)hipMemsetAsync(c->tile_max_depth, 0, n * sizeof(float), c->stream));
+    TRY((int)hipMemsetD32Async((hipDeviceptr_t)(c->tile_max_depth + n), 0x7F800000, n, c->stream));     // cleared minima: +inf
     c->n_tile_floats = (int)n; c->tiles_clear = 1;
   }
   c->max_triangles = cfg->max_triangles;

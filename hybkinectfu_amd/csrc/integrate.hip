@@ -34,7 +34,8 @@ struct IntegrateArgs {
   float fr_slope[4], fr_norm[4]; // frustum side planes through the eye (left, right, top, bottom), widened by one pixel: slope and sqrt(1+slope^2)
   int exp_mode;                  // timing experiments only (KF_INTEGRATE_EXP): 1 = no store, 2 = no load/store
   int parity;                    // which of the double-buffered counter sets (KfCounters) this call uses
-  int clear_tiles, n_tile_floats;   // the fusion pass zeroes the tile tables once the cull has read them
+  int clear_tiles, n_tile_floats;   // the fusion pass clears the tile tables (maxima to 0, minima to +inf) once the cull has read them
+  int sat_cull;                  // the saturation bits are in use (k_integrate_pairs<.., SAT>): the cull may retire whole saturated bricks
 };
 
 // Retire the OTHER parity's counters (nobody touches them during this launch) and clear the tile tables for the next frame's fused
@@ -46,7 +47,7 @@ __device__ __forceinline__ void integrate_maintenance(const IntegrateArgs& a) {
     a.cnt->upd_shard[o][threadIdx.x * 16] = 0ull;
   }
   if (threadIdx.x == 0) a.cnt->n_active[o] = 0u;
-  if (a.clear_tiles) for (int i = threadIdx.x; i < a.n_tile_floats; i += blockDim.x) a.tile_max[i] = 0.f;
+  if (a.clear_tiles) for (int i = threadIdx.x; i < a.n_tile_floats; i += blockDim.x) { a.tile_max[i] = 0.f; a.tile_max[a.n_tile_floats + i] = __builtin_huge_valf(); }
 }
 
 
@@ -56,13 +57,23 @@ __device__ __forceinline__ void integrate_maintenance(const IntegrateArgs& a) {
 // built per cull workgroup in LDS): they only matter for the few bricks next to the eye and cost more than they save.
 // (Fallback: normally the fused preprocess kernel has built the tables already -- preprocess.hip, KfTileAccum.)
 __global__ void __launch_bounds__(256) k_integrate_prepare(IntegrateArgs a) {
-  __shared__ float s_q[4][2][2];                             // [wave][left / right half][unused pad]
+  __shared__ float s_q[4][2][2];                             // [wave][left / right half][max, min]
   const int bw = a.tile_w[1];
   const int tx = blockIdx.x % bw, ty = blockIdx.x / bw;
   const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
   const int x = tx * 16 + lx, y = ty * 16 + ly;
-  float d = 0.f;
-  if (x < a.dcam.cols && y < a.dcam.rows) { float v = a.depth[y * a.dcam.cols + x]; d = (v < a.max_dist) ? v : 0.f; }
+  float d = 0.f, mn = __builtin_huge_valf();
+  if (x < a.dcam.cols && y < a.dcam.rows) { float v = a.depth[y * a.dcam.cols + x]; d = (v < a.max_dist) ? v : 0.f; mn = d; }   // minima: 0 = some pixel cannot integrate
+  {                                                          // the tile minima, same reductions with fminf (pixels outside the image: +inf)
+    mn = fminf(mn, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(mn), 0xB1, 0xf, 0xf, false)));
+    mn = fminf(mn, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(mn), 0x4E, 0xf, 0xf, false)));
+    mn = fminf(mn, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(mn), 0x141, 0xf, 0xf, false)));
+  }
+  const int mi = __float_as_int(mn);
+  const float mleft = fminf(fminf(__int_as_float(__builtin_amdgcn_readlane(mi, 0)), __int_as_float(__builtin_amdgcn_readlane(mi, 16))),
+                            fminf(__int_as_float(__builtin_amdgcn_readlane(mi, 32)), __int_as_float(__builtin_amdgcn_readlane(mi, 48))));
+  const float mright = fminf(fminf(__int_as_float(__builtin_amdgcn_readlane(mi, 8)), __int_as_float(__builtin_amdgcn_readlane(mi, 24))),
+                             fminf(__int_as_float(__builtin_amdgcn_readlane(mi, 40)), __int_as_float(__builtin_amdgcn_readlane(mi, 56))));
   // a wave holds four image rows of 16 pixels (one DPP row each): two quad permutes and a half-row mirror leave the maximum of
   // every 8-pixel half row in all of its lanes; eight readlanes then combine the four rows (no LDS shuffles)
   d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0xB1, 0xf, 0xf, true)));    // quad_perm:[1,0,3,2]
@@ -74,19 +85,22 @@ __global__ void __launch_bounds__(256) k_integrate_prepare(IntegrateArgs a) {
   const float right = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(di, 8)), __int_as_float(__builtin_amdgcn_readlane(di, 24))),
                             fmaxf(__int_as_float(__builtin_amdgcn_readlane(di, 40)), __int_as_float(__builtin_amdgcn_readlane(di, 56))));
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) { s_q[wave][0][0] = left; s_q[wave][1][0] = right; }
+  if (lane == 0) { s_q[wave][0][0] = left; s_q[wave][1][0] = right; s_q[wave][0][1] = mleft; s_q[wave][1][1] = mright; }
   __syncthreads();
+  float* tile_min = a.tile_max + a.n_tile_floats;
   if (threadIdx.x < 4) {                                     // level 0: quadrant (qx, qy) = waves 2*qy and 2*qy + 1, half qx
     const int hx = threadIdx.x & 1, hy = threadIdx.x >> 1;
     const float q = fmaxf(s_q[2 * hy][hx][0], s_q[2 * hy + 1][hx][0]);
+    const float qm = fminf(s_q[2 * hy][hx][1], s_q[2 * hy + 1][hx][1]);
     const int qx = tx * 2 + hx, qy = ty * 2 + hy;
-    if (qx < a.tile_w[0] && qy < a.tile_h[0]) a.tile_max[a.tile_off[0] + qy * a.tile_w[0] + qx] = q;
+    if (qx < a.tile_w[0] && qy < a.tile_h[0]) { a.tile_max[a.tile_off[0] + qy * a.tile_w[0] + qx] = q; tile_min[a.tile_off[0] + qy * a.tile_w[0] + qx] = qm; }
   }
   if (threadIdx.x == 0) {
-    float m16 = 0.f;
+    float m16 = 0.f, n16 = __builtin_huge_valf();
 #pragma unroll
-    for (int w = 0; w < 4; ++w) m16 = fmaxf(m16, fmaxf(s_q[w][0][0], s_q[w][1][0]));
+    for (int w = 0; w < 4; ++w) { m16 = fmaxf(m16, fmaxf(s_q[w][0][0], s_q[w][1][0])); n16 = fminf(n16, fminf(s_q[w][0][1], s_q[w][1][1])); }
     a.tile_max[a.tile_off[1] + blockIdx.x] = m16;
+    tile_min[a.tile_off[1] + blockIdx.x] = n16;
   }
 }
 
@@ -109,13 +123,16 @@ __device__ __forceinline__ bool cull_sphere_visible(const IntegrateArgs& a, cons
 }
 
 #define CULL_WAVES 16
-__global__ void __launch_bounds__(CULL_WAVES * 64) k_integrate_cull(IntegrateArgs a) {
+// SAT: the saturation bits are in use -> whole saturated free-space bricks can be retired here (see below); a separate instantiation
+// because the extra test costs registers the plain cull needs for two workgroups per CU
+template <bool SAT>
+__global__ void __launch_bounds__(CULL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) k_integrate_cull(IntegrateArgs a) {
   if (a.track && !a.track->tracked) {                        // HybKinectfu.cpp:123: integrate only when tracking succeeded
     if (blockIdx.x == 0 && threadIdx.x == 0) a.cnt->frames_lost += 1;
     return;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) a.cnt->frames_fused += 1;
-  __shared__ unsigned s_cnt[CULL_WAVES];
+  __shared__ unsigned s_cnt[CULL_WAVES], s_noop[CULL_WAVES];
   __shared__ unsigned s_base;
   const KfVolume& v = a.vol;
   const int nmxy = (v.nb + 3) >> 2;                          // macro cells per x / y
@@ -156,11 +173,14 @@ __global__ void __launch_bounds__(CULL_WAVES * 64) k_integrate_cull(IntegrateArg
   }
   // depth test against the tile max over the brick's pixel footprint (only when the brick is clear of the eye plane)
   const float zn = pz - ez, zf = pz + ez;
+  bool noop = false;                                                       // a brick retired here: its 512 voxels are counted, not visited
   if (keep && zn > 4.f * cell) {
     const float xl = px - ex, xr = px + ex, yl = py - ey, yr = py + ey;
     float u0 = (xl < 0.f ? xl / zn : xl / zf) * a.dcam.fx + a.dcam.cx, u1 = (xr > 0.f ? xr / zn : xr / zf) * a.dcam.fx + a.dcam.cx;
     float w0 = (yl < 0.f ? yl / zn : yl / zf) * a.dcam.fy + a.dcam.cy, w1 = (yr > 0.f ? yr / zn : yr / zf) * a.dcam.fy + a.dcam.cy;
     int ix0 = (int)floorf(u0) - 1, ix1 = (int)ceilf(u1) + 2, iy0 = (int)floorf(w0) - 1, iy1 = (int)ceilf(w1) + 2;
+    // every voxel's pixel lies in [ix0, ix1] x [iy0, iy1]: inside the reference's 1 .. cols-2 / rows-2 window (integrateVolume.cu:43)?
+    const bool all_inside = ix0 >= 1 && iy0 >= 1 && ix1 <= a.dcam.cols - 2 && iy1 <= a.dcam.rows - 2;
     ix0 = max(ix0, 0); iy0 = max(iy0, 0); ix1 = min(ix1, a.dcam.cols - 1); iy1 = min(iy1, a.dcam.rows - 1);
     if (ix0 > ix1 || iy0 > iy1) keep = false;
     else {
@@ -179,19 +199,38 @@ __global__ void __launch_bounds__(CULL_WAVES * 64) k_integrate_cull(IntegrateArg
           for (int i = 0; i < 4; ++i) dmax = fmaxf(dmax, tbl[min(ty0 + j, ty1) * tw + min(tx0 + i, tx1)]);
         if (dmax == 0.f) keep = false;                                     // no pixel under the brick can integrate
         else if (zn >= dmax + a.sdf_trunc) keep = false;                   // every voxel lies behind every surface it can see
+        else if (SAT && all_inside) {
+          // Saturated free space seen as free space again: all four saturation bits of the brick are set (its 512 voxels are
+          // exactly (tsdf 1, weight max_weight)), every voxel projects inside the image window, every pixel it can land on holds a
+          // depth that integrates (tile minimum > 0 means: all valid, all < max_dist) and that depth is at least one truncation
+          // distance behind the brick's far side -> every voxel passes the reference's predicate (:39-67), observes tsdf
+          // min(1, sdf / trunc) = 1, and (1 * w + 1) / (w + 1) = 1, min(w + 1, max) = w leave it as it is.  Nothing to do but count.
+          const unsigned f = v.flags[kf_brick_slot(v, bx, by, bz)];
+          if ((f & (15u * KF_FLAG_SAT0)) == 15u * KF_FLAG_SAT0) {
+            const float* tmn = tbl + a.n_tile_floats;
+            float dmin = __builtin_huge_valf();
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) dmin = fminf(dmin, tmn[min(ty0 + j, ty1) * tw + min(tx0 + i, tx1)]);
+            if (dmin > 0.f && dmin - zf >= a.sdf_trunc + eps) { keep = false; noop = true; }
+          }
+        }
       }                                                                    // larger footprints (bricks close to the eye) are kept
     }
   }
   // compaction: ONE atomic per 16 macro cells (an address takes ~11 ns per atomic; per-wave atomics made this pass
   // cost more than the fusion itself at 1024^3)
   const unsigned long long mask = __ballot(keep);
-  if (lane == 0) s_cnt[wid] = (unsigned)__popcll(mask);
+  const unsigned n_noop = SAT ? (unsigned)__popcll(__ballot(noop)) : 0u;
+  if (lane == 0) { s_cnt[wid] = (unsigned)__popcll(mask); s_noop[wid] = n_noop; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned total = 0;
+    unsigned total = 0, retired = 0;
 #pragma unroll
-    for (int w = 0; w < CULL_WAVES; ++w) { const unsigned n = s_cnt[w]; s_cnt[w] = total; total += n; }
+    for (int w = 0; w < CULL_WAVES; ++w) { const unsigned n = s_cnt[w]; s_cnt[w] = total; total += n; retired += s_noop[w]; }
     s_base = total ? atomicAdd(&a.cnt->n_active[a.parity], total) : 0u;
+    if (retired) atomicAdd(&a.cnt->upd_shard[a.parity][(blockIdx.x & 63) * 16], (unsigned long long)retired * KF_BRICK_VOX);   // N_upd stays exact
   }
   __syncthreads();
   if (keep) {
@@ -547,6 +586,13 @@ static inline KfCam to_cam(const kf_camera_params* p) {
   KfCam c; c.cols = (int)p->cols; c.rows = (int)p->rows; c.cx = p->cx; c.cy = p->cy; c.fx = p->fx; c.fy = p->fy; return c;
 }
 
+// KF_INTEGRATE_SAT: 0 never, 2 from the first frame, default 1 = after max_weight fused frames
+bool kf_sat_regime(const kf_ctx* c) {
+  static int sat_env = -1;
+  if (sat_env < 0) { const char* e = getenv("KF_INTEGRATE_SAT"); sat_env = e ? atoi(e) : 1; }
+  return sat_env == 2 || (sat_env == 1 && (float)c->fuse_calls >= c->vol.max_weight);
+}
+
 extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weight_color, const kf_mat44* transform,
                                    const kf_integrate_params* ip, const kf_camera_params* dcam, const kf_camera_params* rcam) {
   if (!c || !ip || !dcam) return KF_ERR_ARG;
@@ -577,16 +623,24 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   }
   a.parity = c->int_parity; c->last_parity = c->int_parity; c->int_parity ^= 1;
   a.clear_tiles = 1; a.n_tile_floats = c->n_tile_floats;
+  // saturated free space can only exist once max_weight frames have been fused since the volume was last reset or uploaded; the
+  // saturation bits are kept by the packed-pair kernel only
+  static int pairs_env = -1;
+  if (pairs_env < 0) { const char* e = getenv("KF_INTEGRATE_PAIRS"); pairs_env = e ? atoi(e) : 1; }
+  const bool sat = !has_color && pairs_env && kf_sat_regime(c);
+  a.sat_cull = 0;                                        // decided below, once it is known whether the tile minima describe this depth map
   kf_evt_begin(c, KF_STAGE_INTEGRATE);
   // tile maxima: normally left behind by the fused preprocess kernel for exactly this depth map and distance
   const bool tiles_ready = c->tile_serial != 0 && c->tile_serial == c->trunc_serial && c->tile_built_dist == a.max_dist;
-  if (!tiles_ready) hipLaunchKernelGGL(k_integrate_prepare, dim3(a.tile_w[1] * a.tile_h[1]), dim3(256), 0, c->stream, a);
+  if (!tiles_ready) { hipLaunchKernelGGL(k_integrate_prepare, dim3(a.tile_w[1] * a.tile_h[1]), dim3(256), 0, c->stream, a); c->tile_min_serial = c->trunc_serial; }
+  a.sat_cull = (sat && c->tile_min_serial == c->trunc_serial) ? 1 : 0;     // whole-brick retirement needs the minima of THIS depth map
   c->fuse_max_dist = a.max_dist;                         // what the next preprocess builds the tables for
   c->tile_serial = 0; c->tiles_clear = 1;                // the fusion pass below clears the tables behind the cull
   {
     const int nmxy = (c->vol.nb + 3) >> 2, nmz = ((c->vol.bz1 + 3) >> 2) - (c->vol.bz0 >> 2);
     const unsigned n_macro = (unsigned)nmxy * nmxy * nmz;                      // one wave per macro cell, sixteen per workgroup
-    hipLaunchKernelGGL(k_integrate_cull, dim3((n_macro + CULL_WAVES - 1) / CULL_WAVES), dim3(CULL_WAVES * 64), 0, c->stream, a);
+    if (a.sat_cull) hipLaunchKernelGGL(k_integrate_cull<true>, dim3((n_macro + CULL_WAVES - 1) / CULL_WAVES), dim3(CULL_WAVES * 64), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_integrate_cull<false>, dim3((n_macro + CULL_WAVES - 1) / CULL_WAVES), dim3(CULL_WAVES * 64), 0, c->stream, a);
   }
   static unsigned grid_cap = 0;                          // workgroups walking the queue: tuning knob
   if (!grid_cap) { const char* e = getenv("KF_INTEGRATE_GRID"); grid_cap = e ? (unsigned)atoi(e) : 8192u; if (grid_cap < 64u || grid_cap > 65536u) grid_cap = 8192u; }
@@ -609,10 +663,6 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
     else
 #endif
     if (pairs) {
-      // saturated free space can only exist once max_weight frames have been fused since the volume was last reset or uploaded
-      static int sat_env = -1;
-      if (sat_env < 0) { const char* e = getenv("KF_INTEGRATE_SAT"); sat_env = e ? atoi(e) : 1; }
-      const bool sat = sat_env == 2 || (sat_env == 1 && (float)c->fuse_calls >= c->vol.max_weight);
       if (sat) {
         if (br == 1) hipLaunchKernelGGL((k_integrate_pairs<1, true>), dim3(grid), dim3(256), 0, c->stream, a);
         else if (br == 2) hipLaunchKernelGGL((k_integrate_pairs<2, true>), dim3(grid), dim3(256), 0, c->stream, a);

@@ -56,6 +56,9 @@ struct KfVolume {
   float max_weight;
 };
 
+// (declared in integrate.hip) may saturated free space exist -- max_weight frames fused since the last reset / upload, KF_INTEGRATE_SAT?
+bool kf_sat_regime(const struct kf_ctx* c);
+
 // Device-resident tracker state (what CameraPoseFinder keeps in _pose plus the Gauss-Newton scratch).
 struct KfTrackState {
   float pose[16];        // CameraPoseFinder::_pose
@@ -144,6 +147,7 @@ struct kf_ctx {
   // The tables are normally built by the fused preprocess kernel (atomic max into a CLEARED table) for the integration distance
   // the last kf_integrate_volume used; integrate falls back to k_integrate_prepare when they do not describe the current trunced
   // depth map (serials differ) or another distance is asked for.  The fusion pass clears them again once the cull has read them.
+  unsigned long long tile_min_serial;   // trunc_serial the tile MINIMA were built for (only built while saturation can exist)
   unsigned long long trunc_serial, tile_serial;   // bumped by every writer of trunced_depth / copied when the tables are built
   float tile_built_dist, fuse_max_dist;
   int tiles_clear, int_parity, last_parity;

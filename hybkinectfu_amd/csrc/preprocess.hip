@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) k_bilateral(const float* __restrict__ in,
 // steps give the max of each 8-pixel group and one more that of each 16-pixel group, and the group leaders merge them into the
 // (cleared) tables with fire-and-forget integer atomic maxima -- non-negative floats order like their bit patterns.  That replaces
 // a launch of its own (k_integrate_prepare) in front of every integrate.  acc.tile == nullptr: tables not wanted.
-struct KfTileAccum { int* tile; int off0, w0, off1, w1; float max_dist; };
+struct KfTileAccum { int* tile; int off0, w0, off1, w1, n; float max_dist; };   // n: entries of both maxima tables = offset of the minima (0: minima not wanted)
 template <int R>
 __global__ void __launch_bounds__(256) k_gate_bilateral(const uint16_t* __restrict__ mm, const float* __restrict__ raw_in,
                                                         float* __restrict__ raw_out, float* __restrict__ trunced, float* __restrict__ filtered,
@@ -104,6 +104,17 @@ __global__ void __launch_bounds__(256) k_gate_bilateral(const uint16_t* __restri
     // a group whose leader lies outside the image holds no pixel at all (d == 0): the indices below stay inside the tables
     if ((lx & 7) == 0 && d > 0.f) atomicMax(acc.tile + acc.off0 + (y >> 3) * acc.w0 + (x >> 3), __float_as_int(d));
     if ((lx & 15) == 0 && d16 > 0.f) atomicMax(acc.tile + acc.off1 + (y >> 4) * acc.w1 + (x >> 4), __float_as_int(d16));
+    // the tile MINIMA (second half of the buffer, cleared to +inf): 0 as soon as one pixel of the tile cannot integrate (invalid or
+    // beyond max_dist), else the smallest depth -- what lets the cull prove "every voxel of this brick sees free space" (integrate.hip)
+    if (acc.n) {                                             // uniform
+    float m = inside ? ((value != 0.f && value < acc.max_dist) ? value : 0.f) : __builtin_huge_valf();
+    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0xB1, 0xf, 0xf, false)));
+    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0x4E, 0xf, 0xf, false)));
+    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0x141, 0xf, 0xf, false)));
+    const float m16 = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0x140, 0xf, 0xf, false)));
+    if ((lx & 7) == 0 && x < cols && y < rows) atomicMin(acc.tile + acc.n + acc.off0 + (y >> 3) * acc.w0 + (x >> 3), __float_as_int(m));
+    if ((lx & 15) == 0 && x < cols && y < rows) atomicMin(acc.tile + acc.n + acc.off1 + (y >> 4) * acc.w1 + (x >> 4), __float_as_int(m16));
+    }
   }
   if (!inside) return;
   float result = value;
@@ -313,6 +324,7 @@ static int launch_fused_preprocess(kf_ctx* c, hipStream_t stream, const uint16_t
   if (build_tiles) {                                       // layout of the two tables: kf_integrate_volume (integrate.hip)
     acc.tile = reinterpret_cast<int*>(c->tile_max_depth); acc.max_dist = c->fuse_max_dist;
     acc.off0 = 0; acc.w0 = kf_div_up(c->cols, 8); acc.off1 = acc.w0 * kf_div_up(c->rows, 8); acc.w1 = kf_div_up(c->cols, 16);
+    acc.n = kf_sat_regime(c) ? c->n_tile_floats : 0;         // the minima only matter once saturated free space can exist
   }
   hipLaunchKernelGGL(k_gate_bilateral<4>, grid, dim3(256), 0, stream, mm, raw_in, raw_out, trunced, filtered, c->cols, c->rows, tmin, tmax,
                      ss_inv, sd_inv, sigma_depth, acc);
@@ -345,7 +357,7 @@ extern "C" int kf_preprocess(kf_ctx* c, float tmin, float tmax, float sigma_pixe
     st = launch_fused_preprocess(c, c->stream, c->pending_mm, c->raw_depth, c->raw_depth, c->trunced_depth, c->filtered_depth, c->new_v[0], c->new_n[0],
                                  tmin, tmax, sigma_pixel, sigma_depth, cam, build_tiles);
     c->trunc_serial++;
-    if (build_tiles) { c->tile_serial = c->trunc_serial; c->tile_built_dist = c->fuse_max_dist; c->tiles_clear = 0; }
+    if (build_tiles) { c->tile_serial = c->trunc_serial; c->tile_built_dist = c->fuse_max_dist; c->tiles_clear = 0; if (kf_sat_regime(c)) c->tile_min_serial = c->trunc_serial; }
     c->pending_mm = nullptr;
     if (st == 0) st = kf_pending_depth_consumed(c);
   } else {

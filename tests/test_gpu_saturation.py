@@ -24,19 +24,19 @@ def bits(a):
 class Pair:
     """the same frames through the library and the oracle"""
 
-    def __init__(self, res, size, color=False):
-        self.res, self.size, self.color = res, size, color
-        self.ocam = O.Cam.make(*CAM)
+    def __init__(self, res, size, color=False, cam=CAM):
+        self.res, self.size, self.color, self.cam = res, size, color, cam
+        self.ocam = O.Cam.make(*cam)
         self.ovol = O.OVolume(res, size, MAXW)
-        self.ctx = K.Context(K.camera(*CAM), res, size, MAXW, levels=3, has_color=color)
+        self.ctx = K.Context(K.camera(*cam), res, size, MAXW, levels=3, has_color=color)
         self.rng = np.random.default_rng(3)
 
-    def fuse(self, k, trunc=0.1, max_dist=2.5, color=False):
+    def fuse(self, k, trunc=0.1, max_dist=4.0, color=False):
         pose = S.trajectory_pose(k, self.size).astype(np.float32)
-        mm = S.render_depth_mm(pose, CAM, self.size)
+        mm = S.render_depth_mm(pose, self.cam, self.size)
         tr = O.trunc_depth(O.depth_mm_to_m(mm), P["depth_trunc_min"], P["depth_trunc_max"])
         n = O.vertices_to_normals(O.depth_to_vertices(O.bilateral(tr, P["filter_sigma_pixel"], P["filter_sigma_depth"]), self.ocam))
-        rgb = self.rng.integers(0, 256, (CAM[1], CAM[0], 3)).astype(np.uint8) if color else None
+        rgb = self.rng.integers(0, 256, (self.cam[1], self.cam[0], 3)).astype(np.uint8) if color else None
         n_o = O.integrate(self.ovol, tr, n, rgb, color, color, pose, trunc, max_dist, self.ocam, self.ocam)
         self.ctx.upload_depth_mm(mm)
         self.ctx.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
@@ -44,7 +44,9 @@ class Pair:
             self.ctx.upload_rgb(rgb)
             self.ctx.upload_map(K.MAP_NEW_NORMALS, 0, n)
         self.ctx.integrate(pose, trunc, max_dist, has_color=color, angle_weight=color)
-        assert self.ctx.stats()["updated_last"] == n_o, (k, n_o)
+        st = self.ctx.stats()
+        assert st["updated_last"] == n_o, (k, n_o)
+        self.queued = st["bricks_active"]
 
     def same_volume(self):
         t, w = self.ctx.download_volume()
@@ -54,12 +56,17 @@ class Pair:
         self.ctx.close()
 
 
-@pytest.mark.parametrize("res", [64, 96])
+@pytest.mark.parametrize("res", [64, 256])
 def test_saturated_free_space_is_skipped_without_changing_a_bit(res):
-    p = Pair(res, 3.0)
+    p = Pair(res, 3.0, cam=(320, 240, 159.5, 119.5, 262.5, 262.5) if res >= 256 else CAM)     # 256^3: bricks ~16 px wide, as at 1024^3 / VGA
+    queued = []
     for k in range(10):                                # frames 3.. run the saturation-aware kernel; frames 4.. find saturated quarters
         p.fuse(k)
+        queued.append(p.queued)
     assert p.same_volume()
+    print("bricks queued per frame:", queued)
+    if res >= 256:                                      # bricks small enough on screen (a few 8- or 16-pixel tiles) to be free space throughout
+        assert queued[9] < 0.95 * queued[2]             # whole saturated bricks are retired by the cull (counted, not queued)
     sat = int(((p.ovol.weight == MAXW) & (p.ovol.tsdf == 1.0)).sum())
     assert sat > 0.02 * res ** 3                        # the regime is really there: free space at (1, max_weight)
     for k in (40, 41, 75, 76, 77, 20):                  # other views: surface bands and frustum edges cut into the saturated space
