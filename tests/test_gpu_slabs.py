@@ -13,15 +13,16 @@ pytestmark = pytest.mark.gpu
 P = S.STOCK
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_slabs_equal_whole_volume(world):
+@pytest.mark.parametrize("world,maxw,frames", [(2, P["volume_max_weight"], 3), (4, P["volume_max_weight"], 3),
+                                               (2, 3.0, 9)])       # max_weight 3: from frame 3 on the saturation-aware fusion runs in every context
+def test_slabs_equal_whole_volume(world, maxw, frames):
     cam = S.vga_camera()
     kcam = K.camera(*cam)
     size, res = 3.0, 128
     trunc = 5 * size / res
     inc = 0.7 * trunc
-    whole = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=600000)
-    slabs = [K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=600000, slab=r, halo=PL.slab_halo_layers(res, size, inc))
+    whole = K.Context(kcam, res, size, maxw, levels=3, max_triangles=600000)
+    slabs = [K.Context(kcam, res, size, maxw, levels=3, max_triangles=600000, slab=r, halo=PL.slab_halo_layers(res, size, inc))
              for r in PL.slab_ranges(res, world)]
     dev = torch.device("cuda", 0)
     bufs = [(torch.empty((cam[1], cam[0]), dtype=torch.float32, device=dev), torch.empty((cam[1], cam[0], 4), dtype=torch.float32, device=dev),
@@ -29,7 +30,7 @@ def test_slabs_equal_whole_volume(world):
     pose = S.pose0(size)
     for c in [whole] + slabs:
         c.set_pose(pose)
-    for k in range(3):
+    for k in range(frames):
         mm = S.render_depth_mm(S.trajectory_pose(k, size), cam, size)
         for c in [whole] + slabs:
             c.upload_depth_mm(mm)
