@@ -79,7 +79,8 @@ typedef struct kf_track_result {
 typedef struct kf_volume_stats {
   uint64_t updated_last;    /* N_upd: voxels that passed the update predicate in the last integrate */
   uint64_t weight_gt0;      /* voxels with weight > 0 (owned slab only) */
-  uint64_t bricks_active;   /* 8^3 bricks visited by the last integrate */
+  uint64_t bricks_active;   /* 8^3 bricks queued for the last integrate's fusion pass (after max_weight fused frames, bricks of saturated free
+                             * space that is seen as free space again are counted into updated_last without being queued) */
   uint64_t bricks_total;
   uint64_t updated_total;   /* running sum of updated_last since kf_reset_volume */
   uint64_t frames_fused;    /* integrate calls that ran */
