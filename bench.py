@@ -420,6 +420,11 @@ def main():
                         launches_timed=int(launches), rank=roof_rank, algorithmic_bytes_per_launch=int(alg_bytes),
                         n_upd_per_frame=int(n_upd / max(args.steps, 1)),
                         stage=stage_block(alg_bytes, stage_ms, "HIP events over the timed region"))
+        if args.warmup + args.steps > P["volume_max_weight"]:
+            # frames beyond max_weight run the saturation-aware kernels: `achieved` stays the REFERENCE's bytes over the kernel time
+            roofline["note"] = ("timed frames reach past max_weight = %d fused frames: saturated free space is counted but no longer read or "
+                                "written, so the reference's bytes per launch exceed what the kernel moves (DESIGN.md section 4, steady state)" % int(P["volume_max_weight"]))
+            roofline["traffic"], roofline["traffic_source"] = None, None
     else:
         roofline = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None, kernel="k_integrate_pairs",
                         launches_timed=int(launches), refused="fewer than 10 timed launches of the kernel: run with --steps >= 10")
