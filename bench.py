@@ -272,7 +272,7 @@ STAGE_NAMES = ["upload", "preprocess", "track", "integrate", "raycast", "integra
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=100)      # warmup + steps stay below max_weight = 128 fused frames: one regime
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs of the N=1 line (per-stage pass, raycast / marching-cubes rooflines, PCIe-inclusive rate)")
