@@ -46,6 +46,9 @@ struct TrackArgs {
   float* fold_out;
   // SDF tracker only
   KfVolume vol; const float* depth;
+#ifdef KF_EXPERIMENTS
+  unsigned long long* dbg;                       // KF_ICP_EXP=11: where workgroup 0 accumulates the solve's sub-phase times (10 ns ticks)
+#endif
 };
 
 // ---- 6x6 dense algebra on one lane (stands in for Eigen); every index is static after unrolling -> registers only ----
@@ -237,10 +240,17 @@ __device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_to
     // [20..25] the increment x, [26..28] cosines and [29..31] sines of its three angles.
     float* scratch = const_cast<float*>(s_tot) + 32;
     const unsigned det_lane = blockDim.x > 64u ? 64u : 1u;
+#ifdef KF_EXPERIMENTS
+#define KF_SOLVE_STAMP(i) do { if (a.dbg) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(a.dbg + (i), t_ - t_prev_); t_prev_ = t_; } } while (0)
+    unsigned long long t_prev_ = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#else
+#define KF_SOLVE_STAMP(i) do { } while (0)
+#endif
     if (threadIdx.x == det_lane) {
       float A[36], b[6];
       unpack27(s_tot, A, b);
       scratch[17] = ((double)det6(A) < 1E-10) ? 1.f : 0.f;
+      KF_SOLVE_STAMP(6);                                                     // determinant lane: entry -> done
     }
     // wave 0 runs the solve, the trigonometry and the increment as ONE chain: its lanes hand values to each other through LDS
     // in program order (a wave's LDS operations complete in order), so no workgroup barrier is needed until the determinant
@@ -253,6 +263,7 @@ __device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_to
         llt_solve6(A, b, x);
 #pragma unroll
         for (int i = 0; i < 6; ++i) vs[20 + i] = x[i];
+        KF_SOLVE_STAMP(0);                                                   // unpack + Cholesky solve
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (threadIdx.x < 3) {                                               // the three Euler angles: one lane each, one pass of the trig code
@@ -261,6 +272,7 @@ __device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_to
         vs[26 + threadIdx.x] = cs; vs[29 + threadIdx.x] = sn;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (threadIdx.x == 0) KF_SOLVE_STAMP(1);                               // hand-off + sin/cos + hand-off
       if (threadIdx.x == 0) {
         float x[6], T[16], ncur[16];
 #pragma unroll
@@ -271,17 +283,20 @@ __device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_to
           mat44_mul(T, s_cur, ncur);                                       // ICP.cpp:81 cur = T * cur
           for (int i = 0; i < 16; ++i) vs[i] = ncur[i];
         }
+        KF_SOLVE_STAMP(2);                                                   // rotation, shake test, T * cur
       }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      int code = STEP_APPLIED;
+    if (threadIdx.x == 0) KF_SOLVE_STAMP(3);                                 // workgroup barrier (waits for the determinant lane)
+    {
+      int code = STEP_APPLIED;                                             // every lane reads the two verdicts (LDS broadcast); sixteen lanes copy
       if (scratch[17] != 0.f) code = STEP_LOST_DET;
       else if (scratch[16] != 0.f) code = STEP_LOST_SHAKE;
-      else for (int i = 0; i < 16; ++i) s_cur[i] = scratch[i];
-      *s_code = code;
+      if (code == STEP_APPLIED && threadIdx.x < 16) s_cur[threadIdx.x] = scratch[threadIdx.x];
+      if (threadIdx.x == 0) *s_code = code;
     }
     __syncthreads();
+    if (threadIdx.x == 0) KF_SOLVE_STAMP(4);                                 // verdict + copy + barrier
     return;
   }
   if (threadIdx.x == 0) {
@@ -505,6 +520,9 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   __syncthreads();
   TrackArgs a;
   a.dist_thres = L.dist_thres; a.sin_thres = L.sin_thres; a.dist_shake = L.dist_shake; a.angle_shake = L.angle_shake; a.sdf = 0;
+#ifdef KF_EXPERIMENTS
+  a.dbg = (KF_EXP_MODE(L) == 11 && blockIdx.x == 0) ? L.slots + (size_t)26 * KF_ICP_LOOP_MAX_WG * 32 : nullptr;
+#endif
   int step = 0, n_prev = 0, applied = 0;
   // diagnostic build path (KF_ICP_EXP=7): workgroup 0 accumulates shader-clock ticks per segment into track->reduced
   const bool stamp = KF_EXP_MODE(L) == 7 && blockIdx.x == 0 && threadIdx.x == 0;

@@ -54,3 +54,14 @@ if os.environ.get("KF_ICP_EXP") == "9":
         t0 = b[s_, 16:24].min()
         print("step %2d: fold done %s | solve+pixels done at %s | published at %s (us after the first wave left the fold)" % (
             s_, np.round((b[s_, 16:24] - t0) / 100.0, 2), np.round((b[s_, 0:8] - t0) / 100.0, 2), np.round((b[s_, 8:16] - t0) / 100.0, 2)))
+if os.environ.get("KF_ICP_EXP") == "11":
+    # workgroup 0, per Gauss-Newton step (s_memrealtime, 10 ns ticks, summed over all steps of all frames since the context was created)
+    import ctypes as C
+    buf = np.zeros(8, np.uint64)
+    ctx.lib.kf_exp_read_icp_slots(ctx.h, buf.ctypes.data_as(C.c_void_p), C.c_size_t(26 * 512 * 32), C.c_size_t(buf.size))
+    n_steps = 18 * (50 + 1)          # 18 applied solves per tracked frame (the 19th is applied after the loop), 50 timed frames + 1 before
+    names = ["unpack + Cholesky solve (lane 0)", "hand-off, sin/cos on three lanes, hand-off", "rotation, shake test, T * cur (lane 0)",
+             "workgroup barrier", "verdict + copy + barrier", "-", "determinant (lane 64, from the step's entry)"]
+    for i, nme in enumerate(names):
+        if nme != "-":
+            print("  %-48s %6.2f us per step" % (nme, buf[i] / 100.0 / n_steps))
