@@ -91,8 +91,49 @@ __device__ __forceinline__ float det6(float m[36]) {
   }
   return det;
 }
-// x = LLT(A) \ b, fp32 (ICP.cpp:143, SDF.cpp:79)
+// x = LLT(A) \ b, fp32 (ICP.cpp:143, SDF.cpp:79: Eigen's llt().solve in float).  The solve is one chain of dependent operations on
+// one lane (about 1 us of the 1.7 us a Gauss-Newton step spends between two pixel phases), so its square roots, reciprocals and
+// quotients are the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32 and a product with the reciprocal, not the correctly rounded forms:
+// -7.5 us per frame.  What that costs in fidelity is below what is there anyway -- the 27 sums the solve starts from differ from
+// the reference's in their last bits (fp32 sums in another association order, asserted <= 1e-5), the tracked pose is asserted to
+// 1e-4 against the oracle's exactly rounded Eigen restatement on identical inputs and stays there, and every
+// workgroup, rank and context runs the same instructions, so poses stay bitwise reproducible.  -DKF_SOLVE_EXACT restores the
+// correctly rounded chain.
 __device__ __forceinline__ void llt_solve6(const float A[36], const float b[6], float x[6]) {
+#ifndef KF_SOLVE_EXACT
+  float L[36], rd[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float s = A[j * 6 + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= L[j * 6 + k] * L[j * 6 + k];
+    const float d = __builtin_amdgcn_sqrtf(s);
+    L[j * 6 + j] = d;
+    rd[j] = __builtin_amdgcn_rcpf(d);
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      float t = A[i * 6 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i * 6 + k] * L[j * 6 + k];
+      L[i * 6 + j] = t * rd[j];
+    }
+  }
+  float y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float t = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) t -= L[i * 6 + k] * y[k];
+    y[i] = t * rd[i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    float t = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) t -= L[k * 6 + i] * x[k];
+    x[i] = t * rd[i];
+  }
+#else
   float L[36]; KfRecip rd[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -125,6 +166,7 @@ __device__ __forceinline__ void llt_solve6(const float A[36], const float b[6], 
     for (int k = i + 1; k < 6; ++k) t -= L[k * 6 + i] * x[k];
     x[i] = kf_div(t, rd[i]);
   }
+#endif
 }
 __device__ __forceinline__ void mat3_mul(const float a[9], const float b[9], float o[9]) {
 #pragma unroll
