@@ -96,7 +96,7 @@ __device__ __forceinline__ float det6(float m[36]) {
 // quotients are the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32 and a product with the reciprocal, not the correctly rounded forms:
 // -7.5 us per frame.  What that costs in fidelity is below what is there anyway -- the 27 sums the solve starts from differ from
 // the reference's in their last bits (fp32 sums in another association order, asserted <= 1e-5), the tracked pose is asserted to
-// 1e-4 against the oracle's exactly rounded Eigen restatement on identical inputs and stays there, and every
+// 1e-4 against an exactly rounded CPU restatement of Eigen's chain on identical inputs and stays there, and every
 // workgroup, rank and context runs the same instructions, so poses stay bitwise reproducible.  -DKF_SOLVE_EXACT restores the
 // correctly rounded chain.
 __device__ __forceinline__ void llt_solve6(const float A[36], const float b[6], float x[6]) {
