@@ -33,6 +33,7 @@ struct TrackArgs {
   KfMat cur_val, linv_val;                       // host-supplied transforms (per-call wrappers only)
   int use_state;                                 // 1: transforms come from the device-resident KfTrackState
   float dist_thres, sin_thres, dist_shake, angle_shake;
+  float cos_shake, dist_shake2;                  // cos(angle_shake), dist_shake^2: the shake test without acos / sqrt (set next to the two above)
   float* partials;                               // 2 x KF_ICP_MAX_WG x 32 floats, indexed by step parity
   KfTrackState* track;
   int step;                                      // index of this Gauss-Newton step within the frame (buffer parity)
@@ -81,10 +82,18 @@ __device__ __forceinline__ float det6(float m[36]) {
       }
     const float piv = m[k * 6 + k];
     det *= piv;
+#ifndef KF_SOLVE_EXACT
+    const float rp = __builtin_amdgcn_rcpf(piv);             // 1-ulp reciprocal, as in llt_solve6 below: the result only meets a threshold
+#else
     const KfRecip rp = kf_recip(piv);                        // one reciprocal refinement per pivot, exact quotients (kf_div)
+#endif
 #pragma unroll
     for (int r = k + 1; r < 6; ++r) {
+#ifndef KF_SOLVE_EXACT
+      const float f = m[r * 6 + k] * rp;
+#else
       const float f = kf_div(m[r * 6 + k], rp);
+#endif
 #pragma unroll
       for (int c = k + 1; c < 6; ++c) m[r * 6 + c] -= f * m[k * 6 + c];
     }
@@ -186,25 +195,40 @@ __device__ __forceinline__ void mat44_mul(const float* a, const float* b, float*
 }
 // vector6ToTransformMatrix (ICP.cpp:95-111, SDF.cpp:25-43): R = Rx Ry Rz, shake test on the rotation angle and |t|
 __device__ __forceinline__ bool transform_from_sincos(const float x[6], float c0, float s0, float c1, float s1, float c2, float s2,
-                                                      float dist_shake, float angle_shake, float t[16]) {
-  const float Rx[9] = {1, 0, 0, 0, c0, -s0, 0, s0, c0};
-  const float Ry[9] = {c1, 0, s1, 0, 1, 0, -s1, 0, c1};
-  const float Rz[9] = {c2, -s2, 0, s2, c2, 0, 0, 0, 1};
-  float Rxy[9], R[9];
-  mat3_mul(Rx, Ry, Rxy); mat3_mul(Rxy, Rz, R);
+                                                      float dist_shake2, float cos_shake, float t[16]) {
+  // R = Rx Ry Rz with Rx = {1,0,0, 0,c0,-s0, 0,s0,c0}, Ry = {c1,0,s1, 0,1,0, -s1,0,c1}, Rz = {c2,-s2,0, s2,c2,0, 0,0,1} (ICP.cpp:98-100).
+  // The general 3x3 products spend most of their 90 operations on the literal zeros and ones; written out, every element is the same
+  // sum of the same products in the same order with the x * 0, x * 1 and + 0 terms dropped -- equal values for every finite input
+  // (only the sign of an exact zero can differ, and a NaN angle still poisons R0 / R4 / R8, i.e. the shake verdict).
+  const float xy3 = s0 * s1, xy5 = -s0 * c1, xy6 = -c0 * s1, xy8 = c0 * c1;            // Rx Ry = {c1, 0, s1,  xy3, c0, xy5,  xy6, s0, xy8}
+  const float R[9] = {c1 * c2, c1 * -s2, s1,
+                      xy3 * c2 + c0 * s2, xy3 * -s2 + c0 * c2, xy5,
+                      xy6 * c2 + s0 * s2, xy6 * -s2 + s0 * c2, xy8};
+  // the reference compares AngleAxisf(R).angle() = acos(ca) with angle_shake and |t| with dist_shake (ICP.cpp:101-107); acos is
+  // decreasing and the square root increasing, so the same verdicts come from ca >= cos(angle_shake) and |t|^2 <= dist_shake^2
+  // (thresholds prepared once per call) -- without an acos and a square root on the one-lane chain of every Gauss-Newton step
   float ca = (R[0] + R[4] + R[8] - 1.f) * 0.5f;
   ca = fminf(1.f, fmaxf(-1.f, ca));
-  const float angle = acosf(ca);                             // == AngleAxisf(R).angle()
-  const float d = sqrtf(x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
-  if (!(angle <= angle_shake) || !(d <= dist_shake)) return false;   // a NaN increment counts as shaking: never applied
+  const float d2 = x[3] * x[3] + x[4] * x[4] + x[5] * x[5];
+  if (!(ca >= cos_shake) || !(d2 <= dist_shake2)) return false;        // a NaN increment counts as shaking: never applied
   const float o[16] = {R[0], R[1], R[2], x[3], R[3], R[4], R[5], x[4], R[6], R[7], R[8], x[5], 0, 0, 0, 1};
 #pragma unroll
   for (int i = 0; i < 16; ++i) t[i] = o[i];
   return true;
 }
-__device__ __forceinline__ bool vector6_to_transform(const float x[6], float dist_shake, float angle_shake, float t[16]) {
-  const float c0 = cosf(x[0]), s0 = sinf(x[0]), c1 = cosf(x[1]), s1 = sinf(x[1]), c2 = cosf(x[2]), s2 = sinf(x[2]);
-  return transform_from_sincos(x, c0, s0, c1, s1, c2, s2, dist_shake, angle_shake, t);
+// sine and cosine of an Euler-angle increment: the angles that survive the shake test are below angle_shake (0.3 rad stock), where
+// the Taylor polynomials through x^9 / x^8 are exact to the last bit or two of fp32; larger arguments take the library routine
+__device__ __forceinline__ void kf_sincos_small(float x, float* sn, float* cs) {
+  if (fabsf(x) < 0.5f) {
+    const float x2 = x * x;
+    *sn = x * (1.f + x2 * (-1.f / 6.f + x2 * (1.f / 120.f + x2 * (-1.f / 5040.f + x2 * (1.f / 362880.f)))));
+    *cs = 1.f + x2 * (-0.5f + x2 * (1.f / 24.f + x2 * (-1.f / 720.f + x2 * (1.f / 40320.f))));
+  } else sincosf(x, sn, cs);
+}
+__device__ __forceinline__ bool vector6_to_transform(const float x[6], float dist_shake2, float cos_shake, float t[16]) {
+  float c0, s0, c1, s1, c2, s2;
+  kf_sincos_small(x[0], &s0, &c0); kf_sincos_small(x[1], &s1, &c1); kf_sincos_small(x[2], &s2, &c2);
+  return transform_from_sincos(x, c0, s0, c1, s1, c2, s2, dist_shake2, cos_shake, t);
 }
 
 // ---- fold the previous step's partial sums: identical order in every workgroup ------------------------------------------
@@ -310,7 +334,7 @@ __device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_to
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (threadIdx.x < 3) {                                               // the three Euler angles: one lane each, one pass of the trig code
         const float ang = vs[20 + threadIdx.x];
-        float sn, cs; sincosf(ang, &sn, &cs);                              // one argument reduction for the pair
+        float sn, cs; kf_sincos_small(ang, &sn, &cs);
         vs[26 + threadIdx.x] = cs; vs[29 + threadIdx.x] = sn;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -319,10 +343,16 @@ __device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_to
         float x[6], T[16], ncur[16];
 #pragma unroll
         for (int i = 0; i < 6; ++i) x[i] = vs[20 + i];
-        const bool still = transform_from_sincos(x, vs[26], vs[29], vs[27], vs[30], vs[28], vs[31], a.dist_shake, a.angle_shake, T);
+        const bool still = transform_from_sincos(x, vs[26], vs[29], vs[27], vs[30], vs[28], vs[31], a.dist_shake2, a.cos_shake, T);
         vs[16] = still ? 0.f : 1.f;
         if (still) {
-          mat44_mul(T, s_cur, ncur);                                       // ICP.cpp:81 cur = T * cur
+          // ICP.cpp:81 cur = T * cur; T's last row is (0, 0, 0, 1): that row of the product is cur's own last row, bit for bit
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ncur[i * 4 + j] = T[i * 4] * s_cur[j] + T[i * 4 + 1] * s_cur[4 + j] + T[i * 4 + 2] * s_cur[8 + j] + T[i * 4 + 3] * s_cur[12 + j];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ncur[12 + j] = s_cur[12 + j];
           for (int i = 0; i < 16; ++i) vs[i] = ncur[i];
         }
         KF_SOLVE_STAMP(2);                                                   // rotation, shake test, T * cur
@@ -346,7 +376,7 @@ __device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_to
     unpack27(s_tot, A, b);
     int code = STEP_APPLIED;
     llt_solve6(A, b, x);
-    if (!vector6_to_transform(x, a.dist_shake, a.angle_shake, T)) code = STEP_LOST_SHAKE;
+    if (!vector6_to_transform(x, a.dist_shake2, a.cos_shake, T)) code = STEP_LOST_SHAKE;
     else {
       const float nx = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
       if (nx < 0.001f) code = STEP_CONVERGED;                              // SDF.cpp:87-90: stop before applying x
@@ -492,7 +522,7 @@ struct IcpLoopArgs {
   const float4* model_v[KF_MAX_LEVELS]; const float4* model_n[KF_MAX_LEVELS];
   KfCam cam[KF_MAX_LEVELS];
   int iters[KF_MAX_LEVELS]; int levels;
-  float dist_thres, sin_thres, dist_shake, angle_shake;
+  float dist_thres, sin_thres, dist_shake, angle_shake, cos_shake, dist_shake2;
   unsigned long long* slots;                     // KF_ICP_LOOP_STEPS x KF_ICP_LOOP_MAX_WG x 32 tagged partial sums, one array per step
   unsigned tag_base;                             // this launch's sequence number (host counter x 64); tag = tag_base + step
   KfTrackState* track;
@@ -561,7 +591,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   if (threadIdx.x == 0) kf_mat44_inverse(s_cur, s_linv);                        // ICP.cpp:63 last_transform_inv
   __syncthreads();
   TrackArgs a;
-  a.dist_thres = L.dist_thres; a.sin_thres = L.sin_thres; a.dist_shake = L.dist_shake; a.angle_shake = L.angle_shake; a.sdf = 0;
+  a.dist_thres = L.dist_thres; a.sin_thres = L.sin_thres; a.dist_shake = L.dist_shake; a.angle_shake = L.angle_shake; a.cos_shake = L.cos_shake; a.dist_shake2 = L.dist_shake2; a.sdf = 0;
 #ifdef KF_EXPERIMENTS
   a.dbg = (KF_EXP_MODE(L) == 11 && blockIdx.x == 0) ? L.slots + (size_t)26 * KF_ICP_LOOP_MAX_WG * 32 : nullptr;
 #endif
@@ -788,6 +818,8 @@ __global__ void __launch_bounds__(ICP_THREADS) k_track_finish(TrackArgs a) {
   if (threadIdx.x == 0) st->tracked = 1;
 }
 
+// acos(ca) <= angle  <=>  ca >= cos(angle) for angle in [0, pi]; beyond pi every rotation passes, below 0 none does (NaN stays NaN: none)
+static inline float shake_cos(float angle) { return angle >= 3.14159274f ? -2.f : (angle < 0.f ? 2.f : cosf(angle)); }
 static inline KfCam to_cam(const kf_camera_params* p) {
   KfCam c; c.cols = (int)p->cols; c.rows = (int)p->rows; c.cx = p->cx; c.cy = p->cy; c.fx = p->fx; c.fy = p->fy; return c;
 }
@@ -883,7 +915,7 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
       L.cam[l] = to_cam(&cams[l]); L.iters[l] = iters[l];
     }
     L.levels = c->levels;
-    L.dist_thres = icp->dist_thres; L.sin_thres = icp->norm_sin_thres; L.dist_shake = icp->dist_shake; L.angle_shake = icp->angle_shake;
+    L.dist_thres = icp->dist_thres; L.sin_thres = icp->norm_sin_thres; L.dist_shake = icp->dist_shake; L.angle_shake = icp->angle_shake; L.cos_shake = shake_cos(icp->angle_shake); L.dist_shake2 = icp->dist_shake * icp->dist_shake;
     c->icp_loop_seq += 64u;                                  // tags of one launch never collide with an earlier launch's slots
     L.slots = c->icp_loop_slots; L.tag_base = c->icp_loop_seq; L.track = c->track;
     L.stall_word = (unsigned*)((char*)c->host_pinned + KF_PINNED_STALL_WORD);
@@ -894,7 +926,7 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   }
   TrackArgs a; memset(&a, 0, sizeof(a));
   a.use_state = 1;
-  a.dist_thres = icp->dist_thres; a.sin_thres = icp->norm_sin_thres; a.dist_shake = icp->dist_shake; a.angle_shake = icp->angle_shake;
+  a.dist_thres = icp->dist_thres; a.sin_thres = icp->norm_sin_thres; a.dist_shake = icp->dist_shake; a.angle_shake = icp->angle_shake; a.cos_shake = shake_cos(icp->angle_shake); a.dist_shake2 = icp->dist_shake * icp->dist_shake;
   a.partials = c->icp_partials; a.track = c->track;
   int step = 0, prev_grid = 0;
   for (int l = c->levels - 1; l >= 0; --l)                   // coarse -> fine, ICP.cpp:65
@@ -941,7 +973,7 @@ extern "C" int kf_icp_partition_step(kf_ctx* c, uint32_t step, const kf_icp_para
   a.use_state = 1;
   a.new_v = c->new_v[l]; a.new_n = c->new_n[l]; a.model_v = c->model_v[l]; a.model_n = c->model_n[l];
   a.cam = to_cam(&cam);
-  a.dist_thres = icp->dist_thres; a.sin_thres = icp->norm_sin_thres; a.dist_shake = icp->dist_shake; a.angle_shake = icp->angle_shake;
+  a.dist_thres = icp->dist_thres; a.sin_thres = icp->norm_sin_thres; a.dist_shake = icp->dist_shake; a.angle_shake = icp->angle_shake; a.cos_shake = shake_cos(icp->angle_shake); a.dist_shake2 = icp->dist_shake * icp->dist_shake;
   a.partials = c->icp_partials; a.track = c->track;
   a.step = (int)step; a.consume = step > 0; a.ext_prev = step > 0 ? dev_sums : nullptr;
   const int rows_per = kf_div_up(a.cam.rows, (int)parts);                    // whole image rows per rank
@@ -960,7 +992,7 @@ extern "C" int kf_icp_partition_finish(kf_ctx* c, const kf_icp_params* icp, cons
   int iters[KF_MAX_LEVELS];
   TrackArgs a; memset(&a, 0, sizeof(a));
   a.use_state = 1; a.consume = 1; a.step = icp_iters(c->levels, iters); a.ext_prev = dev_sums;
-  a.dist_shake = icp->dist_shake; a.angle_shake = icp->angle_shake; a.partials = c->icp_partials; a.track = c->track;
+  a.dist_shake = icp->dist_shake; a.angle_shake = icp->angle_shake; a.cos_shake = shake_cos(icp->angle_shake); a.dist_shake2 = icp->dist_shake * icp->dist_shake; a.partials = c->icp_partials; a.track = c->track;
   hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, a);
   return (int)hipGetLastError();
 }
@@ -985,7 +1017,7 @@ extern "C" int kf_sdf_track(kf_ctx* c, uint32_t frame_id, const kf_sdf_tracker_p
   TrackArgs a; memset(&a, 0, sizeof(a));
   a.use_state = 1; a.sdf = 1;
   a.cam = to_cam(cam); a.vol = c->vol; a.depth = c->trunced_depth;
-  a.dist_shake = sp->dist_shake; a.angle_shake = sp->angle_shake;
+  a.dist_shake = sp->dist_shake; a.angle_shake = sp->angle_shake; a.cos_shake = shake_cos(sp->angle_shake); a.dist_shake2 = sp->dist_shake * sp->dist_shake;
   a.partials = c->icp_partials; a.track = c->track;
   const int grid = track_grid(c->cols * c->rows);
   int step = 0;
