@@ -11,6 +11,15 @@ static inline KfCam to_cam(const kf_camera_params* p) {
   KfCam c; c.cols = (int)p->cols; c.rows = (int)p->rows; c.cx = p->cx; c.cy = p->cy; c.fx = p->fx; c.fy = p->fy; return c;
 }
 
+// Bilateral tap weight exp(-(space2 * ss_inv + diff^2 * sd_inv)) (DataPreprocesser.cu:70-73, __expf there) as ONE hardware exp2: the two
+// factors carry log2(e) already, the sum is a fused multiply-add.  The filter is tolerance-checked (2e-6 relative: the reference's fast
+// intrinsic is not reproducible on any other target anyway); the per-call kernel and the fused one share this function and their tap
+// order, so they still agree bit for bit.
+#define KF_LOG2E 1.44269504f
+__device__ __forceinline__ float kf_bilateral_weight(float diff, float space2, float c_ss, float c_sd) {
+  return __builtin_amdgcn_exp2f(__builtin_fmaf(diff * diff, c_sd, -(space2 * c_ss)));
+}
+
 // DataPreprocesser.cu:17-36: keep d iff trunc_min < d < trunc_max (strict both sides)
 __global__ void __launch_bounds__(256) k_trunc_depth(const float* __restrict__ in, float* __restrict__ out, int n, float tmin, float tmax) {
   int i = blockIdx.x * 256 + threadIdx.x;
@@ -43,16 +52,15 @@ __global__ void __launch_bounds__(256) k_bilateral(const float* __restrict__ in,
     float sum1 = 0.f, sum2 = 0.f;
     bool aborted = false;
     const float thr = 5 * sigma_depth;
+    const float c_ss = ss_inv * KF_LOG2E, c_sd = -(sd_inv * KF_LOG2E);               // the weight as one exp2: see kf_bilateral_weight
     for (int dy = -radius; dy <= radius && !aborted; ++dy) {
       const float* rowp = &tile[(ly + radius + dy) * tw + lx + radius];
       for (int dx = -radius; dx <= radius; ++dx) {
         float tmp = rowp[dx];
         if (tmp == 0.f) continue;
         if (fabsf(tmp - value) > thr) { aborted = true; break; }                      // :66-69 keeps the unfiltered value
-        float space2 = (float)(dx * dx + dy * dy);
-        float data2 = (value - tmp) * (value - tmp);
-        float w = __expf(-(space2 * ss_inv + data2 * sd_inv));
-        sum1 += tmp * w; sum2 += w;
+        const float w = kf_bilateral_weight(value - tmp, (float)(dx * dx + dy * dy), c_ss, c_sd);
+        sum1 = __builtin_fmaf(tmp, w, sum1); sum2 += w;
       }
     }
     if (!aborted && sum2 > 0.f) result = sum1 / sum2;
@@ -122,6 +130,7 @@ __global__ void __launch_bounds__(256) k_gate_bilateral(const uint16_t* __restri
     float sum1 = 0.f, sum2 = 0.f;
     float max_diff = 0.f;                                  // largest |tap - centre| over the valid taps: the 5-sigma test, once
     const float thr = 5 * sigma_depth;
+    const float c_ss = ss_inv * KF_LOG2E, c_sd = -(sd_inv * KF_LOG2E);
 #pragma unroll
     for (int dy = -R; dy <= R; ++dy) {
       float row[2 * R + 1];
@@ -133,10 +142,9 @@ __global__ void __launch_bounds__(256) k_gate_bilateral(const uint16_t* __restri
         const bool valid = tmp != 0.f;
         const float diff = value - tmp;
         max_diff = fmaxf(max_diff, valid ? fabsf(diff) : 0.f);
-        const float space2 = (float)(dx * dx + dy * dy);
-        const float arg = -(space2 * ss_inv + diff * diff * sd_inv);
-        const float w = __expf(valid ? arg : -INFINITY);    // exp(-inf) = +0: selecting the argument keeps the tap loop straight-line
-        sum1 += tmp * w; sum2 += w;
+        const float wv = kf_bilateral_weight(diff, (float)(dx * dx + dy * dy), c_ss, c_sd);
+        const float w = valid ? wv : 0.f;                   // an invalid tap adds +0 to both sums: the loop stays straight-line
+        sum1 = __builtin_fmaf(tmp, w, sum1); sum2 += w;
       }
     }
     if (!(max_diff > thr) && sum2 > 0.f) result = sum1 / sum2;
