@@ -606,7 +606,13 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     const float4* __restrict__ new_v = L.new_v[l]; const float4* __restrict__ new_n = L.new_n[l];
     const float4* __restrict__ model_v = L.model_v[l]; const float4* __restrict__ model_n = L.model_n[l];
     const int npx = a.cam.cols * a.cam.rows;
-    const int grid_l = (npx + ICP_THREADS * ICP_PX - 1) / (ICP_THREADS * ICP_PX);
+    // pixels per lane at this level: as few as the resident workgroups allow (coarse levels: 1 -- a step there is latency, and a third of
+    // the pixel work per lane is a third of that part of it; the sums meet in more slots, which the fold reads in one batch anyway)
+    int px_l = ICP_PX;
+#ifndef KF_ICP_FIXED_PX
+    for (int p = 1; p < ICP_PX; ++p) if ((npx + ICP_THREADS * p - 1) / (ICP_THREADS * p) <= (int)gridDim.x) { px_l = p; break; }
+#endif
+    const int grid_l = (npx + ICP_THREADS * px_l - 1) / (ICP_THREADS * px_l);
     const bool has_px = (int)blockIdx.x < grid_l;
     // pixels are dealt to the workgroups in 64-pixel chunks, round robin: every workgroup sees the same mix of surface and
     // background, so they all reach the exchange of partial sums at about the same time (contiguous blocks did not)
@@ -618,7 +624,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     for (int j = 0; j < ICP_PX; ++j) {
       const int i = (chunk0 + j * chunk_step) * 64 + (int)(threadIdx.x & 63);
       iv[j] = make_float4(0.f, 0.f, 0.f, 0.f); in_[j] = iv[j];
-      if (has_px && i < npx) { iv[j] = new_v[i]; in_[j] = new_n[i]; }
+      if (has_px && j < px_l && i < npx) { iv[j] = new_v[i]; in_[j] = new_n[i]; }
     }
     for (int it = 0; it < L.iters[l]; ++it, ++step) {
       KF_STAMP(0);
