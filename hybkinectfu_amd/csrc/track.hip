@@ -606,11 +606,13 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     const float4* __restrict__ new_v = L.new_v[l]; const float4* __restrict__ new_n = L.new_n[l];
     const float4* __restrict__ model_v = L.model_v[l]; const float4* __restrict__ model_n = L.model_n[l];
     const int npx = a.cam.cols * a.cam.rows;
-    // pixels per lane at this level: as few as the resident workgroups allow (coarse levels: 1 -- a step there is latency, and a third of
-    // the pixel work per lane is a third of that part of it; the sums meet in more slots, which the fold reads in one batch anyway)
+    // Pixels per lane at this level.  Two things pull: fewer pixels per lane shorten the pixel phase (a coarse step is mostly latency),
+    // but every workgroup that holds pixels is one more publisher the step has to wait for (all 256 CUs publishing at every level: +36 us
+    // per frame).  Measured at VGA on 200 workgroups, tracking stage in us for (level 0, 1, 2) pixels per lane: (3,3,3) 180, (3,1,1) 175.5,
+    // (3,2,2) 174.9, (3,1,2) 178, (3,2,1) 172.6.  Rule: the fewest pixels per lane that keep the publishers at or below half the launch.
     int px_l = ICP_PX;
 #ifndef KF_ICP_FIXED_PX
-    for (int p = 1; p < ICP_PX; ++p) if ((npx + ICP_THREADS * p - 1) / (ICP_THREADS * p) <= (int)gridDim.x) { px_l = p; break; }
+    for (int p = 1; p < ICP_PX; ++p) if (2 * ((npx + ICP_THREADS * p - 1) / (ICP_THREADS * p)) <= (int)gridDim.x) { px_l = p; break; }
 #endif
     const int grid_l = (npx + ICP_THREADS * px_l - 1) / (ICP_THREADS * px_l);
     const bool has_px = (int)blockIdx.x < grid_l;
