@@ -44,6 +44,10 @@ if os.environ.get("KF_ICP_EXP") == "8":
         print(line)
     late = np.argsort(b[12, :200, 0])[-8:]
     print("latest publishers of step 12:", late, (b[12, late, 0] - b[12, :200, 0].min()) / 100.0)
+    # does a group of workgroups (id mod 8 = the XCD under round-robin placement) publish systematically later?
+    for s_ in (10, 13, 16):
+        d = (b[s_, :200, 0] - b[s_, :200, 0].min()) / 100.0
+        print("step %d: mean publish delay by workgroup id mod 8:" % s_, np.round([d[r::8].mean() for r in range(8)], 2))
 if os.environ.get("KF_ICP_EXP") == "9":
     # workgroup 5, per wave and step (s_memrealtime, 10 ns ticks): fold done [16..23], pixel phase done [0..7], published [8..15]
     import ctypes as C
