@@ -532,6 +532,9 @@ struct IcpLoopArgs {
 
 #define ICP_SPIN_LIMIT 200000u          // polls (~1-2 us each) before a workgroup gives up: a legitimate wait is tens of microseconds
 #define ICP_FOLD_BATCH 13
+#ifndef KF_ICP_POLL_PIPE
+#define KF_ICP_POLL_PIPE 2        // s_sleep between the two polls kept in flight (0 is not a value: -DKF_ICP_POLL_SINGLE selects the one-poll loop)
+#endif
 // Partial sums of the persistent loop travel as 64-bit (value, tag) words: the tag is the launch's sequence number plus the
 // Gauss-Newton step, every step has its own slot array, and a word is published by ONE 8-byte write-through store -- so a
 // reader needs no barrier and no flag: it polls the words it is about to add until their tags are current.  The adds run
@@ -544,6 +547,37 @@ __device__ __forceinline__ void fold_partials_tagged(const unsigned long long* s
     for (int w0 = part; w0 < n_wg; w0 += ICP_FOLD_BATCH * parts) {
       float v[ICP_FOLD_BATCH];
       unsigned spins = 0;
+#ifndef KF_ICP_POLL_SINGLE
+      // several polls in flight: a poll costs a full memory round trip, and words that become current just after a poll has been issued
+      // are otherwise only seen one round trip + one sleep later; the oldest set is checked while the younger one is on its way
+      // (tracking stage 172.5 -> 157.5 us; three or four sets in flight spill registers: 222 / 369 us)
+#ifndef KF_ICP_POLL_DEPTH
+#define KF_ICP_POLL_DEPTH 2
+#endif
+      unsigned long long u[KF_ICP_POLL_DEPTH][ICP_FOLD_BATCH];
+#pragma unroll
+      for (int d = 0; d < KF_ICP_POLL_DEPTH; ++d) {
+        if (d) __builtin_amdgcn_s_sleep(KF_ICP_POLL_PIPE);
+#pragma unroll
+        for (int j = 0; j < ICP_FOLD_BATCH; ++j) { const int w = w0 + j * parts; u[d][j] = (w < n_wg) ? __hip_atomic_load(&slots[w * 32 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32); }
+      }
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < ICP_FOLD_BATCH; ++j) ok = ok && (unsigned)(u[0][j] >> 32) == tag;
+        if (ok) break;
+        if (++spins > ICP_SPIN_LIMIT) { *s_abort = 1; break; }
+#pragma unroll
+        for (int d = 0; d + 1 < KF_ICP_POLL_DEPTH; ++d)
+#pragma unroll
+          for (int j = 0; j < ICP_FOLD_BATCH; ++j) u[d][j] = u[d + 1][j];
+        __builtin_amdgcn_s_sleep(KF_ICP_POLL_PIPE);
+#pragma unroll
+        for (int j = 0; j < ICP_FOLD_BATCH; ++j) { const int w = w0 + j * parts; u[KF_ICP_POLL_DEPTH - 1][j] = (w < n_wg) ? __hip_atomic_load(&slots[w * 32 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32); }
+      }
+#pragma unroll
+      for (int j = 0; j < ICP_FOLD_BATCH; ++j) v[j] = (w0 + j * parts < n_wg) ? __uint_as_float((unsigned)u[0][j]) : 0.f;
+#else
       for (;;) {
         bool ok = true;
 #pragma unroll
@@ -560,6 +594,7 @@ __device__ __forceinline__ void fold_partials_tagged(const unsigned long long* s
         __builtin_amdgcn_s_sleep(2);
         if (++spins > ICP_SPIN_LIMIT) { *s_abort = 1; break; }                   // never spin forever: report instead
       }
+#endif
 #pragma unroll
       for (int j = 0; j < ICP_FOLD_BATCH; ++j) s += v[j];
     }
