@@ -643,11 +643,21 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     const int npx = a.cam.cols * a.cam.rows;
     // Pixels per lane at this level.  Two things pull: fewer pixels per lane shorten the pixel phase (a coarse step is mostly latency),
     // but every workgroup that holds pixels is one more publisher the step has to wait for (all 256 CUs publishing at every level: +36 us
-    // per frame).  Measured at VGA on 200 workgroups, tracking stage in us for (level 0, 1, 2) pixels per lane: (3,3,3) 180, (3,1,1) 175.5,
-    // (3,2,2) 174.9, (3,1,2) 178, (3,2,1) 172.6.  Rule: the fewest pixels per lane that keep the publishers at or below half the launch.
+    // per frame).  Measured at VGA on 200 workgroups, tracking stage in us for (level 0, 1, 2) pixels per lane, with the fold's two polls
+    // in flight: (3,3,1) 162.4, (3,2,2) 161.9, (3,2,1) 159.4, (3,1,1) 156.3 (with one poll in flight (3,2,1) was ahead: 172.6 vs 175.5).
+    // Rule: the fewest pixels per lane the launch can hold.
     int px_l = ICP_PX;
 #ifndef KF_ICP_FIXED_PX
-    for (int p = 1; p < ICP_PX; ++p) if (2 * ((npx + ICP_THREADS * p - 1) / (ICP_THREADS * p)) <= (int)gridDim.x) { px_l = p; break; }
+    for (int p = 1; p < ICP_PX; ++p) if ((npx + ICP_THREADS * p - 1) / (ICP_THREADS * p) <= (int)gridDim.x) { px_l = p; break; }
+#ifdef KF_ICP_PX_L0                                                              // tuning overrides (tools/build_variant.sh)
+    if (l == 0) px_l = KF_ICP_PX_L0;
+#endif
+#ifdef KF_ICP_PX_L1
+    if (l == 1) px_l = KF_ICP_PX_L1;
+#endif
+#ifdef KF_ICP_PX_L2
+    if (l == 2) px_l = KF_ICP_PX_L2;
+#endif
 #endif
     const int grid_l = (npx + ICP_THREADS * px_l - 1) / (ICP_THREADS * px_l);
     const bool has_px = (int)blockIdx.x < grid_l;
