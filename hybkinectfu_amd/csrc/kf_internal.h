@@ -134,7 +134,12 @@ struct kf_ctx {
   unsigned long long* icp_loop_slots; // persistent ICP loop: KF_ICP_LOOP_STEPS x KF_ICP_LOOP_MAX_WG x 32 tagged partial sums
   unsigned icp_loop_seq;              // host-side launch counter of that loop (x 64): tags never repeat across launches
   hipEvent_t ev_track; int track_requested;   // kf_request_track_result / kf_wait_track_result
-  int persistent_disabled;            // set when a persistent loop reported KF_TRACK_STALLED: later frames use one launch per step
+  // the persistent ICP loop after a stall (KF_TRACK_STALLED: some of its workgroups were not resident -- a foreign process on the GPU):
+  // `persistent_backoff` frames track with one launch per step, then the loop is tried again; every further stall doubles the wait
+  int persistent_backoff, persistent_backoff_len;
+  int loop_refused;                   // the device cannot hold the loop's workgroups at once (occupancy check / cooperative launch refused): never tried again
+  int loop_occupancy;                 // workgroups of k_icp_loop one CU can hold (0: not asked yet)
+  int last_track_form;                // kf_track_result::launch_form of the last tracking call
   KfTrackState* track;                // device
   KfCounters* counters;               // device
   KfGridBarrier* grid_barrier;        // device
@@ -440,5 +445,6 @@ __device__ __forceinline__ float kf_row_scan_sum(float v) {
 int kf_launch_pyramids(kf_ctx* ctx, bool model, bool vertices, bool normals);
 int kf_launch_pyramids_and_begin(kf_ctx* ctx, int begin_mode);
 int kf_live_contexts(int device);
+int kf_device_shared(int device);
 int kf_materialize_raw_depth(kf_ctx* ctx);
 int kf_pending_depth_consumed(kf_ctx* ctx);

@@ -34,6 +34,7 @@ struct TrackArgs {
   int use_state;                                 // 1: transforms come from the device-resident KfTrackState
   float dist_thres, sin_thres, dist_shake, angle_shake;
   float cos_shake, dist_shake2;                  // cos(angle_shake), dist_shake^2: the shake test without acos / sqrt (set next to the two above)
+  float dist_thres2, sin_thres2;                 // the correspondence gates' squares (gate_square: a negative threshold rejects everything, as `norm > t` does)
   float* partials;                               // 2 x KF_ICP_MAX_WG x 32 floats, indexed by step parity
   KfTrackState* track;
   int step;                                      // index of this Gauss-Newton step within the frame (buffer parity)
@@ -43,6 +44,10 @@ struct TrackArgs {
   // pixel-partitioned ICP (multi-GPU): this context sums only pixels [px_begin, px_end) (0,0 = all); the previous step's
   // system arrives all-reduced in ext_prev (27 floats) instead of workgroup partials; fold_out receives this step's 27 sums
   int px_begin, px_end;
+  // replicated ICP, one launch per step: the persistent loop's pixel dealing (icp_level_geometry) -- px_l pixels per lane dealt in
+  // 64-pixel chunks round robin over deal_grid workgroups -- so that both launch forms add the same numbers in the same order
+  // (px_l == 0: a contiguous pixel range per workgroup, the pixel-partitioned form)
+  int px_l, deal_grid;
   const float* ext_prev;
   float* fold_out;
   // SDF tracker only
@@ -231,6 +236,24 @@ __device__ __forceinline__ bool vector6_to_transform(const float x[6], float dis
   return transform_from_sincos(x, c0, s0, c1, s1, c2, s2, dist_shake2, cos_shake, t);
 }
 
+// The parts' sums of a fold (s_tot[part * 32 + k], all parts written, no barrier yet) -> s_tot[0..26]: four lanes per total add a quarter
+// of the parts each, two DPP shifts combine them -- a chain of parts/4 + 2 dependent adds instead of parts, in ONE fixed order that the
+// per-step fold (fold_partials) and the persistent loop's fold (fold_partials_tagged) share: the two launch forms of the ICP add the
+// same numbers in the same order and therefore arrive at the same bits.  Needs blockDim.x >= 108.
+__device__ __forceinline__ void fold_combine_parts(float* s_tot, int parts) {
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x < 27 * 4) {
+    const int kk = threadIdx.x >> 2, quarter = threadIdx.x & 3, per = (parts + 3) >> 2;
+    for (int p = quarter * per; p < min(parts, (quarter + 1) * per); ++p) t += s_tot[p * 32 + kk];
+    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x111, 0xf, 0xf, true));   // row_shr:1
+    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x112, 0xf, 0xf, true));   // row_shr:2
+  }
+  __syncthreads();
+  if (threadIdx.x < 27 * 4 && (threadIdx.x & 3) == 3) s_tot[threadIdx.x >> 2] = t;
+  __syncthreads();
+}
+
 // ---- fold the previous step's partial sums: identical order in every workgroup ------------------------------------------
 // s_tot must hold 8 x 32 floats; on return s_tot[0..26] are the totals (all threads, after the barrier)
 // (blockDim/32 interleaved chains per sum; the loads of a chain are issued four at a time so the chain costs
@@ -249,15 +272,7 @@ __device__ __forceinline__ void fold_partials(const float* __restrict__ partials
     }
   }
   s_tot[part * 32 + k] = s;
-  __syncthreads();
-  float t = 0.f;
-  if (threadIdx.x < 27) {
-    t = s_tot[threadIdx.x];
-    for (int p = 1; p < parts; ++p) t += s_tot[p * 32 + threadIdx.x];
-  }
-  __syncthreads();
-  if (threadIdx.x < 27) s_tot[threadIdx.x] = t;
-  __syncthreads();
+  fold_combine_parts(s_tot, parts);
 }
 
 // direct_exponential_map (eigen_utils.cpp:84-127) in double, then SDF.cpp:92-100: R' = R_exp^T R_cur, t' = t_cur - R_exp^T t_exp
@@ -456,7 +471,7 @@ __device__ __forceinline__ bool icp_finish(const TrackArgs& a, float4 vg, float4
   if (kf_is_zero4(nt)) return false;
   // `norm(p - q) > dist || norm(n_tgt x n_in) > sin` (CalPointToPlaneErrSolverParams.cu:52) on the squares: two square roots fewer per pixel
   const float3 dv = kf3(vt.x - vg.x, vt.y - vg.y, vt.z - vg.z), cr = kf_cross(kf3(nt.x, nt.y, nt.z), kf3(ng.x, ng.y, ng.z));
-  if (kf_dot(dv, dv) > a.dist_thres * a.dist_thres || kf_dot(cr, cr) > a.sin_thres * a.sin_thres) return false;
+  if (kf_dot(dv, dv) > a.dist_thres2 || kf_dot(cr, cr) > a.sin_thres2) return false;
   const float3 p = kf3(vt.x, vt.y, vt.z), q = kf3(vg.x, vg.y, vg.z), n = kf3(nt.x, nt.y, nt.z);
   row[0] = q.y * n.z - q.z * n.y; row[1] = q.z * n.x - q.x * n.z; row[2] = q.x * n.y - q.y * n.x;
   row[3] = n.x; row[4] = n.y; row[5] = n.z;
@@ -464,38 +479,51 @@ __device__ __forceinline__ bool icp_finish(const TrackArgs& a, float4 vg, float4
   return true;
 }
 
-// 512 lanes x ICP_PX (3) pixels per workgroup: 200 / 50 / 13 workgroups at VGA level 0 / 1 / 2 (few partials to fold, no register spills).
+// 512 lanes x up to ICP_PX (3) pixels per workgroup: 200 workgroups at VGA level 0 (few partials to fold, no register spills).
 #define ICP_THREADS 512
 #ifndef ICP_PX
 #define ICP_PX 3
 #endif
-__global__ void __launch_bounds__(ICP_THREADS) k_icp_step(TrackArgs a) {
-  __shared__ float s_cur[16], s_linv[16];
-  __shared__ float s_wave[27 * (ICP_THREADS / 16)], s_tot[(ICP_THREADS / 32) * 32];
-  __shared__ int s_code;
-  // the lane's own vertices / normals do not depend on the running transform: request them before the fold + solve
-  const int npx = a.px_end > 0 ? a.px_end : a.cam.cols * a.cam.rows;
-  const int base = a.px_begin + blockIdx.x * (ICP_THREADS * ICP_PX) + threadIdx.x;
-  float4 iv[ICP_PX], in_[ICP_PX];
-#pragma unroll
-  for (int j = 0; j < ICP_PX; ++j) {
-    const int i = base + j * ICP_THREADS;
-    iv[j] = make_float4(0.f, 0.f, 0.f, 0.f); in_[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < npx) { iv[j] = a.new_v[i]; in_[j] = a.new_n[i]; }
-  }
-  if (!step_prologue(a, s_cur, s_linv, s_tot, &s_code)) return;
-  float4 vg[ICP_PX], ng[ICP_PX], vt[ICP_PX], nt[ICP_PX];
-  int mi[ICP_PX];
+// Pixels per lane (px_l) and publishing workgroups (grid_l) of a pyramid level with npx pixels, under a launch geometry of loop_grid
+// workgroups (= the workgroups level 0 needs at ICP_PX pixels per lane).  Two things pull: fewer pixels per lane shorten the pixel
+// phase (a coarse step is mostly latency), but every workgroup that holds pixels is one more publisher the step has to wait for (all
+// 256 CUs publishing at every level: +36 us per frame).  Measured at VGA on 200 workgroups, tracking stage in us for (level 0, 1, 2)
+// pixels per lane, with the fold's two polls in flight: (3,3,1) 162.4, (3,2,2) 161.9, (3,2,1) 159.4, (3,1,1) 156.3 (with one poll in
+// flight (3,2,1) was ahead: 172.6 vs 175.5).  Rule: the fewest pixels per lane the launch can hold.  Host and device, both launch forms.
+__host__ __device__ static inline void icp_level_geometry(int npx, int loop_grid, int level, int& px_l, int& grid_l) {
+  px_l = ICP_PX;
+#ifndef KF_ICP_FIXED_PX
+  for (int p = 1; p < ICP_PX; ++p) if ((npx + ICP_THREADS * p - 1) / (ICP_THREADS * p) <= loop_grid) { px_l = p; break; }
+#ifdef KF_ICP_PX_L0                                                              // tuning overrides (tools/build_variant.sh)
+  if (level == 0) px_l = KF_ICP_PX_L0;
+#endif
+#ifdef KF_ICP_PX_L1
+  if (level == 1) px_l = KF_ICP_PX_L1;
+#endif
+#ifdef KF_ICP_PX_L2
+  if (level == 2) px_l = KF_ICP_PX_L2;
+#endif
+#endif
+  (void)level;
+  grid_l = (npx + ICP_THREADS * px_l - 1) / (ICP_THREADS * px_l);
+}
+// index of this lane's j-th pixel: pixels are dealt to the grid_l workgroups in 64-pixel chunks, round robin -- every workgroup sees
+// the same mix of surface and background, so they all reach the exchange of partial sums at about the same time (contiguous blocks
+// did not)
+__device__ __forceinline__ int icp_dealt_pixel(int j, int grid_l) {
+  return (((int)(threadIdx.x >> 6) * grid_l + (int)blockIdx.x) + j * ((ICP_THREADS / 64) * grid_l)) * 64 + (int)(threadIdx.x & 63);
+}
+// one Gauss-Newton step's pixel phase for this lane's (up to ICP_PX) pixels: correspondences + the 27 products, fused accumulation
+__device__ __forceinline__ void icp_accumulate(const TrackArgs& a, const float* s_cur, const float* s_linv, const float4 iv[ICP_PX], const float4 in_[ICP_PX],
+                                               const float4* __restrict__ model_v, const float4* __restrict__ model_n, float acc[27]) {
+  float4 vg[ICP_PX], ng[ICP_PX], vt[ICP_PX], nt[ICP_PX]; int mi[ICP_PX];
 #pragma unroll
   for (int j = 0; j < ICP_PX; ++j) mi[j] = icp_project(a, s_cur, s_linv, iv[j], in_[j], vg[j], ng[j]);
 #pragma unroll
   for (int j = 0; j < ICP_PX; ++j) {
     nt[j] = make_float4(0.f, 0.f, 0.f, 0.f); vt[j] = nt[j];
-    if (mi[j] >= 0) { nt[j] = a.model_n[mi[j]]; vt[j] = a.model_v[mi[j]]; }
+    if (mi[j] >= 0) { nt[j] = model_n[mi[j]]; vt[j] = model_v[mi[j]]; }
   }
-  float acc[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
 #pragma unroll
   for (int j = 0; j < ICP_PX; ++j) {
     float row[7];
@@ -504,9 +532,54 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_step(TrackArgs a) {
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int c = r; c < 7; ++c) { acc[s] = __builtin_fmaf(row[r], row[c], acc[s]); ++s; }   // :92-105 packing; fused: the sums are tolerance-checked, and this is the better rounding
+      for (int c = r; c < 7; ++c) { acc[s] = __builtin_fmaf(row[r], row[c], acc[s]); ++s; }   // :92-105 packing; fused multiply-add: half the instructions, the better rounding (the sums are tolerance-checked)
   }
-  store_partial(acc, a.partials + (size_t)(a.step & 1) * KF_ICP_MAX_WG * 32, s_wave);
+}
+// workgroup total of the 27 sums (512 lanes): 16-lane row totals by DPP, one LDS word per (sum, row), then 4 lanes per sum add 8 row
+// totals each and two DPP shifts combine the four partial chains (fixed order).  Returns true on the one lane that ends up holding
+// sum k in sw.  s_wave: 27 x 32 floats.
+__device__ __forceinline__ bool icp_wg_reduce(float acc[27], float* s_wave, int& k, float& sw) {
+  const int row = threadIdx.x >> 4;
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = kf_row_scan_sum(acc[i]);      // 27 independent DPP chains, free to interleave
+  if ((threadIdx.x & 15) == 15) {
+#pragma unroll
+    for (int i = 0; i < 27; ++i) s_wave[i * (ICP_THREADS / 16) + row] = acc[i];
+  }
+  __syncthreads();
+  k = threadIdx.x >> 2; sw = 0.f;
+  if (threadIdx.x < 27 * 4) {
+    const int part = threadIdx.x & 3;
+    sw = s_wave[k * (ICP_THREADS / 16) + part * 8];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) sw += s_wave[k * (ICP_THREADS / 16) + part * 8 + w];
+    sw += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sw), 0x111, 0xf, 0xf, true));   // row_shr:1
+    sw += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sw), 0x112, 0xf, 0xf, true));   // row_shr:2
+    return part == 3;
+  }
+  return false;
+}
+__global__ void __launch_bounds__(ICP_THREADS) k_icp_step(TrackArgs a) {
+  __shared__ float s_cur[16], s_linv[16];
+  __shared__ float s_wave[27 * (ICP_THREADS / 16)], s_tot[(ICP_THREADS / 32) * 32];
+  __shared__ int s_code;
+  // the lane's own vertices / normals do not depend on the running transform: request them before the fold + solve
+  const int npx = a.px_end > 0 ? a.px_end : a.cam.cols * a.cam.rows;
+  float4 iv[ICP_PX], in_[ICP_PX];
+#pragma unroll
+  for (int j = 0; j < ICP_PX; ++j) {
+    // px_l > 0: the persistent loop's dealing (same pixels in the same lanes -> same bits); else a contiguous range per workgroup
+    const int i = a.px_l > 0 ? icp_dealt_pixel(j, a.deal_grid) : a.px_begin + (int)blockIdx.x * (ICP_THREADS * ICP_PX) + (int)threadIdx.x + j * ICP_THREADS;
+    iv[j] = make_float4(0.f, 0.f, 0.f, 0.f); in_[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((a.px_l == 0 || j < a.px_l) && i < npx) { iv[j] = a.new_v[i]; in_[j] = a.new_n[i]; }
+  }
+  if (!step_prologue(a, s_cur, s_linv, s_tot, &s_code)) return;
+  float acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+  icp_accumulate(a, s_cur, s_linv, iv, in_, a.model_v, a.model_n, acc);
+  int k; float sw;
+  if (icp_wg_reduce(acc, s_wave, k, sw)) a.partials[(size_t)(a.step & 1) * KF_ICP_MAX_WG * 32 + blockIdx.x * 32 + k] = sw;
 }
 
 // ---- persistent ICP: the whole 19-step loop in ONE launch ---------------------------------------------------------------------
@@ -522,7 +595,7 @@ struct IcpLoopArgs {
   const float4* model_v[KF_MAX_LEVELS]; const float4* model_n[KF_MAX_LEVELS];
   KfCam cam[KF_MAX_LEVELS];
   int iters[KF_MAX_LEVELS]; int levels;
-  float dist_thres, sin_thres, dist_shake, angle_shake, cos_shake, dist_shake2;
+  float dist_thres, sin_thres, dist_shake, angle_shake, cos_shake, dist_shake2, dist_thres2, sin_thres2;
   unsigned long long* slots;                     // KF_ICP_LOOP_STEPS x KF_ICP_LOOP_MAX_WG x 32 tagged partial sums, one array per step
   unsigned tag_base;                             // this launch's sequence number (host counter x 64); tag = tag_base + step
   KfTrackState* track;
@@ -530,7 +603,7 @@ struct IcpLoopArgs {
   int exp_mode;                                  // diagnostics only (KF_ICP_EXP): 1 = skip the solve (timing), 7 = shader-clock stamps per phase
 };
 
-#define ICP_SPIN_LIMIT 200000u          // polls (~1-2 us each) before a workgroup gives up: a legitimate wait is tens of microseconds
+#define ICP_SPIN_LIMIT 8192u            // polls (~1-1.5 us each: about 10 ms) before a workgroup gives up: a legitimate wait is tens of microseconds
 #define ICP_FOLD_BATCH 13
 #ifndef KF_ICP_POLL_PIPE
 #define KF_ICP_POLL_PIPE 2        // s_sleep between the two polls kept in flight (0 is not a value: -DKF_ICP_POLL_SINGLE selects the one-poll loop)
@@ -600,19 +673,7 @@ __device__ __forceinline__ void fold_partials_tagged(const unsigned long long* s
     }
   }
   s_tot[part * 32 + k] = s;
-  __syncthreads();
-  // the parts' sums: four lanes per total add a quarter of the parts each, two DPP shifts combine them (fixed order, the same in
-  // every workgroup) -- a chain of parts/4 + 2 dependent adds instead of parts
-  float t = 0.f;
-  if (threadIdx.x < 27 * 4) {
-    const int kk = threadIdx.x >> 2, quarter = threadIdx.x & 3, per = (parts + 3) >> 2;
-    for (int p = quarter * per; p < min(parts, (quarter + 1) * per); ++p) t += s_tot[p * 32 + kk];
-    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x111, 0xf, 0xf, true));   // row_shr:1
-    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x112, 0xf, 0xf, true));   // row_shr:2
-  }
-  __syncthreads();
-  if (threadIdx.x < 27 * 4 && (threadIdx.x & 3) == 3) s_tot[threadIdx.x >> 2] = t;
-  __syncthreads();
+  fold_combine_parts(s_tot, parts);       // the parts' sums, in the order the per-step fold uses too
 }
 
 __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
@@ -626,7 +687,8 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   if (threadIdx.x == 0) kf_mat44_inverse(s_cur, s_linv);                        // ICP.cpp:63 last_transform_inv
   __syncthreads();
   TrackArgs a;
-  a.dist_thres = L.dist_thres; a.sin_thres = L.sin_thres; a.dist_shake = L.dist_shake; a.angle_shake = L.angle_shake; a.cos_shake = L.cos_shake; a.dist_shake2 = L.dist_shake2; a.sdf = 0;
+  a.dist_thres = L.dist_thres; a.sin_thres = L.sin_thres; a.dist_shake = L.dist_shake; a.angle_shake = L.angle_shake; a.cos_shake = L.cos_shake; a.dist_shake2 = L.dist_shake2;
+  a.dist_thres2 = L.dist_thres2; a.sin_thres2 = L.sin_thres2; a.sdf = 0;
 #ifdef KF_EXPERIMENTS
   a.dbg = (KF_EXP_MODE(L) == 11 && blockIdx.x == 0) ? L.slots + (size_t)26 * KF_ICP_LOOP_MAX_WG * 32 : nullptr;
 #endif
@@ -641,35 +703,15 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     const float4* __restrict__ new_v = L.new_v[l]; const float4* __restrict__ new_n = L.new_n[l];
     const float4* __restrict__ model_v = L.model_v[l]; const float4* __restrict__ model_n = L.model_n[l];
     const int npx = a.cam.cols * a.cam.rows;
-    // Pixels per lane at this level.  Two things pull: fewer pixels per lane shorten the pixel phase (a coarse step is mostly latency),
-    // but every workgroup that holds pixels is one more publisher the step has to wait for (all 256 CUs publishing at every level: +36 us
-    // per frame).  Measured at VGA on 200 workgroups, tracking stage in us for (level 0, 1, 2) pixels per lane, with the fold's two polls
-    // in flight: (3,3,1) 162.4, (3,2,2) 161.9, (3,2,1) 159.4, (3,1,1) 156.3 (with one poll in flight (3,2,1) was ahead: 172.6 vs 175.5).
-    // Rule: the fewest pixels per lane the launch can hold.
-    int px_l = ICP_PX;
-#ifndef KF_ICP_FIXED_PX
-    for (int p = 1; p < ICP_PX; ++p) if ((npx + ICP_THREADS * p - 1) / (ICP_THREADS * p) <= (int)gridDim.x) { px_l = p; break; }
-#ifdef KF_ICP_PX_L0                                                              // tuning overrides (tools/build_variant.sh)
-    if (l == 0) px_l = KF_ICP_PX_L0;
-#endif
-#ifdef KF_ICP_PX_L1
-    if (l == 1) px_l = KF_ICP_PX_L1;
-#endif
-#ifdef KF_ICP_PX_L2
-    if (l == 2) px_l = KF_ICP_PX_L2;
-#endif
-#endif
-    const int grid_l = (npx + ICP_THREADS * px_l - 1) / (ICP_THREADS * px_l);
+    int px_l, grid_l;
+    icp_level_geometry(npx, (int)gridDim.x, l, px_l, grid_l);
     const bool has_px = (int)blockIdx.x < grid_l;
-    // pixels are dealt to the workgroups in 64-pixel chunks, round robin: every workgroup sees the same mix of surface and
-    // background, so they all reach the exchange of partial sums at about the same time (contiguous blocks did not)
-    const int chunk0 = (int)(threadIdx.x >> 6) * grid_l + (int)blockIdx.x, chunk_step = (ICP_THREADS / 64) * grid_l;
     // this lane's own vertices / normals depend neither on the running transform nor on the iteration: they are loaded once
     // per pyramid level and stay in registers for all of its iterations (the reference re-reads them 4 / 5 / 10 times)
     float4 iv[ICP_PX], in_[ICP_PX];
 #pragma unroll
     for (int j = 0; j < ICP_PX; ++j) {
-      const int i = (chunk0 + j * chunk_step) * 64 + (int)(threadIdx.x & 63);
+      const int i = icp_dealt_pixel(j, grid_l);
       iv[j] = make_float4(0.f, 0.f, 0.f, 0.f); in_[j] = iv[j];
       if (has_px && j < px_l && i < npx) { iv[j] = new_v[i]; in_[j] = new_n[i]; }
     }
@@ -699,52 +741,18 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
 #pragma unroll
       for (int k = 0; k < 27; ++k) acc[k] = 0.f;
       if (has_px) {
-        float4 vg[ICP_PX], ng[ICP_PX], vt[ICP_PX], nt[ICP_PX]; int mi[ICP_PX];
-#pragma unroll
-        for (int j = 0; j < ICP_PX; ++j) mi[j] = icp_project(a, s_cur, s_linv, iv[j], in_[j], vg[j], ng[j]);
-#pragma unroll
-        for (int j = 0; j < ICP_PX; ++j) {
-          nt[j] = make_float4(0.f, 0.f, 0.f, 0.f); vt[j] = nt[j];
-          if (mi[j] >= 0) { nt[j] = model_n[mi[j]]; vt[j] = model_v[mi[j]]; }
-        }
-#pragma unroll
-        for (int j = 0; j < ICP_PX; ++j) {
-          float row[7];
-          if (mi[j] < 0 || !icp_finish(a, vg[j], ng[j], vt[j], nt[j], row)) continue;
-          int s = 0;
-#pragma unroll
-          for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = r; c < 7; ++c) { acc[s] = __builtin_fmaf(row[r], row[c], acc[s]); ++s; }    // fused multiply-add: half the instructions of the accumulation
-        }
+        icp_accumulate(a, s_cur, s_linv, iv, in_, model_v, model_n, acc);
         KF_STAMP(3);
 #ifdef KF_EXPERIMENTS
         if (KF_EXP_MODE(L) == 9 && blockIdx.x == 5 && (threadIdx.x & 63) == 0)     // per-wave: pixel phase done (workgroup 5)
           L.slots[(size_t)25 * KF_ICP_LOOP_MAX_WG * 32 + (size_t)step * 32 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime();
 #endif
         // workgroup partial, stored write-through (sc1) for the other CUs
-        // 16-lane row totals by DPP, one LDS word per (sum, row), then 27 lanes add the 32 row totals in a fixed order
-        const int row = threadIdx.x >> 4;
-#pragma unroll
-        for (int k = 0; k < 27; ++k) acc[k] = kf_row_scan_sum(acc[k]);      // 27 independent DPP chains, free to interleave
-        if ((threadIdx.x & 15) == 15) {
-#pragma unroll
-          for (int k = 0; k < 27; ++k) s_wave[k * (ICP_THREADS / 16) + row] = acc[k];
-        }
-        __syncthreads();
-        // 4 lanes per sum add 8 row totals each, then two DPP shifts combine the four partial chains (fixed order)
-        if (threadIdx.x < 27 * 4) {
-          const int k = threadIdx.x >> 2, part = threadIdx.x & 3;
-          float sw = s_wave[k * (ICP_THREADS / 16) + part * 8];
-#pragma unroll
-          for (int w = 1; w < 8; ++w) sw += s_wave[k * (ICP_THREADS / 16) + part * 8 + w];
-          sw += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sw), 0x111, 0xf, 0xf, true));   // row_shr:1
-          sw += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sw), 0x112, 0xf, 0xf, true));   // row_shr:2
-          if (part == 3)
-            __hip_atomic_store(L.slots + (size_t)step * KF_ICP_LOOP_MAX_WG * 32 + blockIdx.x * 32 + k,
-                               ((unsigned long long)(L.tag_base + (unsigned)step) << 32) | (unsigned long long)__float_as_uint(sw),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        int k; float sw;
+        if (icp_wg_reduce(acc, s_wave, k, sw))
+          __hip_atomic_store(L.slots + (size_t)step * KF_ICP_LOOP_MAX_WG * 32 + blockIdx.x * 32 + k,
+                             ((unsigned long long)(L.tag_base + (unsigned)step) << 32) | (unsigned long long)__float_as_uint(sw),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       KF_STAMP(4);
       KF_STAMP(5);
@@ -873,6 +881,15 @@ __global__ void __launch_bounds__(ICP_THREADS) k_track_finish(TrackArgs a) {
 
 // acos(ca) <= angle  <=>  ca >= cos(angle) for angle in [0, pi]; beyond pi every rotation passes, below 0 none does (NaN stays NaN: none)
 static inline float shake_cos(float angle) { return angle >= 3.14159274f ? -2.f : (angle < 0.f ? 2.f : cosf(angle)); }
+// norm > t  <=>  norm^2 > t^2 only for t >= 0; for a negative threshold the reference's comparison holds for every norm (every pixel
+// is rejected, every increment counts as shaking): -1 keeps that, since a squared norm is never below zero
+static inline float gate_square(float t) { return t < 0.f ? -1.f : t * t; }
+// the thresholds of one tracking call, in every form the kernels use
+static inline void set_thresholds(TrackArgs& a, float dist_thres, float sin_thres, float dist_shake, float angle_shake) {
+  a.dist_thres = dist_thres; a.sin_thres = sin_thres; a.dist_shake = dist_shake; a.angle_shake = angle_shake;
+  a.cos_shake = shake_cos(angle_shake); a.dist_shake2 = gate_square(dist_shake);
+  a.dist_thres2 = gate_square(dist_thres); a.sin_thres2 = gate_square(sin_thres);
+}
 static inline KfCam to_cam(const kf_camera_params* p) {
   KfCam c; c.cols = (int)p->cols; c.rows = (int)p->rows; c.cx = p->cx; c.cy = p->cy; c.fx = p->fx; c.fy = p->fy; return c;
 }
@@ -904,7 +921,7 @@ extern "C" int kf_cal_point_to_plane_solver_params(kf_ctx* c, uint32_t level, co
   a.new_v = c->new_v[level]; a.new_n = c->new_n[level]; a.model_v = c->model_v[level]; a.model_n = c->model_n[level];
   a.cam = to_cam(cam);
   for (int i = 0; i < 16; ++i) { a.cur_val.m[i] = cur->m[i]; a.linv_val.m[i] = last_inv->m[i]; }
-  a.dist_thres = dist_thres; a.sin_thres = sin_thres;
+  set_thresholds(a, dist_thres, sin_thres, 0.f, 0.f);
   a.partials = c->icp_partials; a.track = c->track;
   const int grid = icp_grid(a.cam.cols * a.cam.rows);
   if (grid > KF_ICP_MAX_WG) return KF_ERR_ARG;
@@ -936,9 +953,19 @@ extern "C" int kf_read_solver_params(kf_ctx* c, float out27[27]) {
   return 0;
 }
 
+#ifndef KF_ICP_COOPERATIVE_DEFAULT
+#define KF_ICP_COOPERATIVE_DEFAULT 0
+#endif
+// a persistent loop reported KF_TRACK_STALLED: back off to per-step launches for a while (64 frames, doubling up to 4096 on repeats)
+static void kf_note_loop_stall(kf_ctx* c) {
+  c->persistent_backoff_len = c->persistent_backoff_len ? (c->persistent_backoff_len >= 2048 ? 4096 : c->persistent_backoff_len * 2) : 64;
+  c->persistent_backoff = c->persistent_backoff_len;
+}
+
 extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* icp, const kf_camera_params* cam0) {
   if (!c || !icp || !cam0) return KF_ERR_ARG;
   if ((int)icp->pyramid_levels != c->levels || (int)cam0->cols != c->cols || (int)cam0->rows != c->rows) return KF_ERR_ARG;
+  c->last_track_form = 0;
   if (frame_id == 0) {                                       // ICP.cpp:52-55
     hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, 0, c->grid_barrier);
     return (int)hipGetLastError();
@@ -954,32 +981,57 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
     cams[l].cx = cams[l - 1].cx / 2; cams[l].cy = cams[l - 1].cy / 2; cams[l].fx = cams[l - 1].fx / 2; cams[l].fy = cams[l - 1].fy / 2;
   }
   const int grid0 = icp_grid(c->cols * c->rows);
-  static int persistent_env = -1;
+  static int persistent_env = -1, coop_env = -1;
   if (persistent_env < 0) { const char* e = getenv("KF_ICP_PERSISTENT"); persistent_env = e ? atoi(e) : 1; }
-  // a persistent loop of an EARLIER frame that gave up waiting (its workgroups were not co-resident: another process on the
-  // GPU) has set the pinned stall word by now -- no read-back of the verdict needed: from here on one launch per step
-  if (*(volatile unsigned*)((char*)c->host_pinned + KF_PINNED_STALL_WORD)) c->persistent_disabled = 1;
-  if (persistent_env && !c->persistent_disabled && grid0 <= c->num_cus && grid0 <= KF_ICP_LOOP_MAX_WG && iters[0] + iters[1] + iters[2] <= KF_ICP_LOOP_STEPS &&
-      kf_live_contexts(c->cfg.device) == 1) {
-    // every workgroup must be resident at once (they wait for each other's tagged partial sums): one 512-lane workgroup per CU, grid0 <= #CUs
+  if (coop_env < 0) { const char* e = getenv("KF_ICP_COOPERATIVE"); coop_env = e ? atoi(e) : KF_ICP_COOPERATIVE_DEFAULT; }
+  // A persistent loop of an EARLIER frame that gave up waiting (its workgroups were not co-resident: a foreign process on the GPU) has
+  // set the pinned stall word by now -- no read-back of the verdict needed.  The next frames use one launch per step (same bits, see
+  // k_icp_step); after `persistent_backoff_len` of them the loop is tried again, and every further stall doubles that wait.
+  unsigned* stall_word = (unsigned*)((char*)c->host_pinned + KF_PINNED_STALL_WORD);
+  if (__atomic_load_n(stall_word, __ATOMIC_RELAXED)) { __atomic_store_n(stall_word, 0u, __ATOMIC_RELAXED); kf_note_loop_stall(c); }
+  bool use_loop = persistent_env && !c->loop_refused && grid0 <= KF_ICP_LOOP_MAX_WG && iters[0] + iters[1] + iters[2] <= KF_ICP_LOOP_STEPS &&
+                  kf_live_contexts(c->cfg.device) == 1 && !kf_device_shared(c->cfg.device);
+  if (use_loop && c->loop_occupancy == 0) {
+    // every workgroup must be resident at once (they wait for each other's tagged partial sums): ask the runtime how many 512-lane
+    // workgroups of THIS kernel a CU holds (registers, LDS) instead of assuming one
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_icp_loop, ICP_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = -1;
+    c->loop_occupancy = per_cu;
+  }
+  if (use_loop && (c->loop_occupancy < 1 || (long long)grid0 > (long long)c->loop_occupancy * c->num_cus)) use_loop = false;     // e.g. 1280x960: 800 workgroups
+  if (use_loop && c->persistent_backoff > 0) { --c->persistent_backoff; use_loop = false; }
+  if (use_loop) {
     IcpLoopArgs L; memset(&L, 0, sizeof(L));
     for (int l = 0; l < c->levels; ++l) {
       L.new_v[l] = c->new_v[l]; L.new_n[l] = c->new_n[l]; L.model_v[l] = c->model_v[l]; L.model_n[l] = c->model_n[l];
       L.cam[l] = to_cam(&cams[l]); L.iters[l] = iters[l];
     }
     L.levels = c->levels;
-    L.dist_thres = icp->dist_thres; L.sin_thres = icp->norm_sin_thres; L.dist_shake = icp->dist_shake; L.angle_shake = icp->angle_shake; L.cos_shake = shake_cos(icp->angle_shake); L.dist_shake2 = icp->dist_shake * icp->dist_shake;
+    { TrackArgs th; set_thresholds(th, icp->dist_thres, icp->norm_sin_thres, icp->dist_shake, icp->angle_shake);
+      L.dist_thres = th.dist_thres; L.sin_thres = th.sin_thres; L.dist_shake = th.dist_shake; L.angle_shake = th.angle_shake;
+      L.cos_shake = th.cos_shake; L.dist_shake2 = th.dist_shake2; L.dist_thres2 = th.dist_thres2; L.sin_thres2 = th.sin_thres2; }
     c->icp_loop_seq += 64u;                                  // tags of one launch never collide with an earlier launch's slots
     L.slots = c->icp_loop_slots; L.tag_base = c->icp_loop_seq; L.track = c->track;
-    L.stall_word = (unsigned*)((char*)c->host_pinned + KF_PINNED_STALL_WORD);
+    L.stall_word = stall_word;
     { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_ICP_EXP"); L.exp_mode = em; }
-    hipLaunchKernelGGL(k_icp_loop, dim3(grid0), dim3(ICP_THREADS), 0, c->stream, L);
-    kf_evt_end(c, KF_STAGE_TRACK);
-    return (int)hipGetLastError();
+    if (coop_env) {
+      // a cooperative launch: the runtime itself checks that the whole grid can be resident and refuses otherwise
+      void* params[] = {(void*)&L};
+      const hipError_t e = hipLaunchCooperativeKernel((const void*)k_icp_loop, dim3(grid0), dim3(ICP_THREADS), params, 0, c->stream);
+      if (e == hipSuccess) { c->last_track_form = 1; kf_evt_end(c, KF_STAGE_TRACK); return 0; }
+      (void)hipGetLastError();                               // refused: this device / configuration cannot hold the loop -- per-step from now on
+      c->loop_refused = 1;
+    } else {
+      hipLaunchKernelGGL(k_icp_loop, dim3(grid0), dim3(ICP_THREADS), 0, c->stream, L);
+      c->last_track_form = 1;
+      kf_evt_end(c, KF_STAGE_TRACK);
+      return (int)hipGetLastError();
+    }
   }
+  // one launch per Gauss-Newton step: the same pixel dealing, the same reduction and fold orders as the loop -> the same pose bits
   TrackArgs a; memset(&a, 0, sizeof(a));
   a.use_state = 1;
-  a.dist_thres = icp->dist_thres; a.sin_thres = icp->norm_sin_thres; a.dist_shake = icp->dist_shake; a.angle_shake = icp->angle_shake; a.cos_shake = shake_cos(icp->angle_shake); a.dist_shake2 = icp->dist_shake * icp->dist_shake;
+  set_thresholds(a, icp->dist_thres, icp->norm_sin_thres, icp->dist_shake, icp->angle_shake);
   a.partials = c->icp_partials; a.track = c->track;
   int step = 0, prev_grid = 0;
   for (int l = c->levels - 1; l >= 0; --l)                   // coarse -> fine, ICP.cpp:65
@@ -987,13 +1039,15 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
       a.new_v = c->new_v[l]; a.new_n = c->new_n[l]; a.model_v = c->model_v[l]; a.model_n = c->model_n[l];
       a.cam = to_cam(&cams[l]);
       a.step = step; a.consume = step > 0; a.n_prev_wg = prev_grid;
-      const int grid = icp_grid(a.cam.cols * a.cam.rows);
+      icp_level_geometry(a.cam.cols * a.cam.rows, grid0, l, a.px_l, a.deal_grid);
+      const int grid = a.deal_grid;
       if (grid > KF_ICP_MAX_WG) return KF_ERR_ARG;
       hipLaunchKernelGGL(k_icp_step, dim3(grid), dim3(ICP_THREADS), 0, c->stream, a);
       prev_grid = grid; ++step;
     }
   a.step = step; a.consume = 1; a.n_prev_wg = prev_grid;
   hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, a);
+  c->last_track_form = 2;
   kf_evt_end(c, KF_STAGE_TRACK);
   return (int)hipGetLastError();
 }
@@ -1026,7 +1080,7 @@ extern "C" int kf_icp_partition_step(kf_ctx* c, uint32_t step, const kf_icp_para
   a.use_state = 1;
   a.new_v = c->new_v[l]; a.new_n = c->new_n[l]; a.model_v = c->model_v[l]; a.model_n = c->model_n[l];
   a.cam = to_cam(&cam);
-  a.dist_thres = icp->dist_thres; a.sin_thres = icp->norm_sin_thres; a.dist_shake = icp->dist_shake; a.angle_shake = icp->angle_shake; a.cos_shake = shake_cos(icp->angle_shake); a.dist_shake2 = icp->dist_shake * icp->dist_shake;
+  set_thresholds(a, icp->dist_thres, icp->norm_sin_thres, icp->dist_shake, icp->angle_shake);
   a.partials = c->icp_partials; a.track = c->track;
   a.step = (int)step; a.consume = step > 0; a.ext_prev = step > 0 ? dev_sums : nullptr;
   const int rows_per = kf_div_up(a.cam.rows, (int)parts);                    // whole image rows per rank
@@ -1045,7 +1099,7 @@ extern "C" int kf_icp_partition_finish(kf_ctx* c, const kf_icp_params* icp, cons
   int iters[KF_MAX_LEVELS];
   TrackArgs a; memset(&a, 0, sizeof(a));
   a.use_state = 1; a.consume = 1; a.step = icp_iters(c->levels, iters); a.ext_prev = dev_sums;
-  a.dist_shake = icp->dist_shake; a.angle_shake = icp->angle_shake; a.cos_shake = shake_cos(icp->angle_shake); a.dist_shake2 = icp->dist_shake * icp->dist_shake; a.partials = c->icp_partials; a.track = c->track;
+  set_thresholds(a, icp->dist_thres, icp->norm_sin_thres, icp->dist_shake, icp->angle_shake); a.partials = c->icp_partials; a.track = c->track;
   hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, a);
   return (int)hipGetLastError();
 }
@@ -1061,6 +1115,7 @@ extern "C" int kf_exp_read_icp_slots(kf_ctx* c, unsigned long long* dst, size_t 
 extern "C" int kf_sdf_track(kf_ctx* c, uint32_t frame_id, const kf_sdf_tracker_params* sp, const kf_camera_params* cam) {
   if (!c || !sp || !cam) return KF_ERR_ARG;
   if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
+  c->last_track_form = 0;
   if (frame_id == 0) {                                       // SDF.cpp:46-49
     hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, 0, c->grid_barrier);
     return (int)hipGetLastError();
@@ -1070,7 +1125,7 @@ extern "C" int kf_sdf_track(kf_ctx* c, uint32_t frame_id, const kf_sdf_tracker_p
   TrackArgs a; memset(&a, 0, sizeof(a));
   a.use_state = 1; a.sdf = 1;
   a.cam = to_cam(cam); a.vol = c->vol; a.depth = c->trunced_depth;
-  a.dist_shake = sp->dist_shake; a.angle_shake = sp->angle_shake; a.cos_shake = shake_cos(sp->angle_shake); a.dist_shake2 = sp->dist_shake * sp->dist_shake;
+  set_thresholds(a, 0.f, 0.f, sp->dist_shake, sp->angle_shake);
   a.partials = c->icp_partials; a.track = c->track;
   const int grid = track_grid(c->cols * c->rows);
   int step = 0;
@@ -1103,8 +1158,8 @@ extern "C" int kf_wait_track_result(kf_ctx* c, kf_track_result* out) {
   c->track_requested = 0;
   const KfTrackState* h = (const KfTrackState*)((const char*)c->host_pinned + 1024);
   memcpy(out->pose.m, h->pose, 64);
-  out->tracked = h->tracked; out->status = h->status; out->iterations = h->iterations; out->reserved = 0;
-  if (h->status == KF_TRACK_STALLED) c->persistent_disabled = 1;
+  out->tracked = h->tracked; out->status = h->status; out->iterations = h->iterations; out->launch_form = c->last_track_form;
+  if (h->status == KF_TRACK_STALLED && c->persistent_backoff == 0) kf_note_loop_stall(c);
   return 0;
 }
 
@@ -1114,9 +1169,9 @@ extern "C" int kf_read_track_result(kf_ctx* c, kf_track_result* out) {
   KF_CHECK(hipMemcpyAsync(h, c->track, sizeof(KfTrackState), hipMemcpyDeviceToHost, c->stream));
   KF_CHECK(hipStreamSynchronize(c->stream));
   memcpy(out->pose.m, h->pose, 64);
-  out->tracked = h->tracked; out->status = h->status; out->iterations = h->iterations; out->reserved = 0;
+  out->tracked = h->tracked; out->status = h->status; out->iterations = h->iterations; out->launch_form = c->last_track_form;
   // status 3: the persistent loop gave up waiting for a partial sum -- some of its workgroups were not resident (another
-  // process on the GPU?).  The frame counts as lost; from now on this context tracks with one launch per step.
-  if (h->status == KF_TRACK_STALLED) c->persistent_disabled = 1;
+  // process on the GPU?).  The frame counts as lost; the next frames track with one launch per step, then the loop is tried again.
+  if (h->status == KF_TRACK_STALLED && c->persistent_backoff == 0) kf_note_loop_stall(c);
   return 0;
 }

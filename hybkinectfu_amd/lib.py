@@ -58,7 +58,7 @@ class Config(C.Structure):
 
 
 class TrackResult(C.Structure):
-    _fields_ = [("pose", Mat44), ("tracked", C.c_int32), ("status", C.c_int32), ("iterations", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("pose", Mat44), ("tracked", C.c_int32), ("status", C.c_int32), ("iterations", C.c_int32), ("launch_form", C.c_int32)]
 
 
 class VolumeStats(C.Structure):
@@ -283,6 +283,7 @@ class Context:
     def track_result(self):
         r = TrackResult()
         _chk(self.lib.kf_read_track_result(self.h, C.byref(r)), "kf_read_track_result")
+        self.last_form = r.launch_form       # 1: persistent device loop, 2: one launch per Gauss-Newton step (same pose bits), 0: none
         return bool(r.tracked), r.pose.numpy(), r.status, r.iterations
 
     # ---- volume ----

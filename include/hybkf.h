@@ -73,7 +73,8 @@ typedef struct kf_track_result {
   int32_t  tracked;         /* bool returned by findCameraPose */
   int32_t  status;          /* KF_TRACK_* */
   int32_t  iterations;      /* Gauss-Newton iterations actually applied */
-  int32_t  reserved;
+  int32_t  launch_form;     /* how the last ICP call was launched: 0 none (frame 0, SDF tracker), 1 persistent device loop, 2 one launch per
+                             * Gauss-Newton step (image too large for co-resident workgroups, GPU shared, after a stall); same pose bits either way */
 } kf_track_result;
 
 typedef struct kf_volume_stats {

@@ -177,6 +177,11 @@ inline bool interpolate_color(const okf_volume* v, f3 pos, uint8_t out[3]) {
   return true;
 }
 
+/* tests only, see okf_set_perturbation below; 0 = the restatement proper */
+int g_perturb = 0;
+/* a quotient as a product with the divisor's rounded reciprocal: at most an ulp or so off the IEEE quotient (perturbation bit 3) */
+inline float quot(float a, float b) { return (g_perturb & 8) ? a * (1.0f / b) : a / b; }
+
 /* ---- small dense linear algebra in fp32 (stands in for Eigen, which the image lacks) ---- */
 /* determinant by LU with partial pivoting (Eigen's path for 6x6: PartialPivLU) */
 float det6(const float A[36]) {
@@ -207,12 +212,12 @@ void llt_solve6(const float A[36], const float b[6], float x[6]) {
     for (int i = j + 1; i < 6; ++i) {
       float t = A[i * 6 + j];
       for (int k = 0; k < j; ++k) t -= L[i * 6 + k] * L[j * 6 + k];
-      L[i * 6 + j] = t / d;
+      L[i * 6 + j] = quot(t, d);
     }
   }
   float y[6];
-  for (int i = 0; i < 6; ++i) { float t = b[i]; for (int k = 0; k < i; ++k) t -= L[i * 6 + k] * y[k]; y[i] = t / L[i * 6 + i]; }
-  for (int i = 5; i >= 0; --i) { float t = y[i]; for (int k = i + 1; k < 6; ++k) t -= L[k * 6 + i] * x[k]; x[i] = t / L[i * 6 + i]; }
+  for (int i = 0; i < 6; ++i) { float t = b[i]; for (int k = 0; k < i; ++k) t -= L[i * 6 + k] * y[k]; y[i] = quot(t, L[i * 6 + i]); }
+  for (int i = 5; i >= 0; --i) { float t = y[i]; for (int k = i + 1; k < 6; ++k) t -= L[k * 6 + i] * x[k]; x[i] = quot(t, L[i * 6 + i]); }
 }
 /* 27 packed sums -> symmetric 6x6 + rhs : src/CameraPoseFinderICP.cpp:119-136 */
 void unpack27(const float in[27], float A[36], float b[6]) {
@@ -235,6 +240,12 @@ const uint64_t kTriWords[256] = {
 }  // namespace
 
 extern "C" {
+
+/* Last-bit perturbations of the tracker's inputs (tests only: how far does the oracle diverge from a 1-ulp-perturbed copy of
+ * itself over a sequence?  tests/test_tracking_floor.py).  bit 0: the 27 ICP / SDF sums are accumulated in the reversed pixel order;
+ * bit 1: bilateral weights by exp2f(x * log2(e)) instead of expf(x); bit 2: the products of a row are accumulated with fused
+ * multiply-adds; bit 3: the Cholesky solve's quotients as products with a rounded reciprocal.  0 (default) = the restatement proper. */
+void okf_set_perturbation(int mode) { g_perturb = mode; }
 
 int okf_set_threads(int n) {
   if (n > 0) omp_set_num_threads(n);
@@ -279,7 +290,8 @@ void okf_bilateral(const float* in, int cols, int rows, float sigma_pixel, float
           if (fabsf(tmp - value) > 5 * sigma_depth) { abort_px = true; break; }   /* :66-69 keeps the raw value */
           float space2 = (float)((x - cx) * (x - cx) + (y - cy) * (y - cy));
           float data2 = (value - tmp) * (value - tmp);
-          float w = expf(-(space2 * ss_inv + data2 * sd_inv));                       /* __expf on the device */
+          float w = (g_perturb & 2) ? exp2f(-(space2 * ss_inv + data2 * sd_inv) * 1.44269504f)
+                                    : expf(-(space2 * ss_inv + data2 * sd_inv));     /* __expf on the device */
           sum1 += tmp * w; sum2 += w;
         }
       if (abort_px) continue;
@@ -379,19 +391,24 @@ void okf_icp_system(const float* new_v, const float* new_n, const float* model_v
   double* rowd = (double*)calloc((size_t)rows * 27, sizeof(double));
   float* rowf = (float*)calloc((size_t)rows * 27, sizeof(float));
   int* rown = (int*)calloc((size_t)rows, sizeof(int));
+  const bool rev = (g_perturb & 1) != 0, fused = (g_perturb & 4) != 0;
 #pragma omp parallel for schedule(static)
   for (int y = 0; y < rows; ++y)
-    for (int x = 0; x < cols; ++x) {
+    for (int xx = 0; xx < cols; ++xx) {
+      const int x = rev ? cols - 1 - xx : xx;
       float row[7];
       if (!icp_row(x, y, new_v, new_n, model_v, model_n, *cam, cur, last_inv, dist_thres, sin_thres, row)) continue;
       ++rown[y];
       int s = 0;
       for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 7; ++j) { float pr = row[i] * row[j]; rowd[y * 27 + s] += (double)pr; rowf[y * 27 + s] += pr; ++s; }   /* :92-105 */
+        for (int j = i; j < 7; ++j) {                                                                     /* :92-105 */
+          float pr = row[i] * row[j]; rowd[y * 27 + s] += (double)pr;
+          rowf[y * 27 + s] = fused ? fmaf(row[i], row[j], rowf[y * 27 + s]) : rowf[y * 27 + s] + pr; ++s;
+        }
     }
   double accd[27]; float accf[27]; int nvalid = 0;
   for (int k = 0; k < 27; ++k) { accd[k] = 0; accf[k] = 0; }
-  for (int y = 0; y < rows; ++y) { nvalid += rown[y]; for (int k = 0; k < 27; ++k) { accd[k] += rowd[y * 27 + k]; accf[k] += rowf[y * 27 + k]; } }
+  for (int yy = 0; yy < rows; ++yy) { const int y = rev ? rows - 1 - yy : yy; nvalid += rown[y]; for (int k = 0; k < 27; ++k) { accd[k] += rowd[y * 27 + k]; accf[k] += rowf[y * 27 + k]; } }
   free(rowd); free(rowf); free(rown);
   if (out27d) memcpy(out27d, accd, sizeof(accd));
   if (out27f) memcpy(out27f, accf, sizeof(accf));
@@ -539,8 +556,10 @@ void okf_sdf_system(const okf_volume* vol, const float* depth, const okf_cam* ca
   int cols = cam->cols, rows = cam->rows;
   double accd[27]; float accf[27]; int nvalid = 0;
   for (int k = 0; k < 27; ++k) { accd[k] = 0; accf[k] = 0; }
-  for (int y = 0; y < rows; ++y)
-    for (int x = 0; x < cols; ++x) {
+  const bool rev = (g_perturb & 1) != 0, fused = (g_perturb & 4) != 0;      /* tests only: okf_set_perturbation */
+  for (int yy = 0; yy < rows; ++yy)
+    for (int xx = 0; xx < cols; ++xx) {
+      const int y = rev ? rows - 1 - yy : yy, x = rev ? cols - 1 - xx : xx;
       float d = depth[y * cols + x];
       if (d == 0) continue;
       float row[7];
@@ -549,7 +568,7 @@ void okf_sdf_system(const okf_volume* vol, const float* depth, const okf_cam* ca
       ++nvalid;
       int s = 0;
       for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 7; ++j) { float pr = row[i] * row[j]; accd[s] += (double)pr; accf[s] += pr; ++s; }
+        for (int j = i; j < 7; ++j) { float pr = row[i] * row[j]; accd[s] += (double)pr; accf[s] = fused ? fmaf(row[i], row[j], accf[s]) : accf[s] + pr; ++s; }
     }
   if (out27d) memcpy(out27d, accd, sizeof(accd));
   if (out27f) memcpy(out27f, accf, sizeof(accf));

@@ -42,6 +42,7 @@ typedef struct okf_volume {
 typedef struct okf_vertex { float pos[3]; float color[3]; } okf_vertex;
 typedef struct okf_triangle { okf_vertex v[3]; } okf_triangle;
 
+void okf_set_perturbation(int mode);    /* tests only: last-bit perturbations of the tracker's arithmetic (bit 0 reversed sums, 1 exp2f taps, 2 fused accumulation, 3 reciprocal-product solve); 0 = off */
 int  okf_set_threads(int n);            /* OpenMP threads used by the loops below; returns the count in effect */
 
 /* a1  src/HybKinectfu.cpp:63-96 */

@@ -273,3 +273,9 @@ def ref():
         _ref.ref_vol_create.restype = C.c_void_p
         _ref.ref_norm.restype = C.c_float
     return _ref
+
+
+def set_perturbation(mode):
+    """Tests only (tests/test_tracking_floor.py): last-bit perturbations of the oracle's tracker arithmetic -- bit 0 reversed
+    summation order of the 27 ICP sums, bit 1 exp2f bilateral taps, bit 2 fused accumulation.  0 restores the restatement proper."""
+    lib().okf_set_perturbation(C.c_int(int(mode)))

@@ -1,5 +1,6 @@
 """GPU: the C++ host classes (HybKinectfu / CameraPoseFinderICP / CameraPoseFinderSDF / MeshGeneratorMarchingcube) run a
 short sequence end to end; poses are compared with the CPU oracle running the same per-frame path."""
+import json
 import os
 
 import numpy as np
@@ -45,6 +46,11 @@ def test_hybkinectfu_icp_sequence(host_loop):
     trunc = 5 * size / res
     n = 5
     o_poses, o_tracked, ovol = oracle_sequence(res, size, cam, trunc, n)
+    floor = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "floor_h128.npz"))
+    meta = json.loads(str(floor["meta"]))
+    assert meta["res"] == res and meta["size"] == size and abs(meta["kw"]["sdf_trunc"] - trunc) < 1e-9      # the fixture is this configuration
+    assert np.array_equal(np.stack(o_poses).astype(np.float32).view(np.uint32), floor["poses"][:n].view(np.uint32))
+    floor_t, floor_r = meta["floor_dt_m"], meta["floor_dr"]
     app = H.App(res, size, cam, host_loop=host_loop, sdf_trunc=trunc, max_triangles=600000)
     for k in range(n):
         mm = S.render_depth_mm(S.trajectory_pose(k, size), cam, size)
@@ -52,13 +58,12 @@ def test_hybkinectfu_icp_sequence(host_loop):
         tracked, pose = app.pose()
         assert ok == o_tracked[k] == True
         gt = S.trajectory_pose(k, size)
-        # End to end the two sides do NOT see identical tracker inputs (device __expf in the bilateral filter, a volume fused
-        # with last-bit-different poses), and the reference solves its 6x6 normal equations in fp32 in WORLD coordinates
-        # (condition number ~1e6 on this scene), so last-bit input differences move the weakly constrained direction by
-        # up to ~1 mm on either implementation.  The 1e-4 m / 1e-4 rad bar is asserted where it is meaningful -- identical
-        # tracker inputs -- in test_gpu_parity.py::test_icp_system_and_track.  Here: same verdicts, both near the truth.
-        assert np.max(np.abs(pose[:3, 3] - o_poses[k][:3, 3])) < 2e-3, (k, pose, o_poses[k])
-        assert np.max(np.abs(pose[:3, :3] - o_poses[k][:3, :3])) < 2e-3
+        # End to end the two sides do not see identical tracker inputs (device __expf in the bilateral filter, another summation
+        # order, a volume fused with last-bit-different poses).  How much that may move the pose is MEASURED: the oracle against
+        # last-bit-perturbed copies of itself on exactly this configuration (tests/golden/floor_h128.npz, tests/tracking_floor.py;
+        # a few micrometres) -- the host classes must stay within twice that floor (round 2 allowed 2e-3 here).
+        assert np.max(np.abs(pose[:3, 3] - o_poses[k][:3, 3])) <= 2 * floor_t, (k, pose, o_poses[k])
+        assert np.max(np.abs(pose[:3, :3] - o_poses[k][:3, :3])) <= 2 * floor_r
         assert np.max(np.abs(pose[:3, 3] - gt[:3, 3])) < 6e-3
     ntri = app.generate_mesh()
     otris = O.marching_cubes(ovol, False, 300 * size / res, 600000)
@@ -78,13 +83,17 @@ def test_hybkinectfu_sdf_tracker_sequence():
     trunc = 5 * size / res
     n = 4
     o_poses, o_tracked, _ = oracle_sequence(res, size, cam, trunc, n, sdf=True)
+    floor = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "floor_sdf128.npz"))
+    meta = json.loads(str(floor["meta"]))                     # oracle vs last-bit-perturbed oracle, this configuration and tracker
+    assert meta["res"] == res and meta["kw"]["sdf_tracker"] and np.array_equal(np.stack(o_poses).astype(np.float32).view(np.uint32), floor["poses"][:n].view(np.uint32))
     app = H.App(res, size, cam, sdf_tracker=True, sdf_trunc=trunc)
     for k in range(n):
         ok = app.process_frame(S.render_depth_mm(S.trajectory_pose(k, size), cam, size), k)
         tracked, pose = app.pose()
         assert ok == o_tracked[k]
         if ok:
-            assert np.max(np.abs(pose - o_poses[k])) < 2e-3, (k, pose, o_poses[k])
+            assert np.max(np.abs(pose[:3, 3] - o_poses[k][:3, 3])) <= 2 * meta["floor_dt_m"], (k, pose, o_poses[k])
+            assert np.max(np.abs(pose[:3, :3] - o_poses[k][:3, :3])) <= 2 * meta["floor_dr"]
     app.close()
 
 

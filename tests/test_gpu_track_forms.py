@@ -1,0 +1,124 @@
+"""GPU: every launch form of the device ICP against the oracle's CameraPoseFinderICP loop (src/CameraPoseFinderICP.cpp:50-145).
+
+kf_icp_track runs either ONE persistent launch (k_icp_loop) or one launch per Gauss-Newton step (k_icp_step + k_track_finish): the
+latter whenever the image needs more workgroups than the chip holds at once (1280x960, BASELINE config C5), a second context lives
+on the device, the GPU is shared with another process, or after a stall.  Both forms deal the pixels, reduce and fold in the same
+order, so they must agree BITWISE; each is compared with the oracle at the north star's 1e-4 m / 1e-4 rad on identical maps.
+The pixel-partitioned form (kf_icp_partition_*, the multi-GPU all-reduce of the 27-float system) is compared with the oracle too.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from hybkinectfu_amd import lib as K
+from hybkinectfu_amd import scene as S
+from test_gpu_parity import _tracking_case, mid_cam, ragged_cam
+
+pytestmark = pytest.mark.gpu
+P = S.STOCK
+ICP = (P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+
+
+def _oracle_pose(maps, ocam, pose, levels=3, icp=ICP):
+    v, n, ov, on, _ = maps
+    return O.icp_estimate(O.pyramid(v, levels), O.pyramid(n, levels, True), O.pyramid(ov, levels), O.pyramid(on, levels, True), ocam, *icp, pose)
+
+
+def _track(ctx, pose, icp=ICP):
+    ctx.set_pose(pose)
+    ctx.icp_track(1, *icp)
+    ok, p, status, iters = ctx.track_result()
+    return ok, p, status, iters, ctx.last_form, ctx.read_solver_params()
+
+
+@pytest.mark.parametrize("res,cam", [(128, S.vga_camera()), (64, mid_cam()), (96, ragged_cam())])
+def test_persistent_loop_and_per_step_launches_agree_bitwise(res, cam):
+    size, trunc = 3.0, 5 * 3.0 / res
+    ctx, ovol, pose, nxt, ocam, maps = _tracking_case(res, size, cam, trunc)
+    ok_o, pose_o = _oracle_pose(maps, ocam, pose)
+    ok1, p1, st1, it1, form1, sums1 = _track(ctx, pose)
+    assert form1 == 1                                        # alone on the device: the persistent loop
+    other = K.Context(K.camera(*mid_cam()), 32, 3.0, levels=3)      # a second live context: co-residency is no longer guaranteed
+    ok2, p2, st2, it2, form2, sums2 = _track(ctx, pose)
+    other.close()
+    assert form2 == 2                                        # one launch per step
+    assert ok1 and ok2 and ok_o and st1 == st2 == 0 and it1 == it2 == 19
+    assert np.array_equal(p1.view(np.uint32), p2.view(np.uint32))            # same pose bits
+    assert np.array_equal(sums1.view(np.uint32), sums2.view(np.uint32))      # same final 27 sums
+    for p in (p1, p2):
+        assert np.max(np.abs(p[:3, 3] - pose_o[:3, 3])) < 1e-4 and np.max(np.abs(p[:3, :3] - pose_o[:3, :3])) < 1e-4
+    ok3, p3, _, _, form3, _ = _track(ctx, pose)              # alone again: back on the loop, same bits
+    assert form3 == 1 and np.array_equal(p3.view(np.uint32), p1.view(np.uint32))
+    ctx.close()
+
+
+def test_per_step_form_at_1280x960_against_the_oracle():
+    """BASELINE config C5's image: 800 workgroups at level 0 do not fit the chip at once -> one launch per step."""
+    cam, res, size = S.vga_camera(2), 128, 3.0
+    trunc = 5 * size / res
+    ctx, ovol, pose, nxt, ocam, maps = _tracking_case(res, size, cam, trunc)
+    ok_o, pose_o = _oracle_pose(maps, ocam, pose)
+    ok, p, status, iters, form, _ = _track(ctx, pose)
+    assert form == 2 and ok and ok_o and status == 0 and iters == 19
+    assert np.max(np.abs(p[:3, 3] - pose_o[:3, 3])) < 1e-4 and np.max(np.abs(p[:3, :3] - pose_o[:3, :3])) < 1e-4
+    assert np.linalg.norm(p[:3, 3] - nxt[:3, 3]) < np.linalg.norm(pose[:3, 3] - nxt[:3, 3]) + 1e-3
+    # lost verdict through the same form: shake threshold 0 rejects the first step, pose unchanged
+    ok_l, p_l, st_l, it_l, form_l, _ = _track(ctx, pose, (ICP[0], ICP[1], 0.0, 0.0))
+    assert form_l == 2 and not ok_l and st_l == 2 and it_l == 0 and np.array_equal(p_l, pose)
+    ctx.close()
+
+
+@pytest.mark.parametrize("parts", [2, 3])
+def test_pixel_partitioned_icp_against_the_oracle(parts):
+    """--icp-mode allreduce: `parts` contexts play the ranks on identical maps, the 27-float systems are added per step (the
+    all-reduce) and every rank applies the sum: pose within 1e-4 of the oracle, verdict and iteration count equal, ranks bitwise equal."""
+    import torch
+    cam, res, size = S.vga_camera(), 128, 3.0
+    trunc = 5 * size / res
+    ctx, ovol, pose, nxt, ocam, maps = _tracking_case(res, size, cam, trunc)
+    v, n, ov, on, _ = maps
+    ok_o, pose_o = _oracle_pose(maps, ocam, pose)
+    ranks = [ctx] + [K.Context(K.camera(*cam), 32, size, levels=3) for _ in range(parts - 1)]
+    for c in ranks:
+        c.upload_map(K.MAP_NEW_VERTICES, 0, v); c.upload_map(K.MAP_NEW_NORMALS, 0, n)
+        c.upload_map(K.MAP_MODEL_VERTICES, 0, ov); c.upload_map(K.MAP_MODEL_NORMALS, 0, on)
+        c.set_pose(pose)
+    lib = K.load()
+    icp = K.IcpParams(3, P["icp_thre_sin_angle"], P["icp_thre_dist"], P["camera_shake_dist"], P["camera_shake_angle"])
+    sums = [torch.zeros(32, dtype=torch.float32, device="cuda") for _ in ranks]
+    for c in ranks:
+        assert lib.kf_icp_partition_begin(c.h, 1) == 0
+    for step in range(lib.kf_icp_partition_steps(ctx.h)):
+        for r, c in enumerate(ranks):
+            assert lib.kf_icp_partition_step(c.h, step, C.byref(icp), C.byref(c.cam), r, parts, C.c_void_p(sums[r].data_ptr())) == 0
+            c.sync()
+        total = sums[0].clone()
+        for s_ in sums[1:]:
+            total += s_                                       # rank order, as a ring all-reduce of three would fix it
+        for s_ in sums:
+            s_.copy_(total)
+        torch.cuda.synchronize()
+    for r, c in enumerate(ranks):
+        assert lib.kf_icp_partition_finish(c.h, C.byref(icp), C.c_void_p(sums[r].data_ptr())) == 0
+    res_r = [c.track_result() for c in ranks]
+    assert ok_o and all(r[0] and r[2] == 0 and r[3] == 19 for r in res_r)
+    for r in res_r[1:]:
+        assert np.array_equal(r[1].view(np.uint32), res_r[0][1].view(np.uint32))
+    p = res_r[0][1]
+    assert np.max(np.abs(p[:3, 3] - pose_o[:3, 3])) < 1e-4 and np.max(np.abs(p[:3, :3] - pose_o[:3, :3])) < 1e-4
+    for c in ranks:
+        c.close()
+
+
+@pytest.mark.parametrize("icp", [(-0.1, ICP[1], ICP[2], ICP[3]), (ICP[0], -0.1, ICP[2], ICP[3]), (ICP[0], ICP[1], -0.3, ICP[3]), (ICP[0], ICP[1], ICP[2], -0.3)])
+def test_negative_thresholds_reject_like_the_reference(icp):
+    """`norm > negative` holds for every pixel / every increment in the reference (CalPointToPlaneErrSolverParams.cu:52,
+    CameraPoseFinderICP.cpp:101-107): no correspondence survives (singular system) resp. every step counts as camera shake."""
+    ctx, ovol, pose, nxt, ocam, maps = _tracking_case(64, 3.0, mid_cam(), 5 * 3.0 / 64)
+    ok_o, _ = _oracle_pose(maps, ocam, pose, icp=icp)
+    ok, p, status, iters, form, _ = _track(ctx, pose, icp)
+    assert not ok_o and not ok and status in (1, 2) and np.array_equal(p, pose)
+    assert status == (1 if (icp[0] < 0 or icp[1] < 0) else 2)
+    ctx.close()
