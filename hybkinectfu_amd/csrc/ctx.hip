@@ -199,7 +199,7 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
   v.nm = (v.res + KF_MACRO - 1) / KF_MACRO;
   TRY(dev_alloc(&v.macro, (size_t)v.nm * v.nm * v.nm + 4));   // read as 32-bit words by the raycast's LDS copy
   TRY(dev_alloc(&v.negbits, kf_negbit_words(c->n_stored_bricks)));
-  TRY(dev_alloc(&c->active_bricks, c->n_stored_bricks));
+  TRY(dev_alloc(&c->active_bricks, c->n_stored_bricks + 8));       // + 16 aligned spare bytes behind the queue (integrate.hip: queue_pad; +8 words keeps them aligned for any count)
   {                                                          // tile maxima over 8- and 16-pixel tiles, see integrate.hip
     size_t n = 0;
     for (int l = 0; l < 2; ++l) n += (size_t)kf_div_up(c->cols, 8 << l) * kf_div_up(c->rows, 8 << l);

@@ -27,6 +27,7 @@ struct IntegrateArgs {
   int tile_off[2], tile_w[2], tile_h[2];   // offset / width / height of each level's table inside tile_max
   int fine_tiles;                // 1: bricks are small on screen, the cull reads the 8-pixel table where the footprint allows
   unsigned* queue;               // active brick slots
+  const unsigned* queue_pad;     // 16 aligned bytes nobody writes during the fusion pass (what non-updating lanes load)
   KfCounters* cnt;
   const KfTrackState* track;     // non-null: integrate only when track->tracked
   float sdf_trunc, max_dist;
@@ -36,6 +37,7 @@ struct IntegrateArgs {
   int parity;                    // which of the double-buffered counter sets (KfCounters) this call uses
   int clear_tiles, n_tile_floats;   // the fusion pass clears the tile tables (maxima to 0, minima to +inf) once the cull has read them
   int sat_cull;                  // the saturation bits are in use (k_integrate_pairs<.., SAT>): the cull may retire whole saturated bricks
+  int free_ok;                   // sdf_trunc > 0 (and the shortcut not disabled): free-space waves skip the quotients (k_integrate_pairs)
 };
 
 // Retire the OTHER parity's counters (nobody touches them during this launch) and clear the tile tables for the next frame's fused
@@ -423,17 +425,55 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   unsigned upd_total = 0;
   if (threadIdx.x == 0) s_upd = 0;
   __syncthreads();
+  // The queue entries of an iteration are requested one iteration ahead.  On gfx9-family hardware loads and stores share one in-order
+  // counter (vmcnt): a queue load issued AFTER the previous iteration's voxel stores can only be waited for together with them, which
+  // puts the stores' completion on the chain queue -> projection -> depth gather -> voxel load of every iteration.  Requested before
+  // the stores, the entries are older than them and the next iteration starts projecting while its predecessor's stores drain.
+  // The loads are made to look lane-varying (kf_opaque) on purpose: for a wave-uniform load the compiler moves the result into a scalar
+  // register with v_readfirstlane right behind the load, i.e. waits for it on the spot -- which serialised the queue and flag loads of
+  // the BR bricks into 2 x BR dependent round trips at the top of every iteration.  Here they all go out together and are made
+  // scalar (readfirstlane) only where they are used.
+#ifndef KF_INT_NO_QPREFETCH
+  unsigned ahead[BR];
+#pragma unroll
+  for (int b = 0; b < BR; ++b) { const unsigned i = kf_opaque(blockIdx.x * BR + b); ahead[b] = (i < n_active) ? a.queue[i] : 0u; }
+#endif
   for (unsigned q0 = blockIdx.x * BR; q0 < n_active; q0 += gridDim.x * BR) {
     unsigned slot[BR], fold[BR]; int bx[BR], by[BR], bz[BR];
     kf_f2 pfz[BR], d[BR]; int pix0[BR], pix1[BR]; bool ok0[BR], ok1[BR];
+#ifndef KF_INT_NO_QPREFETCH
+    unsigned entry[BR];
+#pragma unroll
+    for (int b = 0; b < BR; ++b) entry[b] = (unsigned)__builtin_amdgcn_readfirstlane((int)ahead[b]);
+    {
+      const unsigned qn = q0 + gridDim.x * BR;
+#pragma unroll
+      for (int b = 0; b < BR; ++b) { const unsigned i = kf_opaque(qn + b); ahead[b] = (i < n_active) ? a.queue[i] : 0u; }
+    }
+#endif
+    // the bricks' flag bytes (the atomics below are only issued when a bit is new; SAT reads the saturation bits): requested together
+    unsigned fold_v[BR];
+#pragma unroll
+    for (int b = 0; b < BR; ++b) {
+#ifndef KF_INT_NO_QPREFETCH
+      const unsigned packed = entry[b];
+#else
+      const unsigned packed = (q0 + b < n_active) ? a.queue[q0 + b] : 0u;
+#endif
+      const unsigned sl = ((packed >> 20) * (unsigned)v.nb + ((packed >> 10) & 1023u)) * (unsigned)v.nb + (packed & 1023u);
+      fold_v[b] = v.flags[kf_opaque(sl)];
+    }
     // Phase A: project both voxels (tsdfVolume.h:38-49 voxel centre; Mat.h:230-238 row * vector summed left to right)
 #pragma unroll
     for (int b = 0; b < BR; ++b) {
       const bool live = q0 + b < n_active;
+#ifndef KF_INT_NO_QPREFETCH
+      const unsigned packed = entry[b];
+#else
       const unsigned packed = live ? a.queue[q0 + b] : 0u;
+#endif
       bx[b] = (int)(packed & 1023u); by[b] = (int)((packed >> 10) & 1023u); bz[b] = (int)(packed >> 20) + v.bz0;
       slot[b] = ((unsigned)(bz[b] - v.bz0) * (unsigned)v.nb + (unsigned)by[b]) * (unsigned)v.nb + (unsigned)bx[b];
-      fold[b] = v.flags[slot[b]];                           // current flags: the atomic below is only issued when a bit is new
       const float x0 = (float)(bx[b] * 8 + lx);
       kf_f2 xi = {x0, x0 + 1.0f};                           // (float)(x + 1) == (float)x + 1 for these small integers
       const kf_f2 wx = (xi + f2_splat(0.5f)) * f2_splat(cell);
@@ -465,45 +505,64 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
       upd0[b] = ok0[b] && d[b].x != 0.f && d[b].x < a.max_dist && sdf[b].x > -a.sdf_trunc;
       upd1[b] = ok1[b] && d[b].y != 0.f && d[b].y < a.max_dist && sdf[b].y > -a.sdf_trunc;
     }
-    // SAT: the observed tsdf first (it does not need the voxel); a wave whose quarter is saturated free space and whose updating
-    // voxels all observe tsdf 1 again skips the memory side altogether (wave-uniform)
-    kf_f2 tsdf_obs[BR]; bool skip[BR];
+    // Free space, decided per wave before the voxels are even requested: when no updating voxel of the wave lies inside the truncation
+    // band (sdf >= trunc for all of them) every one observes tsdf = fminf(1, sdf / trunc) = 1 EXACTLY -- x >= t > 0 implies RN(x / t) >= 1
+    // because rounding is monotone -- so the quotient is never formed (FREE; a non-positive or NaN truncation distance turns this off).
+    // SAT: a wave whose quarter is saturated free space and which observes free space again skips the memory side altogether.
+    bool free_wave[BR], skip[BR];
+#pragma unroll
+    for (int b = 0; b < BR; ++b) fold[b] = (unsigned)__builtin_amdgcn_readfirstlane((int)fold_v[b]);
 #pragma unroll
     for (int b = 0; b < BR; ++b) {
-      skip[b] = false;
-      if (SAT) {
-        tsdf_obs[b] = kf_div2(sdf[b], rtrunc);
-        tsdf_obs[b].x = fminf(1.0f, tsdf_obs[b].x); tsdf_obs[b].y = fminf(1.0f, tsdf_obs[b].y);
-        const bool changes = (upd0[b] && tsdf_obs[b].x != 1.0f) || (upd1[b] && tsdf_obs[b].y != 1.0f);
-        skip[b] = (fold[b] & satbit) != 0u && __ballot(changes) == 0ull;
-      }
+      const bool band = (upd0[b] && sdf[b].x < a.sdf_trunc) || (upd1[b] && sdf[b].y < a.sdf_trunc);
+      free_wave[b] = a.free_ok && __ballot(band) == 0ull;
+      skip[b] = SAT && (fold[b] & satbit) != 0u && (a.free_ok ? free_wave[b] : __ballot(band) == 0ull && a.sdf_trunc > 0.f);
     }
     // one 16-byte read-modify-write per lane and brick, only where a voxel of the pair passed; the loads go out together
-    float4* p[BR]; float4 q[BR];
+    float4* p[BR]; float4 q[BR]; bool rw[BR];
 #pragma unroll
     for (int b = 0; b < BR; ++b) {
       p[b] = reinterpret_cast<float4*>(v.tw + (size_t)slot[b] * KF_BRICK_VOX) + threadIdx.x;
-      q[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((upd0[b] || upd1[b]) && !skip[b] && KF_EXP_MODE(a) != 2) q[b] = *p[b];
+      // no branch around the load: a lane that updates nothing reads one shared, never-written 16-byte word instead (an L1 hit; its
+      // value is not used) -- with a conditional load the compiler parks a register copy, and with it a wait, behind EACH of the BR
+      // loads, and they no longer travel together
+      const bool touch = upd0[b] || upd1[b];
+      rw[b] = touch && !skip[b];
+      const float4* src = (rw[b] && KF_EXP_MODE(a) != 2) ? p[b] : reinterpret_cast<const float4*>(a.queue_pad);
+      q[b] = *src;
     }
 #pragma unroll
     for (int b = 0; b < BR; ++b) {
       if (SAT && skip[b]) { upd_total += (upd0[b] ? 1u : 0u) + (upd1[b] ? 1u : 0u); continue; }       // uniform: counted, nothing else to do
       // tsdfVolume.h:63-66 on both voxels; a voxel that failed the predicate keeps its stored value
-      kf_f2 tsdf;
-      if (SAT) tsdf = tsdf_obs[b];
-      else { tsdf = kf_div2(sdf[b], rtrunc); tsdf.x = fminf(1.0f, tsdf.x); tsdf.y = fminf(1.0f, tsdf.y); }
       const kf_f2 ot = {q[b].x, q[b].z}, ow = {q[b].y, q[b].w};
       const kf_f2 ow1 = ow + f2_splat(1.f);
-      const kf_f2 nt = kf_div2(ot * ow + tsdf, kf_recip2(ow1));               // `tsdf * 1.f` is the identity, bit for bit
+      // A free-space wave whose updating voxels all hold tsdf 1 already (weight any value in [0, 2^24]): (1 * w + 1) / (w + 1) has the
+      // SAME rounded sum RN(w + 1) above and below the line (1 * w is exact), a finite non-zero number divided by itself: nt = 1
+      // exactly -- neither the reciprocal nor the second quotient is formed, only the weight moves.  Wave-uniform branch.
+      bool unit = false;
+      if (free_wave[b]) {
+        const bool k0 = !upd0[b] || (__float_as_uint(ot.x) == one_f && __float_as_uint(ow.x) <= 0x4B800000u);
+        const bool k1 = !upd1[b] || (__float_as_uint(ot.y) == one_f && __float_as_uint(ow.y) <= 0x4B800000u);
+        unit = __ballot(!(k0 && k1)) == 0ull;
+      }
+      kf_f2 nt = f2_splat(1.0f);
+      if (!unit) {
+        kf_f2 tsdf = f2_splat(1.0f);
+        if (!free_wave[b]) { tsdf = kf_div2(sdf[b], rtrunc); tsdf.x = fminf(1.0f, tsdf.x); tsdf.y = fminf(1.0f, tsdf.y); }
+        nt = kf_div2(ot * ow + tsdf, kf_recip2(ow1));                       // `tsdf * 1.f` is the identity, bit for bit
+      }
       const float nw0 = fminf(ow1.x, v.max_weight), nw1 = fminf(ow1.y, v.max_weight);
       unsigned flags = 0;
       bool lane_sat = false;
-      if (upd0[b] || upd1[b]) {
+      if (rw[b]) {
         float4 r = q[b];
         if (upd0[b]) { r.x = nt.x; r.y = nw0; }
         if (upd1[b]) { r.z = nt.y; r.w = nw1; }
         if (KF_EXP_MODE(a) == 0 || KF_EXP_MODE(a) >= 8 || r.x == 123.456f) *p[b] = r;     // experiments 1 / 2: no store
+      }
+      if (upd0[b] || upd1[b]) {
+        const float4 r = make_float4(upd0[b] ? nt.x : q[b].x, upd0[b] ? nw0 : q[b].y, upd1[b] ? nt.y : q[b].z, upd1[b] ? nw1 : q[b].w);
         upd_total += (upd0[b] ? 1u : 0u) + (upd1[b] ? 1u : 0u);
         flags = KF_FLAG_OBSERVED | (((upd0[b] && nt.x < 0.f) || (upd1[b] && nt.y < 0.f)) ? KF_FLAG_HASNEG : 0u);
         if (SAT) lane_sat = __float_as_uint(r.x) == one_f && __float_as_uint(r.z) == one_f && __float_as_uint(r.y) == sat_w && __float_as_uint(r.w) == sat_w;
@@ -552,7 +611,8 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
 #ifdef KF_EXPERIMENTS
 // experiments 4-7: the memory side of the fusion pass alone -- every queued brick is read and / or written back (16 bytes per
 // lane, all lanes), no arithmetic: what the brick-queue access pattern can reach on this chip (tools/bench_integrate.py).
-// MODE 0: load + store; 1: non-temporal load + store; 2: read only (sum kept alive); 3: write only
+// MODE 0: load + store; 1: non-temporal load + store; 2: read only (sum kept alive); 3: write only; 4: load + store of as many bricks
+// as the queue holds but CONTIGUOUS in memory (slots 0 .. n_active-1): what the scattering of the queue itself costs
 template <int BR, int MODE>
 __global__ void __launch_bounds__(256) k_exp_brick_rmw(IntegrateArgs a) {
   const KfVolume& v = a.vol;
@@ -564,7 +624,7 @@ __global__ void __launch_bounds__(256) k_exp_brick_rmw(IntegrateArgs a) {
 #pragma unroll
     for (int b = 0; b < BR; ++b) {
       const unsigned packed = (q0 + b < n_active) ? a.queue[q0 + b] : a.queue[q0];
-      const unsigned slot = ((packed >> 20) * (unsigned)v.nb + ((packed >> 10) & 1023u)) * (unsigned)v.nb + (packed & 1023u);
+      const unsigned slot = MODE == 4 ? ((q0 + b < n_active) ? q0 + b : q0) : ((packed >> 20) * (unsigned)v.nb + ((packed >> 10) & 1023u)) * (unsigned)v.nb + (packed & 1023u);
       p[b] = reinterpret_cast<float4*>(v.tw + (size_t)slot * KF_BRICK_VOX) + threadIdx.x;
       if (MODE == 1) { typedef float v4 __attribute__((ext_vector_type(4))); const v4 t = __builtin_nontemporal_load(reinterpret_cast<v4*>(p[b])); q[b] = make_float4(t.x, t.y, t.z, t.w); }
       else if (MODE == 3) q[b] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -602,8 +662,11 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   a.vol = c->vol; a.dcam = to_cam(dcam); a.rcam = rcam ? to_cam(rcam) : a.dcam;
   a.depth = c->trunced_depth; a.normals = c->new_n[0]; a.rgb = c->raw_rgb;
   a.tile_max = c->tile_max_depth; a.queue = c->active_bricks; a.cnt = c->counters;
+  a.queue_pad = c->active_bricks + ((c->n_stored_bricks + 3) & ~(size_t)3);     // 16-byte aligned spare words behind the queue (allocated in ctx.hip)
   a.sdf_trunc = ip->sdf_truncation; a.max_dist = ip->max_integrate_dist;
   a.has_color = has_color; a.color_angled = use_angle_weight_color;
+  { static int fs = -1; if (fs < 0) { const char* e = getenv("KF_INTEGRATE_FREESPACE"); fs = e ? atoi(e) : 1; }      // 0: always form the quotients (A/B)
+    a.free_ok = (fs && a.sdf_trunc > 0.f) ? 1 : 0; }
   for (int l = 0, off = 0; l < 2; ++l) {
     a.tile_w[l] = kf_div_up(c->cols, 8 << l); a.tile_h[l] = kf_div_up(c->rows, 8 << l);
     a.tile_off[l] = off; off += a.tile_w[l] * a.tile_h[l];
@@ -660,6 +723,7 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
     else if (a.exp_mode == 5) hipLaunchKernelGGL((k_exp_brick_rmw<4, 1>), dim3(grid), dim3(256), 0, c->stream, a);
     else if (a.exp_mode == 6) hipLaunchKernelGGL((k_exp_brick_rmw<4, 2>), dim3(grid), dim3(256), 0, c->stream, a);
     else if (a.exp_mode == 7) hipLaunchKernelGGL((k_exp_brick_rmw<4, 3>), dim3(grid), dim3(256), 0, c->stream, a);
+    else if (a.exp_mode == 12) hipLaunchKernelGGL((k_exp_brick_rmw<4, 4>), dim3(grid), dim3(256), 0, c->stream, a);
     else
 #endif
     if (pairs) {

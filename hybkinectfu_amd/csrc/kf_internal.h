@@ -221,6 +221,9 @@ __device__ __forceinline__ float3 kf_mat_point3(const float* m, float x, float y
              m[8] * x + m[9] * y + m[10] * z + m[11] * w);
 }
 
+// identity the compiler cannot see through: the value becomes lane-varying as far as it knows (no instruction is emitted)
+__device__ __forceinline__ unsigned kf_opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
+
 // (int) of a double / float the way the reference's CUDA path converts (cvt.rzi.s32): truncation, saturating, NaN -> 0 --
 // which is also what gfx950's v_cvt_i32_f64 / v_cvt_i32_f32 do.  Written out (C++ leaves the out-of-range cast undefined,
 // so the compiler may not be handed it).
