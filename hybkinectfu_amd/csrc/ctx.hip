@@ -384,9 +384,9 @@ extern "C" int kf_upload_map(kf_ctx* c, int id, uint32_t level, const void* src,
   if (!c || !src) return KF_ERR_ARG;
   void* p; size_t bytes; bool rgb;
   int st = map_ptr(c, id, level, &p, &bytes, &rgb);
-  if (id == KF_MAP_TRUNCED_DEPTH) c->trunc_serial++;             // the integrate tile maxima no longer describe this map
   if (st) return st;
   if (src_bytes != bytes) return KF_ERR_ARG;
+  if (id == KF_MAP_TRUNCED_DEPTH) c->trunc_serial++;             // (only once the arguments are known to be good) the integrate tile maxima no longer describe this map
   if (rgb) {
     if (id != KF_MAP_RAW_RGB) return KF_ERR_ARG;
     return kf_upload_rgb(c, (const uint8_t*)src, c->cfg.rgb_camera.cols, c->cfg.rgb_camera.rows);
@@ -481,7 +481,9 @@ extern "C" int kf_download_volume(kf_ctx* c, uint32_t z0, uint32_t z1, float* ts
   return volume_xfer(c, z0, z1, tsdf, weight, color, true);
 }
 extern "C" int kf_upload_volume(kf_ctx* c, uint32_t z0, uint32_t z1, const float* tsdf, const float* weight, const uint8_t* color) {
-  if (c) { ++c->vol_flags_serial; c->fuse_calls = 0; }     // the upload rebuilds the brick flags: some may be cleared
+  if (!c || !tsdf || !weight) return KF_ERR_ARG;
+  if (z0 >= z1 || (int)z0 < c->vol.bz0 * KF_BRICK || (int)z1 > c->vol.bz1 * KF_BRICK) return KF_ERR_ARG;       // volume_xfer's own checks, before any bookkeeping moves
+  ++c->vol_flags_serial; c->fuse_calls = 0;                // the upload rebuilds the brick flags: some may be cleared
   return volume_xfer(c, z0, z1, (float*)tsdf, (float*)weight, (uint8_t*)color, false);
 }
 

@@ -160,7 +160,8 @@ struct kf_ctx {
   unsigned* mc_block_counts; size_t mc_blocks_cap;
   unsigned* mc_list; unsigned* mc_nbr_bits; unsigned* mc_partials;   // extraction scratch, allocated by the first kf_marching_cubes
   unsigned short* mc_codes; unsigned char* mc_surv; unsigned* mc_block_bits; uint2* mc_recs; unsigned* mc_d1_list;   // voxel classes, sieve bits, cell records, brick list (mcubes.hip), same scratch
-  unsigned fuse_calls;           // integrate calls since the volume was last reset or uploaded (saturation can only exist after max_weight of them)
+  unsigned fuse_calls;           // kf_integrate_volume CALLS (lost frames included: an upper bound of the frames fused) since the volume was last reset or
+                                 // uploaded: saturation can only exist after max_weight of them, so the bound errs on the side of checking for it
   unsigned vol_flags_serial, mc_zero_serial;   // bumped when brick flags may have been CLEARED (reset, upload) / the serial the class tables were last zeroed for
   void* host_pinned;                  // small pinned staging buffer (4 KiB); byte KF_PINNED_STALL_WORD: the ICP loop's stall word
   // per-stage hipEvent timers (KF_STAGE_*): bit s of timers_enabled turns stage s on

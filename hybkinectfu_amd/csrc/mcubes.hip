@@ -617,15 +617,24 @@ extern "C" int kf_marching_cubes(kf_ctx* c, int has_color, float thr) {
   const unsigned n_chunks = (a.n_blocks + MC_CHUNK - 1) / MC_CHUNK;
   if (!c->mc_list) {                                       // extraction scratch: allocated by the first extraction, not by every context
     KF_CHECK(hipSetDevice(c->cfg.device));                 // (per 4-KiB brick: 128 B of voxel classes + 64 B of sieve bits + 8 B of row bits)
-    KF_CHECK(hipMalloc((void**)&c->mc_list, (c->mc_blocks_cap + 4) * sizeof(unsigned)));                 // [0] list length, [1] records, [2] overflow; then the block ids
-    KF_CHECK(hipMalloc((void**)&c->mc_nbr_bits, (c->n_stored_bricks / 32 + 4) * sizeof(unsigned)));
-    KF_CHECK(hipMalloc((void**)&c->mc_partials, ((c->mc_blocks_cap + MC_CHUNK - 1) / MC_CHUNK + 1) * sizeof(unsigned)));
-    KF_CHECK(hipMalloc((void**)&c->mc_codes, c->n_stored_bricks * 64 * sizeof(unsigned short)));
-    KF_CHECK(hipMalloc((void**)&c->mc_surv, c->n_stored_bricks * 64));
-    KF_CHECK(hipMalloc((void**)&c->mc_d1_list, c->n_stored_bricks * sizeof(unsigned)));
+    // all or nothing: the pointers are committed to the context only once every allocation has succeeded (at 2048^3 the scratch is
+    // ~3.3 GB next to 68.7 GB of voxels -- a failure must not leave a half-allocated set behind that the next call would trust)
+    const size_t sizes[8] = {(c->mc_blocks_cap + 4) * sizeof(unsigned),                                  // list: [0] length, [1] records, [2] overflow, [3] bricks; then the block ids
+                             (c->n_stored_bricks / 32 + 4) * sizeof(unsigned),                           // neighbourhood bits
+                             ((c->mc_blocks_cap + MC_CHUNK - 1) / MC_CHUNK + 1) * sizeof(unsigned),       // scan partials
+                             c->n_stored_bricks * 64 * sizeof(unsigned short),                            // voxel classes
+                             c->n_stored_bricks * 64,                                                    // sieve survivors
+                             c->n_stored_bricks * sizeof(unsigned),                                      // brick list
+                             (c->mc_blocks_cap / 32 + 2) * sizeof(unsigned),                             // block bits
+                             (size_t)c->max_triangles * sizeof(uint2)};                                  // records: a recorded cell holds >= 1 triangle
+    void* got[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 8; ++i) {
+      const hipError_t e = hipMalloc(&got[i], sizes[i]);
+      if (e != hipSuccess) { for (int j = 0; j < i; ++j) hipFree(got[j]); (void)hipGetLastError(); return (int)e; }
+    }
+    c->mc_list = (unsigned*)got[0]; c->mc_nbr_bits = (unsigned*)got[1]; c->mc_partials = (unsigned*)got[2]; c->mc_codes = (unsigned short*)got[3];
+    c->mc_surv = (unsigned char*)got[4]; c->mc_d1_list = (unsigned*)got[5]; c->mc_block_bits = (unsigned*)got[6]; c->mc_recs = (uint2*)got[7];
     c->mc_zero_serial = c->vol_flags_serial - 1;
-    KF_CHECK(hipMalloc((void**)&c->mc_block_bits, (c->mc_blocks_cap / 32 + 2) * sizeof(unsigned)));
-    KF_CHECK(hipMalloc((void**)&c->mc_recs, (size_t)c->max_triangles * sizeof(uint2)));                  // a recorded cell holds >= 1 triangle
   }
   a.block_counts = c->mc_block_counts; a.tris = c->triangles; a.max_tris = c->max_triangles; a.cnt = c->counters;
   a.count_work = c->count_work;

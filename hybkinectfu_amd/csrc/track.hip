@@ -519,11 +519,16 @@ __device__ __forceinline__ void icp_accumulate(const TrackArgs& a, const float* 
   float4 vg[ICP_PX], ng[ICP_PX], vt[ICP_PX], nt[ICP_PX]; int mi[ICP_PX];
 #pragma unroll
   for (int j = 0; j < ICP_PX; ++j) mi[j] = icp_project(a, s_cur, s_linv, iv[j], in_[j], vg[j], ng[j]);
+  // the model-map gathers of all pixels go out together: no branch around them (a pixel without a correspondence reads entry 0 and
+  // is dropped below) -- behind a conditional load the compiler parks a register copy and with it a wait, and the ICP_PX gathers
+  // became ICP_PX dependent round trips per Gauss-Newton step
+#ifndef KF_ICP_COND_GATHER
 #pragma unroll
-  for (int j = 0; j < ICP_PX; ++j) {
-    nt[j] = make_float4(0.f, 0.f, 0.f, 0.f); vt[j] = nt[j];
-    if (mi[j] >= 0) { nt[j] = model_n[mi[j]]; vt[j] = model_v[mi[j]]; }
-  }
+  for (int j = 0; j < ICP_PX; ++j) { const int g = mi[j] >= 0 ? mi[j] : 0; nt[j] = model_n[g]; vt[j] = model_v[g]; }
+#else
+#pragma unroll
+  for (int j = 0; j < ICP_PX; ++j) { nt[j] = make_float4(0.f, 0.f, 0.f, 0.f); vt[j] = nt[j]; if (mi[j] >= 0) { nt[j] = model_n[mi[j]]; vt[j] = model_v[mi[j]]; } }
+#endif
 #pragma unroll
   for (int j = 0; j < ICP_PX; ++j) {
     float row[7];
@@ -712,6 +717,8 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
 #pragma unroll
     for (int j = 0; j < ICP_PX; ++j) {
       const int i = icp_dealt_pixel(j, grid_l);
+      // (a conditional load on purpose: the branch-free form that helps the per-step gathers in icp_accumulate costs 21 us per frame
+      // here -- measured, profiles/r03_icp_step.txt -- and these loads happen once per pyramid level, not once per step)
       iv[j] = make_float4(0.f, 0.f, 0.f, 0.f); in_[j] = iv[j];
       if (has_px && j < px_l && i < npx) { iv[j] = new_v[i]; in_[j] = new_n[i]; }
     }

@@ -3,7 +3,7 @@
  *
  * TEST INFRASTRUCTURE ONLY.  Built by oracle/Makefile into oracle/_ref/libkfref.so, in this container only,
  * from the headers where they lie under /root/reference/src (nothing is copied into the repo):
- *   cuda/tsdfVolume.h  cuda/Mat.h  cuda/DepthCamera.h  cuda/cuda_declar.h  cuda/DataMap.h  AppParams.h
+ *   cuda/tsdfVolume.h  cuda/Mat.h  cuda/DepthCamera.h  cuda/cuda_declar.h  cuda/DataMap.h  cuda/marchingcube_table.h  AppParams.h
  * The CUDA *headers* they include (cuda_runtime_api.h, vector_functions.h) ship in this image inside the
  * triton wheel; no CUDA runtime library exists here, so the GPU branches of DataMap.h (cudaMalloc/cudaFree,
  * never executed for DeviceKind CPU) are left unresolved at link time (-Wl,--unresolved-symbols=ignore-all).
@@ -17,6 +17,7 @@
 #include "cuda/tsdfVolume.h"
 #include "cuda/Mat.h"
 #include "cuda/DepthCamera.h"
+#include "cuda/marchingcube_table.h"     /* edgeTable :19, triTable :56 -- compiled as they lie; pins csrc/mc_tables.inc and oracle/mc_tables.inc */
 
 namespace {
 struct VolAccess : public tsdfvolume {
@@ -76,6 +77,10 @@ void ref_cross(const float a[3], const float b[3], float out[3]) {
   float3 r = cross(make_float3(a[0], a[1], a[2]), make_float3(b[0], b[1], b[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 float ref_norm(const float v[3]) { return norm(make_float3(v[0], v[1], v[2])); }
+/* the reference's marching-cubes tables, element for element (src/cuda/marchingcube_table.h:19,56) */
+void ref_mc_tables(int edge_out[256], int tri_out[256 * 16]) {
+  for (int c = 0; c < 256; ++c) { edge_out[c] = edgeTable[c]; for (int i = 0; i < 16; ++i) tri_out[c * 16 + i] = triTable[c][i]; }
+}
 unsigned ref_sizeof_voxel() { return (unsigned)sizeof(Voxel); }
 unsigned ref_sizeof_camera_params() { return (unsigned)sizeof(CameraParams); }
 }

@@ -215,3 +215,42 @@ def test_color_interpolation_world_to_voxel_and_norm():
         assert np.float32(r.ref_norm(O.fp(v))).view(np.uint32) == np.float32(O.norm(v)).view(np.uint32)
     assert n_ok > 500
     r.ref_vol_destroy(h)
+
+
+def _unpack_mc_inc(path):
+    """csrc/mc_tables.inc / oracle/mc_tables.inc: 256 64-bit words, nibble i = edge id of triTable[c][i], 0xF = -1 (tools/pack_mc_tables.py)."""
+    import re
+    words = [int(w, 16) for w in re.findall(r"0x([0-9a-fA-F]{16})ull", open(path).read())]
+    assert len(words) == 256
+    tri = np.full((256, 16), -1, np.int32)
+    edge = np.zeros(256, np.int32)
+    for c, w in enumerate(words):
+        for i in range(16):
+            nib = (w >> (4 * i)) & 0xF
+            if nib != 0xF:
+                tri[c, i] = nib
+                edge[c] |= 1 << nib
+    return edge, tri
+
+
+# sha256 of the reference's tables as its own header compiles them (int32 little endian: edgeTable[256], triTable[256][16]), recorded from
+# oracle/_ref/libkfref.so::ref_mc_tables so that the pin also holds where /root/reference is absent (test_mc_tables_hash_without_reference)
+MC_EDGE_SHA256 = "ffc58719f11be7a8b34988740a15dcd043dc314a3e2fe01e917fd796001815b9"
+MC_TRI_SHA256 = "85e6eb7486ad0101a95aaf3b332a15ba6e5d187a24d31c5eb77874d3aa45d996"
+
+
+def test_marching_cubes_tables_equal_the_reference_header():
+    """edgeTable / triTable of src/cuda/marchingcube_table.h:19,56, compiled as they lie, against the packed tables the HIP kernels
+    (hybkinectfu_amd/csrc/mc_tables.inc) and the oracle (oracle/mc_tables.inc) carry: element for element."""
+    import hashlib
+    import os
+    r = O.ref()
+    edge = np.zeros(256, np.int32)
+    tri = np.zeros(256 * 16, np.int32)
+    r.ref_mc_tables(O.fp(edge), O.fp(tri))
+    tri = tri.reshape(256, 16)
+    assert hashlib.sha256(edge.tobytes()).hexdigest() == MC_EDGE_SHA256 and hashlib.sha256(tri.tobytes()).hexdigest() == MC_TRI_SHA256
+    for rel in ("hybkinectfu_amd/csrc/mc_tables.inc", "oracle/mc_tables.inc"):
+        e, t = _unpack_mc_inc(os.path.join(O.ROOT, rel))
+        assert np.array_equal(t, tri), rel
+        assert np.array_equal(e, edge), rel          # the 12-bit edge mask of a case is exactly the set of edges its triangles use
