@@ -9,8 +9,12 @@ already resident in HBM when the timed region starts.  N=1 runs BASELINE.json co
 N>1 runs configs[3] ("C4": 1024^3 @ 6 m, z-slab per GPU, strong scaling) under torch.distributed/RCCL.
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (the TSDF fusion kernel, HBM-bound,
 timed with HIP events on the context's own stream) and `cpu_baseline` (the CPU oracle on a bounded sample, N=1 only).
-The N=1 line also carries `multi_gpu_workload_on_1_gpu`: C4 unpartitioned on this one GPU (50 frames), the same-workload
-reference for the N=2/4/8 lines -- the headline `value` at N=1 is C2, as BASELINE.json's metric states.
+The N=1 line also carries `multi_gpu_workload_on_1_gpu` (C4 unpartitioned on this one GPU, the same-workload reference for the
+N=2/4/8 lines), `other_configs` (C1: 256^3 @ 3 m, C3: 512^3 with the SDF tracker, C5: 2048^3 @ 8 m with 1280x960 depth and mesh
+extraction, a few dozen frames each) and `steady_state`; the headline `value` at N=1 is C2, as BASELINE.json's metric states.
+The N>1 line carries `per_rank` (what every z-slab rank fused and how long its integrate / raycast / merge stages took) and a short
+`c5` block (2048^3 @ 8 m on the same ranks).  `config.env` lists every KF_* variable that was set; `regime` says which side of the
+weight saturation the timed frames ran on.
 """
 import argparse
 import json
@@ -36,6 +40,15 @@ def workload(n_gpus, name="auto"):
     if name == "c2":
         return dict(name="C2", res=512, size=4.0, cam=S.vga_camera(), trunc_max=P["depth_trunc_max"], integ_dist=P["integrate_depth_trunc"],
                     desc="C2: synthetic 640x480 depth stream (Scene S), 512^3 @ 4 m TSDF, 3-level ICP 10/5/4, %dxMI355X" % n_gpus)
+    if name == "c1":
+        # C1: BASELINE.json configs[0] is TUM freiburg1_xyz through DataSourceProducerRGBDDataset; the dataset is not in this image, so the
+        # same geometry (VGA, 256^3 @ 3 m, 3-level ICP) runs on Scene S (the reader itself is covered by tests/test_gpu_configs.py::C1)
+        return dict(name="C1", res=256, size=3.0, cam=S.vga_camera(), trunc_max=P["depth_trunc_max"], integ_dist=P["integrate_depth_trunc"],
+                    desc="C1 geometry: 640x480 depth (Scene S; the TUM freiburg1_xyz files are not in this image), 256^3 @ 3 m TSDF, 3-level ICP, %dxMI355X" % n_gpus)
+    if name == "c3":
+        return dict(name="C3", res=512, size=4.0, cam=S.vga_camera(), trunc_max=P["depth_trunc_max"], integ_dist=P["integrate_depth_trunc"], tracker="sdf",
+                    desc="C3 geometry: 640x480 depth (Scene S; the TUM freiburg3_long_office files are not in this image), 512^3 @ 4 m TSDF, "
+                         "CameraPoseFinderSDF (direct SDF tracking, max %d iterations), %dxMI355X" % (int(P["sdf_max_iter_nums"]), n_gpus))
     if name == "c5":
         # C5: 1280x960 depth, 2048^3 @ 8 m (68.7 GB of voxels: one GPU holds it, N GPUs hold a z-slab each), mesh extraction at the end
         return dict(name="C5", res=2048, size=8.0, cam=S.vga_camera(2), trunc_max=8.0, integ_dist=8.0, extract_mesh=True,
@@ -66,7 +79,9 @@ def cpu_baseline(wl, frames_mm, n_sample=150):
         fl = O.bilateral(tr, P["filter_sigma_pixel"], P["filter_sigma_depth"])
         v = O.depth_to_vertices(fl, ocam)
         n = O.vertices_to_normals(v)
-        if k > 0:
+        if k > 0 and wl.get("tracker") == "sdf":
+            ok, pose, _ = O.sdf_estimate(vol, tr, ocam, P["sdf_max_iter_nums"], P["camera_shake_dist"], P["camera_shake_angle"], pose)
+        elif k > 0:
             ok, pose = O.icp_estimate(O.pyramid(v, 3), O.pyramid(n, 3, True), O.pyramid(mv, 3), O.pyramid(mn, 3, True), ocam,
                                       P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"], pose)
         O.integrate(vol, tr, n, None, False, False, pose, P["integrate_sdf_trunc"], wl["integ_dist"], ocam, ocam)
@@ -76,30 +91,68 @@ def cpu_baseline(wl, frames_mm, n_sample=150):
                 sample="%d frames of the same stream through oracle/libkforacle.so (preprocess+ICP+integrate+raycast), %.1f s" % (n_sample, dt))
 
 
-def single_gpu_reference(name, n_frames=50, warmup=10):
+def env_knobs():
+    """Every KF_* variable set in this process's environment (they select library variants and tuning / diagnostic paths: a line
+    measured with one of them set says so)."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("KF_")}
+
+
+def ping_pong(k, n):
+    """Index into n unique frames of the stream for frame k: 0 .. n-1, n-1 .. 0, ... -- a short cached stretch of the trajectory walked
+    back and forth, so consecutive frames stay neighbours of the camera path (a wrap-around would jump)."""
+    if n <= 1:
+        return 0
+    m = k % (2 * n - 2)
+    return m if m < n else 2 * n - 2 - m
+
+
+def single_gpu_reference(name, n_frames=50, warmup=10, n_unique=None, overrides=None):
     """Frames/s of workload `name` on ONE GPU without partitioning: the same-workload reference point of the multi-GPU series
-    (BASELINE.json's metric quotes 1024^3 for 1/2/4/8 GPUs, while the N=1 headline line is the 512^3 configuration)."""
+    (BASELINE.json's metric quotes 1024^3 for 1/2/4/8 GPUs, while the N=1 headline line is the 512^3 configuration), and the
+    other BASELINE configurations next to the headline (`other_configs`)."""
     import torch
     from hybkinectfu_amd.pipeline import SingleGpuPipeline
-    wl = workload(1, name)
+    wl = dict(workload(1, name))
+    wl.update(overrides or {})
     cam = wl["cam"]
-    frames, _ = S.make_stream(n_frames, cam, wl["size"])
+    n_unique = min(n_frames, 100) if n_unique is None else n_unique
+    frames, _ = S.make_stream(n_unique, cam, wl["size"])
     dev = torch.from_numpy(frames.astype(np.int16)).cuda()
     fb = cam[0] * cam[1] * 2
-    pipe = SingleGpuPipeline(K.camera(*cam), wl["res"], wl["size"], wl, device=torch.cuda.current_device())
+    at = (lambda k: k % n_unique) if n_unique >= min(n_frames, 100) else (lambda k: ping_pong(k, n_unique))
+    pipe = SingleGpuPipeline(K.camera(*cam), wl["res"], wl["size"], wl, device=torch.cuda.current_device(),
+                             max_triangles=(16_000_000 if wl.get("extract_mesh") else 0))
+    if wl.get("color"):
+        pipe.ctx.upload_rgb(np.random.default_rng(1).integers(0, 256, (cam[1], cam[0], 3)).astype(np.uint8))
     for k in range(warmup):
-        pipe.process_frame_device(dev.data_ptr() + k * fb, k)
+        pipe.process_frame_device(dev.data_ptr() + at(k) * fb, k)
     pipe.sync(); torch.cuda.synchronize()
     s0 = pipe.stats()
+    pipe.stage_timers((1 << 2) | (1 << 3) | (1 << 4) | (1 << 5) | (4 << 8))
     t0 = time.perf_counter()
     for k in range(warmup, n_frames):
-        pipe.process_frame_device(dev.data_ptr() + k * fb, k)
+        pipe.process_frame_device(dev.data_ptr() + at(k) * fb, k)
     pipe.sync(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    lost = pipe.stats()["frames_lost"] - s0["frames_lost"]
+    ms, cnt = pipe.read_stage_ms()
+    s1 = pipe.stats()
+    lost = s1["frames_lost"] - s0["frames_lost"]
+    out = dict(workload=wl["desc"], value=round((n_frames - warmup) / dt, 2), unit="frames/s", steps=n_frames - warmup,
+               ms_per_step=round(1000.0 * dt / (n_frames - warmup), 4), frames_lost=int(lost),
+               n_upd_per_frame=int((s1["updated_total"] - s0["updated_total"]) / max(n_frames - warmup, 1)),
+               stage_us={STAGE_NAMES[i]: round(1000.0 * float(ms[i]) / max(int(cnt[i]), 1), 2) for i in (2, 3, 4, 5)})
+    if wl.get("extract_mesh"):
+        import ctypes as C
+        pipe.ctx.marching_cubes(300.0 * wl["size"] / wl["res"])        # first call allocates the extraction's scratch
+        pipe.ctx.clear_triangles(); pipe.sync()
+        t0m = time.perf_counter()
+        pipe.ctx.marching_cubes(300.0 * wl["size"] / wl["res"])
+        n_tri = C.c_uint32()
+        K._chk(pipe.ctx.lib.kf_triangle_count(pipe.ctx.h, C.byref(n_tri)), "kf_triangle_count")
+        out["mesh_extraction"] = dict(triangles=int(n_tri.value), ms=round(1000.0 * (time.perf_counter() - t0m), 3),
+                                      note="second kf_marching_cubes call (the first allocates its scratch), wall time incl. the count read-back")
     pipe.close()
-    return dict(workload=wl["desc"], value=round((n_frames - warmup) / dt, 2), unit="frames/s", steps=n_frames - warmup,
-                ms_per_step=round(1000.0 * dt / (n_frames - warmup), 4), frames_lost=int(lost))
+    return out
 
 
 def steady_state(name, n_timed=100):
@@ -132,12 +185,26 @@ def steady_state(name, n_timed=100):
     n_upd = (s1["updated_total"] - s0["updated_total"]) / n_timed
     alg = n_upd * 16.0 + cam[0] * cam[1] * 4.0
     k_ms = float(ms[5]) / max(int(cnt[5]), 1)
-    return dict(workload=wl["desc"], frames_fused_before=n_pre, steps=n_timed, value=round(n_timed / dt, 2), unit="frames/s",
-                frames_lost=int(s1["frames_lost"] - s0["frames_lost"]), kernel="k_integrate_pairs<.., SAT>", kernel_ms=round(k_ms, 5),
-                launches_timed=int(cnt[5]), reference_bytes_per_launch=int(alg),
-                reference_bytes_rate=round(alg / (k_ms * 1e-3) / 1e9, 2) if k_ms > 0 else None, unit_rate="GB/s",
-                frac_of_hbm_peak=round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
-                note="bytes the REFERENCE's update moves for these frames / kernel time; the kernel itself moves fewer: saturated free space is counted, not touched")
+    out = dict(workload=wl["desc"], frames_fused_before=n_pre, steps=n_timed, value=round(n_timed / dt, 2), unit="frames/s",
+               frames_lost=int(s1["frames_lost"] - s0["frames_lost"]), kernel="k_integrate_pairs<.., SAT>", kernel_ms=round(k_ms, 5),
+               launches_timed=int(cnt[5]), reference_bytes_per_launch=int(alg),
+               reference_bytes_rate=round(alg / (k_ms * 1e-3) / 1e9, 2) if k_ms > 0 else None, unit_rate="GB/s",
+               reference_bytes_rate_over_peak=round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
+               note="reference_bytes = what the REFERENCE's update moves for these frames (N_upd x 16 B + the depth image); the kernel itself moves fewer -- "
+                    "saturated free space is counted, not touched -- so reference_bytes_rate is NOT an HBM rate and may exceed the 8 TB/s peak; "
+                    "kernel_traffic_* is what the kernel really moves")
+    # what the SAT kernel really moves per launch: rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, separate passes) from the builder's own profile run
+    tpath = os.path.join(ROOT, "profiles", "integrate_traffic.json")
+    try:
+        tj = json.load(open(tpath))
+        tr = tj.get(wl["name"] + "_sat")
+    except Exception:
+        tj, tr = {}, None
+    out["kernel_traffic_bytes_per_launch"] = tr
+    out["kernel_traffic_rate"] = round(tr / (k_ms * 1e-3) / 1e9, 2) if (tr and k_ms > 0) else None
+    out["kernel_traffic_frac_of_hbm_peak"] = round(tr / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (tr and k_ms > 0) else None
+    out["kernel_traffic_source"] = tj.get("source_sat") if tr else None
+    return out
 
 
 def stage_block(alg_bytes, stage_ms, how):
@@ -266,6 +333,87 @@ def roofline_extra(pipe, run, first_frame, res, size, n_frames=20):
     return out
 
 
+def per_rank_leg(pipe, run, barrier, dist, world, rank, first, n_frames):
+    """z-slab runs: what every rank did over n_frames extra frames (outside the timed region) -- voxels fused, bricks queued, and the
+    device time of its stages (HIP events) plus the merge (torch events around both all-reduces, pack, unpack; the next frame's
+    preprocess is enqueued inside it while the first all-reduce is in flight).  Slabs are not equally busy: this makes it visible."""
+    import torch
+    pipe.stage_timers((1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 5))
+    pipe.time_merge(True)
+    s0 = pipe.stats()
+    run(first, n_frames)
+    barrier()
+    ms, cnt = pipe.read_stage_ms()
+    merge_ms, merge_n = pipe.read_merge_ms()
+    pipe.time_merge(False)
+    pipe.stage_timers(0)
+    s1 = pipe.stats()
+    us = lambda i: 1000.0 * float(ms[i]) / max(int(cnt[i]), 1)
+    mine = torch.tensor([float(rank), (s1["updated_total"] - s0["updated_total"]) / float(n_frames), float(s1["bricks_active"]), us(1), us(2), us(3), us(5), us(4),
+                         1000.0 * merge_ms / max(merge_n, 1), float(s1["frames_lost"] - s0["frames_lost"]), float(pipe.slab[0]), float(pipe.slab[1])],
+                        device="cuda", dtype=torch.float64)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    keys = ["rank", "n_upd_per_frame", "bricks_queued_last_frame", "preprocess_us", "track_us", "integrate_us", "integrate_kernel_us", "raycast_us", "merge_us",
+            "frames_lost", "z_begin", "z_end"]
+    rows = [{k: (int(v) if k in ("rank", "n_upd_per_frame", "bricks_queued_last_frame", "frames_lost", "z_begin", "z_end") else round(float(v), 2))
+             for k, v in zip(keys, e.tolist())} for e in every]
+    return dict(frames=n_frames, ranks=rows,
+                note="device time per frame and rank (HIP events; merge: torch events around MIN all-reduce + pack + integer SUM all-reduce + unpack, "
+                     "with the next frame's preprocess enqueued behind the first all-reduce)")
+
+
+def slab_block(name, args, world, rank, device, dist, n_frames, warmup, n_unique):
+    """A short run of workload `name` on the z-slab pipeline of THIS process group (the N > 1 line's C5 block): frames/s over
+    n_frames - warmup frames, per-rank statistics, lock-step check, and the mesh extraction of every rank's slab."""
+    import ctypes as C
+    import torch
+    from hybkinectfu_amd.pipeline import SlabPipeline
+    wl = workload(world, name)
+    cam, res, size = wl["cam"], wl["res"], wl["size"]
+    frames, _ = S.make_stream(n_unique, cam, size)
+    dev_frames = torch.from_numpy(frames.astype(np.int16)).cuda()
+    fb = cam[0] * cam[1] * 2
+    pipe = SlabPipeline(K.camera(*cam), res, size, wl, rank=rank, world=world, device=device, icp_mode=args.icp_mode, tracker=args.tracker,
+                        max_triangles=(16_000_000 // world + 1_000_000 if wl.get("extract_mesh") else 0))
+
+    def run(first, count):
+        for k in range(first, first + count):
+            pipe.process_frame_device(dev_frames.data_ptr() + ping_pong(k, n_unique) * fb, k, dev_frames.data_ptr() + ping_pong(k + 1, n_unique) * fb)
+
+    def barrier():
+        pipe.sync(); torch.cuda.synchronize(); dist.barrier()
+
+    run(0, warmup)
+    barrier()
+    s0 = pipe.stats()
+    t0 = time.perf_counter()
+    run(warmup, n_frames - warmup)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    lost = pipe.stats()["frames_lost"] - s0["frames_lost"]
+    out = dict(workload=wl["desc"], value=round((n_frames - warmup) / dt, 2), unit="frames/s", steps=n_frames - warmup, warmup=warmup,
+               ms_per_step=round(1000.0 * dt / (n_frames - warmup), 4), frames_lost=int(lost), halo_layers=int(pipe.halo),
+               unique_frames=n_unique, per_rank=per_rank_leg(pipe, run, barrier, dist, world, rank, n_frames, 10))
+    out["lockstep"] = pipe.verify_lockstep()
+    if wl.get("extract_mesh"):
+        barrier()
+        t0m = time.perf_counter()
+        pipe.ctx.marching_cubes(300.0 * size / res)
+        n_tri = C.c_uint32()
+        K._chk(pipe.ctx.lib.kf_triangle_count(pipe.ctx.h, C.byref(n_tri)), "kf_triangle_count")
+        barrier()
+        tt = torch.tensor([float(n_tri.value)], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        out["mesh_extraction"] = dict(triangles=int(tt.item()), ms=round(1000.0 * (time.perf_counter() - t0m), 3),
+                                      note="kf_marching_cubes on every rank's slab (first call: includes the scratch allocation), wall time incl. the count read-back")
+    pipe.close()
+    return out
+
+
 STAGE_NAMES = ["upload", "preprocess", "track", "integrate", "raycast", "integrate_kernel", "mcubes", "raycast_kernel"]
 
 
@@ -276,7 +424,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs of the N=1 line (per-stage pass, raycast / marching-cubes rooflines, PCIe-inclusive rate)")
-    ap.add_argument("--config", default="auto", choices=["auto", "c2", "c4", "c5"],
+    ap.add_argument("--pre-frames", type=int, default=0,
+                    help="frames fused before the warm-up (e.g. 160 = past max_weight: the timed frames then run the saturation-aware kernels; "
+                         "used to profile that regime -- the default 0 keeps warm-up + steps inside the early regime)")
+    ap.add_argument("--tracker", default="icp", choices=["icp", "sdf"], help="z-slab pipeline only: CameraPoseFinderICP (default) or CameraPoseFinderSDF on slabs")
+    ap.add_argument("--no-c5", action="store_true", help="N > 1: skip the short C5 block (2048^3 @ 8 m, 1280x960) that follows the C4 measurement")
+    ap.add_argument("--config", default="auto", choices=["auto", "c1", "c2", "c3", "c4", "c5"],
                     help="auto: C2 (512^3 @ 4 m) on 1 GPU, C4 (1024^3 @ 6 m, z-slabs) on N > 1, as BASELINE.json's metric states; "
                          "c5: 2048^3 @ 8 m, 1280x960 depth, mesh extraction after the timed frames (BASELINE.json configs[4])")
     ap.add_argument("--icp-mode", default="replicated", choices=["replicated", "allreduce"],
@@ -330,7 +483,7 @@ def main():
     cam, res, size = wl["cam"], wl["res"], wl["size"]
     kcam = K.camera(*cam)
     period = 100
-    n_unique = min(period, args.warmup + args.steps)
+    n_unique = min(period, args.pre_frames + args.warmup + args.steps)
     frames, _ = S.make_stream(n_unique, cam, size)
     dev_frames = torch.from_numpy(frames.astype(np.int16)).cuda()        # u16 bits, resident in HBM
     frame_bytes = cam[0] * cam[1] * 2
@@ -341,7 +494,7 @@ def main():
         pipe = Pipe(kcam, res, size, wl, device=device, max_triangles=(16_000_000 if wl.get("extract_mesh") else 4_000_000 if not args.no_extras else 0))
     else:
         from hybkinectfu_amd.pipeline import SlabPipeline as Pipe
-        pipe = Pipe(kcam, res, size, wl, rank=rank, world=world, device=device, icp_mode=args.icp_mode,
+        pipe = Pipe(kcam, res, size, wl, rank=rank, world=world, device=device, icp_mode=args.icp_mode, tracker=args.tracker,
                     max_triangles=(16_000_000 // world + 1_000_000 if wl.get("extract_mesh") else 0))
 
     def run(first, count):
@@ -357,7 +510,10 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    run(0, args.warmup)
+    base = args.pre_frames
+    if base:
+        run(0, base)
+    run(base, args.warmup)
     barrier()
     s0 = pipe.stats()
     # Time the fusion kernel (bit 5) and the whole integrate stage (bit 3) inside the timed region with HIP events on the context's
@@ -371,7 +527,7 @@ def main():
     pipe.stage_timers((timer_period << 8) | (1 << 5) | (0 if extras_planned else (1 << 3)))
     barrier()
     t0 = time.perf_counter()
-    run(args.warmup, args.steps)
+    run(base + args.warmup, args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -420,7 +576,7 @@ def main():
                         launches_timed=int(launches), rank=roof_rank, algorithmic_bytes_per_launch=int(alg_bytes),
                         n_upd_per_frame=int(n_upd / max(args.steps, 1)),
                         stage=stage_block(alg_bytes, stage_ms, "HIP events over the timed region"))
-        if args.warmup + args.steps > P["volume_max_weight"]:
+        if base + args.warmup + args.steps > P["volume_max_weight"]:
             # frames beyond max_weight run the saturation-aware kernels: `achieved` stays the REFERENCE's bytes over the kernel time
             roofline["note"] = ("timed frames reach past max_weight = %d fused frames: saturated free space is counted but no longer read or "
                                 "written, so the reference's bytes per launch exceed what the kernel moves (DESIGN.md section 4, steady state)" % int(P["volume_max_weight"]))
@@ -447,11 +603,20 @@ def main():
             total = int(tt.item())
         mesh = dict(triangles=total, ms=round(1000.0 * dtm, 3), note="kf_marching_cubes on every rank's slab after the timed frames (wall time incl. the count read-back)")
 
+    n_before = base + args.warmup
+    maxw = int(P["volume_max_weight"])
+    regime = ("pre-saturation" if n_before + args.steps <= maxw else "saturated" if n_before >= maxw else "mixed")
     out = dict(metric="depth frames/sec into TSDF (integrate+ICP+raycast)", value=round(fps, 2), unit="frames/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(1000.0 * dt / args.steps, 4), higher_is_better=True,
                scaling="weak" if world == 1 else "strong", vs_baseline=None, dtype="f32", data="synthetic",
+               regime=dict(name=regime, frames_fused_before_timed=n_before, timed_frames=args.steps, max_weight=maxw,
+                           note="pre-saturation: every timed frame runs before any voxel weight can have reached max_weight (plain fusion kernels); "
+                                "saturated: the saturation-aware kernels run (free space at (tsdf 1, weight max) is counted, not touched); "
+                                "`steady_state` reports that regime separately on the N=1 line"),
                config=dict(workload=wl["desc"], volume="%d^3 @ %g m" % (res, size), image="%dx%d" % (cam[0], cam[1]),
-                           tracker="ICP 10/5/4 (device-resident Gauss-Newton)", frames_lost=int(lost),
+                           tracker=("CameraPoseFinderSDF (max %d iterations, device-resident)" % int(P["sdf_max_iter_nums"])
+                                    if (wl.get("tracker") == "sdf" or (slab and args.tracker == "sdf")) else "ICP 10/5/4 (device-resident Gauss-Newton)"),
+                           frames_lost=int(lost), env=env_knobs(),
                            world_size=(dist.get_world_size() if dist is not None else 1),
                            backend=("none" if dist is None else ("rccl" if args.backend == "nccl" else "gloo (rehearsal: host-staged collectives, ranks may share a GPU)")),
                            partition="none" if not slab else
@@ -460,11 +625,19 @@ def main():
                roofline=roofline)
     if mesh is not None:
         out["mesh_extraction"] = mesh
+    if slab and dist is not None:
+        # z-slab runs: per-rank statistics over 20 extra frames, then the lock-step check (all ranks fused / lost the same frames, same pose bits)
+        out["per_rank"] = per_rank_leg(pipe, run, barrier, dist, world, rank, base + args.warmup + args.steps, 20)
+        out["lockstep"] = pipe.verify_lockstep()
+        if world > 1 and args.config == "auto" and not args.no_c5:
+            # the north star quotes 1024^3 AND 2048^3 for 1/2/4/8 GPUs: a short C5 block (2048^3 @ 8 m, 1280x960 depth, mesh extraction) on the same ranks
+            pipe.close()
+            out["c5"] = slab_block("c5", args, world, rank, device, dist, n_frames=30, warmup=6, n_unique=12)
     extras = world == 1 and not wl.get("extract_mesh") and not args.force_slab and not args.no_extras
     if extras:
         # per-stage device time (HIP events around every stage, 50 extra frames outside the timed region)
         pipe.stage_timers(0x1F | (1 << 5))
-        run(args.warmup + args.steps, 50)
+        run(base + args.warmup + args.steps, 50)
         pipe.sync()
         sm, sc = pipe.read_stage_ms()
         out["stage_us"] = {STAGE_NAMES[i]: round(1000.0 * float(sm[i]) / max(int(sc[i]), 1), 2) for i in (1, 2, 3, 4, 5)}
@@ -473,10 +646,21 @@ def main():
             out["roofline"]["stage"] = stage_block(out["roofline"]["algorithmic_bytes_per_launch"], float(sm[3]) / max(int(sc[3]), 1),
                                                    "HIP events on the 50 frames after the timed region (inside it only the kernel is timed)")
         pipe.stage_timers(0)
-        out["roofline_extra"] = roofline_extra(pipe, run, args.warmup + args.steps + 50, res, size)
+        out["roofline_extra"] = roofline_extra(pipe, run, base + args.warmup + args.steps + 50, res, size)
     if world == 1 and args.config == "auto" and not args.force_slab and not args.no_scaling_reference:
         pipe.close()
         out["multi_gpu_workload_on_1_gpu"] = single_gpu_reference("c4")      # what --gpus 2/4/8 should be compared with
+    if extras and args.config == "auto":
+        # the other BASELINE.json configurations next to the headline (short runs, each on a fresh context), and C2 with the reference's
+        # stock colour switches (use_color=1, color_angle_weight=1: src/config.ini:2,7)
+        pipe.close()
+        out["other_configs"] = {
+            "C1": single_gpu_reference("c1", n_frames=70),
+            "C3": single_gpu_reference("c3", n_frames=70),
+            "C5_on_1_gpu": single_gpu_reference("c5", n_frames=30, warmup=6, n_unique=12),
+            "C2_color": single_gpu_reference("c2", n_frames=110, overrides=dict(color=True, desc="C2 with use_color=1, color_angle_weight=1 (the reference's stock switches): "
+                                                                                 "colour planes fused and raycast beside tsdf / weight; one synthetic colour image reused")),
+        }
     if extras:
         pipe.close()
         out["pcie_inclusive"] = pcie_inclusive(wl, frames)

@@ -52,6 +52,7 @@ struct TrackArgs {
   float* fold_out;
   // SDF tracker only
   KfVolume vol; const float* depth;
+  int slab_pixels;                               // 1: sum only pixels whose own voxel (pworld0) lies in the layers this context OWNS (z-slab partition)
 #ifdef KF_EXPERIMENTS
   unsigned long long* dbg;                       // KF_ICP_EXP=11: where workgroup 0 accumulates the solve's sub-phase times (10 ns ticks)
 #endif
@@ -820,6 +821,12 @@ __global__ void __launch_bounds__(TRK_THREADS) k_sdf_step(TrackArgs a) {
     // testing their verdicts in the reference's order is equivalent: 7 dependent round trips per pixel instead of 13.
     float sdf0, sw[6], sv[6];
     const float4 pw0 = kf_mat_vec(s_m[0], p4);
+    if (a.slab_pixels) {
+      // z-slabs: a pixel belongs to the slab that owns the voxel of its world point; every rank sums its own
+      // pixels and the 27-float systems are all-reduced.  The 13 lookups reach at most the halo (kf_sdf_partition_step checks it).
+      const int gz = kf_world_to_voxel(a.vol, kf3(pw0.x, pw0.y, pw0.z)).z;
+      if (gz < a.vol.own_z0 || gz >= a.vol.own_z1) continue;
+    }
     bool ok = kf_interpolate_sdf(a.vol, kf3(pw0.x, pw0.y, pw0.z), sdf0);
 #pragma unroll
     for (int k = 0; k < 6; k += 2) {
@@ -1144,6 +1151,54 @@ extern "C" int kf_sdf_track(kf_ctx* c, uint32_t frame_id, const kf_sdf_tracker_p
   a.step = step; a.consume = step > 0; a.n_prev_wg = grid;
   hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, a);
   kf_evt_end(c, KF_STAGE_TRACK);
+  return (int)hipGetLastError();
+}
+
+// ---- SDF tracker on z-slabs (pixel -> owning slab by pworld0.z, all-reduce of the 27-float system) -----------
+// Same protocol as the pixel-partitioned ICP above: the caller owns a 32-float device buffer `dev_sums`; per Gauss-Newton iteration
+// kf_sdf_partition_step sums the pixels whose world point falls into the layers this context owns and leaves the 27 sums there, the
+// caller all-reduces it (SUM) over the ranks, the next step (or kf_sdf_partition_finish) applies the reduced system.  Every rank
+// applies identical numbers -> identical poses.  All `max_iter_nums` steps are always issued (launches after convergence return at
+// once), so every rank makes the same collective calls.
+extern "C" int kf_sdf_partition_begin(kf_ctx* c, uint32_t frame_id) {
+  if (!c) return KF_ERR_ARG;
+  c->last_track_form = 0;
+  hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, frame_id == 0 ? 0 : 1, c->grid_barrier);
+  return (int)hipGetLastError();
+}
+static int sdf_partition_args(kf_ctx* c, const kf_sdf_tracker_params* sp, const kf_camera_params* cam, TrackArgs& a) {
+  if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
+  // the perturbed lookups (rotations by 0.001 rad about the origin of a volume-sized lever, +- one cell) and their trilinear taps must
+  // stay inside the stored layers: refuse a halo thinner than that, as kf_raycast_volume_slab does for its own reach
+  const int need = (int)ceilf(0.001f * 1.7320508f * c->vol.size / c->vol.cell) + 3;
+  const int lo = c->vol.own_z0 - c->vol.bz0 * KF_BRICK, hi = c->vol.bz1 * KF_BRICK - c->vol.own_z1;
+  if ((c->vol.own_z0 > 0 && lo < need) || (c->vol.own_z1 < c->vol.res && hi < need)) return KF_ERR_ARG;
+  memset(&a, 0, sizeof(a));
+  a.use_state = 1; a.sdf = 1; a.slab_pixels = 1;
+  a.cam = to_cam(cam); a.vol = c->vol; a.depth = c->trunced_depth;
+  set_thresholds(a, 0.f, 0.f, sp->dist_shake, sp->angle_shake);
+  a.partials = c->icp_partials; a.track = c->track;
+  return 0;
+}
+extern "C" int kf_sdf_partition_step(kf_ctx* c, uint32_t step, const kf_sdf_tracker_params* sp, const kf_camera_params* cam, float* dev_sums) {
+  if (!c || !sp || !cam || !dev_sums || step >= sp->max_iter_nums) return KF_ERR_ARG;
+  TrackArgs a;
+  int st = sdf_partition_args(c, sp, cam, a);
+  if (st) return st;
+  const int grid = track_grid(c->cols * c->rows);
+  a.step = (int)step; a.consume = step > 0; a.n_prev_wg = grid; a.ext_prev = step > 0 ? dev_sums : nullptr;
+  hipLaunchKernelGGL(k_sdf_step, dim3(grid), dim3(TRK_THREADS), 0, c->stream, a);
+  TrackArgs f = a; f.step = (int)step + 1; f.n_prev_wg = grid; f.fold_out = dev_sums; f.ext_prev = nullptr;
+  hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, f);
+  return (int)hipGetLastError();
+}
+extern "C" int kf_sdf_partition_finish(kf_ctx* c, const kf_sdf_tracker_params* sp, const kf_camera_params* cam, const float* dev_sums) {
+  if (!c || !sp || !cam || !dev_sums) return KF_ERR_ARG;
+  TrackArgs a;
+  int st = sdf_partition_args(c, sp, cam, a);
+  if (st) return st;
+  a.consume = sp->max_iter_nums > 0; a.step = (int)sp->max_iter_nums; a.ext_prev = dev_sums;
+  hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, a);
   return (int)hipGetLastError();
 }
 

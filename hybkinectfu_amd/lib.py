@@ -85,6 +85,7 @@ SYMBOLS = [
     "kf_upload_map", "kf_download_volume", "kf_upload_volume", "kf_get_volume_stats", "kf_stored_z_range",
     "kf_stage_timers", "kf_read_stage_ms", "kf_read_work_counters", "kf_set_stream", "kf_raycast_volume_slab", "kf_slab_mask_candidates", "kf_set_model_maps_device", "kf_slab_pack_candidates", "kf_set_model_maps_packed", "kf_selftest_div",
     "kf_icp_partition_begin", "kf_icp_partition_steps", "kf_icp_partition_step", "kf_icp_partition_finish",
+    "kf_sdf_partition_begin", "kf_sdf_partition_step", "kf_sdf_partition_finish",
 ]
 
 
@@ -275,6 +276,18 @@ class Context:
                  "kf_icp_partition_step")
             all_reduce()
         _chk(self.lib.kf_icp_partition_finish(self.h, C.byref(p), C.c_void_p(dev_sums_ptr)), "kf_icp_partition_finish")
+
+    def sdf_partition_track(self, frame_id, max_iter, dist_shake, angle_shake, dev_sums_ptr, all_reduce):
+        """CameraPoseFinderSDF on a z-slab: this context sums the pixels whose world point it owns; `all_reduce()` must sum the 32-float
+        buffer at dev_sums_ptr over the ranks (called max_iter times on every rank, whatever the convergence)."""
+        p = SdfTrackerParams(max_iter, dist_shake, angle_shake)
+        _chk(self.lib.kf_sdf_partition_begin(self.h, frame_id), "kf_sdf_partition_begin")
+        if frame_id == 0:
+            return
+        for step in range(max_iter):
+            _chk(self.lib.kf_sdf_partition_step(self.h, step, C.byref(p), C.byref(self.cam), C.c_void_p(dev_sums_ptr)), "kf_sdf_partition_step")
+            all_reduce()
+        _chk(self.lib.kf_sdf_partition_finish(self.h, C.byref(p), C.byref(self.cam), C.c_void_p(dev_sums_ptr)), "kf_sdf_partition_finish")
 
     def sdf_track(self, frame_id, max_iter, dist_shake, angle_shake):
         p = SdfTrackerParams(max_iter, dist_shake, angle_shake)

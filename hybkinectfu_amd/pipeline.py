@@ -16,7 +16,9 @@ class SingleGpuPipeline:
         self.cam = kcam
         self.trunc_max = wl.get("trunc_max", P["depth_trunc_max"])
         self.integ_dist = wl.get("integ_dist", P["integrate_depth_trunc"])
-        self.ctx = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=max_triangles, device=device)
+        self.tracker = wl.get("tracker", "icp")                # "icp": CameraPoseFinderICP, "sdf": CameraPoseFinderSDF
+        self.color = bool(wl.get("color", False))              # the reference's stock switches use_color=1, color_angle_weight=1 (src/config.ini:2,7)
+        self.ctx = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=max_triangles, device=device, has_color=self.color)
         self.ctx.set_pose(S.pose0(size))                       # HybKinectfu::init  src/HybKinectfu.cpp:51-57
         self.inc = P["raycast_increment_factor"] * P["integrate_sdf_trunc"]     # AppParamsProducer.cpp:113-117
 
@@ -26,11 +28,14 @@ class SingleGpuPipeline:
         c = self.ctx
         c.set_depth_mm_device(dev_mm_ptr)                                                                    # copyFrameToGPU
         c.preprocess(P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])  # :106-110
-        c.icp_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])  # :116
+        if self.tracker == "sdf":
+            c.sdf_track(frame_id, P["sdf_max_iter_nums"], P["camera_shake_dist"], P["camera_shake_angle"])                  # :116 with CameraPoseFinderSDF
+        else:
+            c.icp_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])  # :116
         if next_mm_ptr is not None:
             c.prefetch_frame(next_mm_ptr, P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
-        c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist)                                         # :125-140
-        c.raycast(None, self.inc, P["depth_trunc_min"], self.trunc_max)                                      # :149-154
+        c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist, has_color=self.color, angle_weight=self.color)      # :125-140
+        c.raycast(None, self.inc, P["depth_trunc_min"], self.trunc_max, has_color=self.color)                           # :149-154
 
     def sync(self):
         self.ctx.sync()
@@ -141,10 +146,11 @@ class SlabPipeline:
     by SlabExchange's two all-reduces.
     """
 
-    def __init__(self, kcam, res, size, wl=None, rank=0, world=1, device=0, max_triangles=0, icp_mode="replicated"):
+    def __init__(self, kcam, res, size, wl=None, rank=0, world=1, device=0, max_triangles=0, icp_mode="replicated", tracker="icp"):
         import torch
         import torch.distributed as dist
         self.icp_mode = icp_mode            # "replicated" (default, faster at VGA) or "allreduce" (pixels split over the ranks)
+        self.tracker = tracker              # "icp" (CameraPoseFinderICP) or "sdf" (CameraPoseFinderSDF: pixels go to the slab that owns their world point, 27-float all-reduce per iteration)
         wl = wl or {}
         self.dist, self.torch = dist, torch
         self.rank, self.world = rank, world
@@ -169,6 +175,7 @@ class SlabPipeline:
                                unpack=lambda packed: c.set_model_maps_packed(packed.data_ptr()))
         self.sums = torch.zeros(32, dtype=torch.float32, device=dev)
         self._preprocessed = None           # device pointer of a frame whose preprocess was enqueued during the previous frame's merge
+        self._merge_events = None           # time_merge(True): (start, end) torch event pairs around every frame's merge
 
     def process_frame_device(self, dev_mm_ptr, frame_id, next_mm_ptr=None):
         with self.torch.cuda.stream(self.stream):
@@ -184,7 +191,10 @@ class SlabPipeline:
         if self._preprocessed != dev_mm_ptr:                              # not done ahead of time by the previous call (see below)
             self._preprocess(dev_mm_ptr)
         self._preprocessed = None
-        if self.icp_mode == "allreduce":
+        if self.tracker == "sdf":
+            c.sdf_partition_track(frame_id, P["sdf_max_iter_nums"], P["camera_shake_dist"], P["camera_shake_angle"], self.sums.data_ptr(),
+                                  lambda: dist.all_reduce(self.sums, op=dist.ReduceOp.SUM))
+        elif self.icp_mode == "allreduce":
             c.icp_partition_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"],
                                   self.rank, self.world, self.sums.data_ptr(), lambda: dist.all_reduce(self.sums, op=dist.ReduceOp.SUM))
         else:
@@ -198,7 +208,44 @@ class SlabPipeline:
             if next_mm_ptr is not None:
                 self._preprocess(next_mm_ptr)
                 self._preprocessed = next_mm_ptr
-        ex.merge(overlap)
+        if self._merge_events is not None:
+            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0.record(self.stream)
+            ex.merge(overlap)
+            e1.record(self.stream)
+            self._merge_events.append((e0, e1))
+        else:
+            ex.merge(overlap)
+
+    def time_merge(self, on=True):
+        """Measurement legs only: time every frame's merge (both all-reduces, pack, unpack, and whatever the overlap hook enqueues)
+        with a torch event pair on the pipeline's stream."""
+        self._merge_events = [] if on else None
+
+    def read_merge_ms(self):
+        """(total ms, frames) of the merges timed since time_merge(True); resets the list."""
+        self.sync()
+        ev, self._merge_events = self._merge_events or [], ([] if self._merge_events is not None else None)
+        return float(sum(a.elapsed_time(b) for a, b in ev)), len(ev)
+
+    def verify_lockstep(self):
+        """Every rank must have fused and lost the same frames and hold the same pose bits -- halo layers are re-integrated by both
+        neighbours, so a rank that silently lost a frame (or tracked differently) would let its halo drift from its neighbour's owned
+        layers.  A collective (all ranks call it at the same point, outside timed regions); raises on disagreement."""
+        import numpy as np
+        torch, dist = self.torch, self.dist
+        self.sync()
+        st = self.stats()
+        _, pose, status, _ = self.track_result()
+        bits = np.ascontiguousarray(pose, np.float32).view(np.uint32).astype(np.int64).reshape(-1)
+        mine = torch.tensor([int(st["frames_fused"]), int(st["frames_lost"]), int(status)] + bits.tolist(), dtype=torch.int64, device=self.ex.t.device)
+        every = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(every, mine)
+        for r, other in enumerate(every):
+            if not torch.equal(other, every[0]):
+                raise RuntimeError("z-slab ranks out of lock-step: rank 0 (fused, lost, status, pose bits) = %s, rank %d = %s"
+                                   % (every[0].tolist()[:3], r, other.tolist()[:3]))
+        return dict(frames_fused=int(st["frames_fused"]), frames_lost=int(st["frames_lost"]))
 
     def sync(self):
         self.ctx.sync()

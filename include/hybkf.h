@@ -188,6 +188,13 @@ int kf_icp_partition_steps(kf_ctx* ctx);
 int kf_icp_partition_step(kf_ctx* ctx, uint32_t step, const kf_icp_params* icp, const kf_camera_params* depth_camera,
                           uint32_t part, uint32_t parts, float* dev_sums);
 int kf_icp_partition_finish(kf_ctx* ctx, const kf_icp_params* icp, const float* dev_sums);
+/* The same protocol for CameraPoseFinderSDF on z-slabs (src/CameraPoseFinderSDF.cpp:44-106, src/cuda/CalSDFErrSolverParams.cu:68-138): a pixel is
+ * summed by the context that OWNS the voxel of its world point (the 13 lookups around it reach into the halo at most: a thinner halo is
+ * refused with an argument error); the caller all-reduces (SUM) the 27-float system in `dev_sums` between the calls.  All max_iter_nums steps
+ * are issued on every rank (after convergence they return at once), so the ranks' collective calls line up. */
+int kf_sdf_partition_begin(kf_ctx* ctx, uint32_t frame_id);
+int kf_sdf_partition_step(kf_ctx* ctx, uint32_t step, const kf_sdf_tracker_params* params, const kf_camera_params* depth_camera, float* dev_sums);
+int kf_sdf_partition_finish(kf_ctx* ctx, const kf_sdf_tracker_params* params, const kf_camera_params* depth_camera, const float* dev_sums);
 
 /* cudaMarchingcube  src/cuda/marchingcube.cu:154-164.  Triangles are appended after those already stored
  * (the reference never clears its counter, src/cuda/MarchingcubeData.h:56,99) in the canonical order (z, y, x, k). */

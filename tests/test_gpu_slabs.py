@@ -1,3 +1,4 @@
+    assert lib.kf_sdf_partition_step(thin.h, 0, C.byref(sp), C.byref(thin.cam), C.c_void_p(sums[0].data_ptr())) == 1001      # KF_ERR_ARG
 """GPU (one device): N z-slab contexts, merged exactly as SlabPipeline merges them over RCCL, reproduce the whole-volume
 context bit for bit -- TSDF planes, update counts, raycast maps, tracked pose, marching-cubes triangle sequence."""
 import numpy as np
@@ -249,3 +250,73 @@ def test_slab_raycast_refuses_thin_halo():
     edge.raycast_slab(S.pose0(size), inc, 0.3, 4.0, t.data_ptr(), v.data_ptr(), n.data_ptr())
     edge.sync()
     edge.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sdf_tracker_on_slabs_matches_whole_volume_and_oracle(world):
+    """CameraPoseFinderSDF with the volume split into z-slabs (kf_sdf_partition_*): every context sums the pixels whose world point
+    it owns, the 27-float systems are added per iteration (the all-reduce) and every context applies the sum.  The partition changes
+    only the association of the fp32 sums: same verdict and iteration count as the whole-volume tracker and as the oracle, pose within
+    the north star's 1e-4; the contexts agree bitwise with each other; the pixels are partitioned exactly (valid counts add up)."""
+    import ctypes as C
+    cam = S.vga_camera()
+    kcam, ocam = K.camera(*cam), O.Cam.make(*cam)
+    size, res = 3.0, 128
+    trunc = 5 * size / res
+    inc = 0.7 * trunc
+    halo = PL.slab_halo_layers(res, size, inc)
+    whole = K.Context(kcam, res, size, P["volume_max_weight"], levels=3)
+    slabs = [K.Context(kcam, res, size, P["volume_max_weight"], levels=3, slab=r, halo=halo) for r in PL.slab_ranges(res, world)]
+    ovol = O.OVolume(res, size, P["volume_max_weight"])
+    dev = torch.device("cuda", 0)
+    sums = [torch.zeros(32, dtype=torch.float32, device=dev) for _ in slabs]
+    lib = K.load()
+    sp = K.SdfTrackerParams(P["sdf_max_iter_nums"], P["camera_shake_dist"], P["camera_shake_angle"])
+    pose = S.pose0(size)
+    for c in [whole] + slabs:
+        c.set_pose(pose)
+    o_pose = pose.copy()
+    for k in range(4):
+        mm = S.render_depth_mm(S.trajectory_pose(k, size), cam, size)
+        tr = O.trunc_depth(O.depth_mm_to_m(mm), P["depth_trunc_min"], P["depth_trunc_max"])
+        nn = O.vertices_to_normals(O.depth_to_vertices(O.bilateral(tr, P["filter_sigma_pixel"], P["filter_sigma_depth"]), ocam))
+        for c in [whole] + slabs:
+            c.upload_depth_mm(mm)
+            c.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+        whole.sdf_track(k, sp.max_iter_nums, sp.dist_shake, sp.angle_shake)
+        for c in slabs:
+            assert lib.kf_sdf_partition_begin(c.h, k) == 0
+        if k > 0:
+            for step in range(sp.max_iter_nums):
+                for r, c in enumerate(slabs):
+                    assert lib.kf_sdf_partition_step(c.h, step, C.byref(sp), C.byref(c.cam), C.c_void_p(sums[r].data_ptr())) == 0
+                    c.sync()
+                total = sums[0].clone()
+                for s_ in sums[1:]:
+                    total += s_                                   # the all-reduce
+                for s_ in sums:
+                    s_.copy_(total)
+                torch.cuda.synchronize()
+            for r, c in enumerate(slabs):
+                assert lib.kf_sdf_partition_finish(c.h, C.byref(sp), C.byref(c.cam), C.c_void_p(sums[r].data_ptr())) == 0
+            ok_o, o_pose, it_o = O.sdf_estimate(ovol, tr, ocam, sp.max_iter_nums, sp.dist_shake, sp.angle_shake, o_pose)
+        ok_w, pose_w, st_w, it_w = whole.track_result()
+        res_s = [c.track_result() for c in slabs]
+        assert ok_w and all(r[0] and r[2] == st_w and r[3] == it_w for r in res_s)
+        for r in res_s[1:]:
+            assert np.array_equal(r[1].view(np.uint32), res_s[0][1].view(np.uint32))
+        assert np.max(np.abs(res_s[0][1] - pose_w)) < 1e-4
+        if k > 0:
+            assert ok_o and it_o == it_w and np.max(np.abs(res_s[0][1] - o_pose)) < 1e-4
+        # keep all volumes identical: fuse with the WHOLE-volume tracker's pose everywhere (the slab poses differ from it in the last bits)
+        for c in [whole] + slabs:
+            c.integrate(pose_w, trunc, 2.5)
+            c.set_pose(pose_w)
+        O.integrate(ovol, tr, nn, None, False, False, pose_w, trunc, 2.5, ocam, ocam)
+        o_pose = pose_w.copy()
+    # a halo thinner than the lookups reach is refused
+    thin = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, slab=PL.slab_ranges(res, 2)[1], halo=0)
+    assert lib.kf_sdf_partition_step(thin.h, 0, C.byref(sp), C.byref(thin.cam), C.c_void_p(sums[0].data_ptr())) == K.load().kf_sdf_partition_step(thin.h, 0, C.byref(sp), C.byref(thin.cam), C.c_void_p(sums[0].data_ptr())) != 0
+    thin.close()
+    for c in [whole] + slabs:
+        c.close()
