@@ -28,6 +28,7 @@ struct IntegrateArgs {
   int fine_tiles;                // 1: bricks are small on screen, the cull reads the 8-pixel table where the footprint allows
   unsigned* queue;               // active brick slots
   const unsigned* queue_pad;     // 16 aligned bytes nobody writes during the fusion pass (what non-updating lanes load)
+  unsigned queue_cap;            // entries the queue can hold (= stored bricks)
   KfCounters* cnt;
   const KfTrackState* track;     // non-null: integrate only when track->tracked
   float sdf_trunc, max_dist;
@@ -400,6 +401,40 @@ __device__ __forceinline__ kf_f2 kf_div2(kf_f2 a, const KfRecip2& k) {     // kf
   return f2_fma(e2, k.r, q1);
 }
 
+// tsdfVolume.h:68-70 on the pair's two colour words (c0 | c1 << 8 | c2 << 16), observed colour words `col`, OLD weights `ow`; integrateVolume.cu:72
+// `(color_angled ? fminf(1.0, abs(normalz) / 0.75) : 1.0) * 2.0`.  Both voxels at once, packed like the rest of the kernel.
+__device__ __forceinline__ uint2 integrate_color_update2(uint2 oc, unsigned col0, unsigned col1, kf_f2 ow, kf_f2 nz, bool u0, bool u1, int color_angled, const KfRecip2& r075) {
+  // The reference forms the weight in double: fminf(1.0, abs(normalz) / 0.75) * 2.0.  Narrowed to float, that quotient equals the
+  // correctly rounded FP32 quotient |nz| / 0.75f for every float |nz|: 0.75 is a float, the exact quotient 4|nz|/3 is either exact or
+  // has the repeating tail 0101.. / 1010.., never within double rounding's reach of a float midpoint (checked exhaustively over a
+  // binade and the denormals: tests/test_oracle_golden.py::test_color_weight_fp32_form_equals_reference_double_form); the doubling
+  // is exact.  (A denormal |nz| gives a weight the divisor test below sends down the compiler's full division anyway.)
+  kf_f2 wc = f2_splat(2.0f);
+  if (color_angled) {
+    const kf_f2 an = {fabsf(nz.x), fabsf(nz.y)};
+    kf_f2 qn = kf_div2(an, r075);
+    if (__ballot((u0 && !(an.x >= 0x1p-60f || an.x == 0.f)) || (u1 && !(an.y >= 0x1p-60f || an.y == 0.f))) != 0ull) { qn.x = an.x / 0.75f; qn.y = an.y / 0.75f; }   // tiny or NaN: full division
+    wc.x = 2.0f * fminf(1.0f, qn.x); wc.y = 2.0f * fminf(1.0f, qn.y);
+  }
+  const kf_f2 den = ow + wc;
+  // the three IEEE quotients of a voxel share their divisor: one refined reciprocal per voxel (kf_div2, exact in the normal range); a
+  // divisor outside it (first observation at a grazing normal: ow = 0, wc tiny or 0) takes the compiler's full division -- wave-uniform, rare
+  const bool slow = __ballot((u0 && !(den.x >= 0x1p-60f && den.x <= 0x1p60f)) || (u1 && !(den.y >= 0x1p-60f && den.y <= 0x1p60f))) != 0ull;
+  const kf_f2 dsafe = {u0 ? den.x : 1.0f, u1 ? den.y : 1.0f};
+  const KfRecip2 rd = kf_recip2(dsafe);
+  unsigned w0 = 0u, w1 = 0u;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const kf_f2 o = {(float)((oc.x >> (8 * ch)) & 255u), (float)((oc.y >> (8 * ch)) & 255u)}, cn = {(float)((col0 >> (8 * ch)) & 255u), (float)((col1 >> (8 * ch)) & 255u)};
+    const kf_f2 num = o * ow + cn * wc;
+    kf_f2 q = kf_div2(num, rd);
+    if (slow) { q.x = num.x / den.x; q.y = num.y / den.y; }
+    w0 |= (unsigned)(unsigned char)fminf(255.0f, q.x) << (8 * ch);
+    w1 |= (unsigned)(unsigned char)fminf(255.0f, q.y) << (8 * ch);
+  }
+  return make_uint2(u0 ? w0 : oc.x, u1 ? w1 : oc.y);
+}
+
 // SAT (used once max_weight frames have been fused since the last reset / upload -- before that no voxel can be saturated): free
 // space the camera keeps looking through ends up as (tsdf 1, weight max_weight), and one more free-space observation of such a voxel
 // is the identity bit for bit: (1 * w + 1) / (w + 1) == 1, min(w + 1, max) == w.  A per-brick flag bit per wave (KF_FLAG_SAT0 << wave)
@@ -407,8 +442,13 @@ __device__ __forceinline__ kf_f2 kf_div2(kf_f2 a, const KfRecip2& k) {     // kf
 // them -- it only counts them.  The bit is set by a wave that updated (hence read) all its 128 voxels and left nothing else behind,
 // and cleared by any wave that writes something else.  After 128 frames of the benchmark stream about half (512^3) to three quarters
 // (1024^3) of the waves that would touch memory are of this kind (tools/exp_noop_waves.py).
-template <int BR, bool SAT>
+// COLOR (the reference's use_color, optionally color_angle_weight: its stock switches): the colour plane rides along -- the voxel's colour
+// projection (integrateVolume.cu:56-63) joins the update predicate, the pair's two colour words are one more 8-byte read-modify-write,
+// the running average of tsdfVolume.h:68-70 keeps the reference's double-precision weight expression and its IEEE quotients.  Colour
+// changes even where (tsdf, weight) no longer do, so COLOR excludes SAT; a wave that writes drops its quarter's saturation bit.
+template <int BR, bool SAT, bool COLOR = false>
 __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
+  static_assert(!(SAT && COLOR), "colour changes where (tsdf, weight) are saturated: no skipping");
   const KfVolume& v = a.vol;
   const unsigned n_active = a.cnt->n_active[a.parity] >> ((KF_EXP_MODE(a) == 8 || KF_EXP_MODE(a) == 9) ? KF_EXP_MODE(a) - 7 : 0);     // exp_mode 8 / 9: half / quarter of the queue (timing only)
   if (blockIdx.x == 0) integrate_maintenance(a);
@@ -421,6 +461,7 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   const unsigned xlim = (unsigned)(a.dcam.cols - 2), ylim = (unsigned)(a.dcam.rows - 2);
   const unsigned satbit = KF_FLAG_SAT0 << (threadIdx.x >> 6);           // this wave's quarter of the brick (z layers 2w, 2w + 1)
   const unsigned sat_w = __float_as_uint(v.max_weight), one_f = __float_as_uint(1.0f);
+  const KfRecip2 r075 = kf_recip2(f2_splat(0.75f));                     // COLOR: the angle weight's |nz| / 0.75
   __shared__ unsigned s_upd;
   unsigned upd_total = 0;
   if (threadIdx.x == 0) s_upd = 0;
@@ -436,15 +477,19 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
 #ifndef KF_INT_NO_QPREFETCH
   unsigned ahead[BR];
 #pragma unroll
-  for (int b = 0; b < BR; ++b) { const unsigned i = kf_opaque(blockIdx.x * BR + b); ahead[b] = (i < n_active) ? a.queue[i] : 0u; }
+  // (the first entries are requested without waiting for the queue length -- every index below the queue's capacity is readable, and an
+  // entry at or beyond n_active is discarded below -- so the two loads of a workgroup's start-up travel together: at 512^3 a workgroup
+  // lives for one or two iterations and its start-up round trips are a visible part of the kernel)
+  for (int b = 0; b < BR; ++b) { const unsigned i = kf_opaque(blockIdx.x * BR + b); ahead[b] = a.queue[i < a.queue_cap ? i : 0u]; }
 #endif
   for (unsigned q0 = blockIdx.x * BR; q0 < n_active; q0 += gridDim.x * BR) {
     unsigned slot[BR], fold[BR]; int bx[BR], by[BR], bz[BR];
     kf_f2 pfz[BR], d[BR]; int pix0[BR], pix1[BR]; bool ok0[BR], ok1[BR];
+    int cpix0[BR], cpix1[BR]; bool okc0[BR], okc1[BR];          // COLOR: the voxels' pixels in the colour image, and whether they lie inside its window
 #ifndef KF_INT_NO_QPREFETCH
     unsigned entry[BR];
 #pragma unroll
-    for (int b = 0; b < BR; ++b) entry[b] = (unsigned)__builtin_amdgcn_readfirstlane((int)ahead[b]);
+    for (int b = 0; b < BR; ++b) entry[b] = (q0 + b < n_active) ? (unsigned)__builtin_amdgcn_readfirstlane((int)ahead[b]) : 0u;
     {
       const unsigned qn = q0 + gridDim.x * BR;
 #pragma unroll
@@ -493,6 +538,17 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
       ok1[b] = z1 && (unsigned)(sx1 - 1) < xlim && (unsigned)(sy1 - 1) < ylim;
       pix0[b] = ok0[b] ? sy0 * a.dcam.cols + sx0 : 0;
       pix1[b] = ok1[b] ? sy1 * a.dcam.cols + sx1 : 0;
+      if (COLOR) {
+        // :56-57 `int(pf.x * 525 / pf.z + 320)`, `int(pf.y * 525 / pf.z + 240)` -- the reference's literal intrinsics, fp32, truncated;
+        // :59 the window test against the colour camera's size
+        const kf_f2 cx = kf_div2(pfx * f2_splat(525.f), rz) + f2_splat(320.f), cy = kf_div2(pfy * f2_splat(525.f), rz) + f2_splat(240.f);
+        const int cx0 = kf_f2i(cx.x), cx1 = kf_f2i(cx.y), cy0 = kf_f2i(cy.x), cy1 = kf_f2i(cy.y);
+        const unsigned cxlim = (unsigned)(a.rcam.cols - 2), cylim = (unsigned)(a.rcam.rows - 2);
+        okc0[b] = (unsigned)(cx0 - 1) < cxlim && (unsigned)(cy0 - 1) < cylim;
+        okc1[b] = (unsigned)(cx1 - 1) < cxlim && (unsigned)(cy1 - 1) < cylim;
+        cpix0[b] = okc0[b] ? cy0 * a.rcam.cols + cx0 : 0;
+        cpix1[b] = okc1[b] ? cy1 * a.rcam.cols + cx1 : 0;
+      }
     }
     // depth gathers of all BR x 2 voxels back to back (L2-resident image)
 #pragma unroll
@@ -504,6 +560,7 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
       sdf[b] = d[b] - pfz[b];
       upd0[b] = ok0[b] && d[b].x != 0.f && d[b].x < a.max_dist && sdf[b].x > -a.sdf_trunc;
       upd1[b] = ok1[b] && d[b].y != 0.f && d[b].y < a.max_dist && sdf[b].y > -a.sdf_trunc;
+      if (COLOR) { upd0[b] = upd0[b] && okc0[b]; upd1[b] = upd1[b] && okc1[b]; }              // :59-62 `continue` when the colour pixel is outside
     }
     // Free space, decided per wave before the voxels are even requested: when no updating voxel of the wave lies inside the truncation
     // band (sdf >= trunc for all of them) every one observes tsdf = fminf(1, sdf / trunc) = 1 EXACTLY -- x >= t > 0 implies RN(x / t) >= 1
@@ -530,6 +587,19 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
       rw[b] = touch && !skip[b];
       const float4* src = (rw[b] && KF_EXP_MODE(a) != 2) ? p[b] : reinterpret_cast<const float4*>(a.queue_pad);
       q[b] = *src;
+    }
+    // COLOR: the pair's stored colours (8 bytes), the observed colours and -- for the angle weight -- the normals' z, all branch-free
+    uint2* pc[BR]; uint2 qc[BR]; unsigned rgb0[BR], rgb1[BR]; float nz0[BR], nz1[BR];
+    if (COLOR) {
+#pragma unroll
+      for (int b = 0; b < BR; ++b) {
+        pc[b] = reinterpret_cast<uint2*>(v.color + (size_t)slot[b] * KF_BRICK_VOX) + threadIdx.x;
+        qc[b] = *(rw[b] ? pc[b] : reinterpret_cast<const uint2*>(a.queue_pad));
+        rgb0[b] = reinterpret_cast<const unsigned*>(a.rgb)[upd0[b] ? cpix0[b] : 0];
+        rgb1[b] = reinterpret_cast<const unsigned*>(a.rgb)[upd1[b] ? cpix1[b] : 0];
+        nz0[b] = a.normals[upd0[b] ? pix0[b] : 0].z;        // (read whether or not the angle weight is on: a conditional load would be waited for on the spot)
+        nz1[b] = a.normals[upd1[b] ? pix1[b] : 0].z;
+      }
     }
 #pragma unroll
     for (int b = 0; b < BR; ++b) {
@@ -560,6 +630,10 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
         if (upd0[b]) { r.x = nt.x; r.y = nw0; }
         if (upd1[b]) { r.z = nt.y; r.w = nw1; }
         if (KF_EXP_MODE(a) == 0 || KF_EXP_MODE(a) >= 8 || r.x == 123.456f) *p[b] = r;     // experiments 1 / 2: no store
+        if (COLOR) {
+          const kf_f2 nz = {nz0[b], nz1[b]};
+          *pc[b] = integrate_color_update2(qc[b], rgb0[b], rgb1[b], ow, nz, upd0[b], upd1[b], a.color_angled, r075);
+        }
       }
       if (upd0[b] || upd1[b]) {
         const float4 r = make_float4(upd0[b] ? nt.x : q[b].x, upd0[b] ? nw0 : q[b].y, upd1[b] ? nt.y : q[b].z, upd1[b] ? nw1 : q[b].w);
@@ -593,6 +667,8 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
           atomicOr(&v.negbits[slot[b] >> 5], 1u << (slot[b] & 31u));
         }
       }
+      if (COLOR && (fold[b] & satbit) && wrote && (threadIdx.x & 63) == 0)      // colour frames do not keep the saturation bits current: a wave that writes drops its quarter's
+        atomicAnd(reinterpret_cast<unsigned*>(v.flags) + (slot[b] >> 2), ~(satbit << (8u * (slot[b] & 3u))));
       if (SAT && wrote) {                                                  // the quarter's saturation bit follows what this wave left behind
         const bool now_sat = __ballot(lane_sat) == ~0ull, was_sat = (fold[b] & satbit) != 0u;      // all 64 lanes wrote: all 128 voxels known
         if (now_sat != was_sat && (threadIdx.x & 63) == 0) {
@@ -662,6 +738,7 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   a.vol = c->vol; a.dcam = to_cam(dcam); a.rcam = rcam ? to_cam(rcam) : a.dcam;
   a.depth = c->trunced_depth; a.normals = c->new_n[0]; a.rgb = c->raw_rgb;
   a.tile_max = c->tile_max_depth; a.queue = c->active_bricks; a.cnt = c->counters;
+  a.queue_cap = (unsigned)c->n_stored_bricks;
   a.queue_pad = c->active_bricks + ((c->n_stored_bricks + 3) & ~(size_t)3);     // 16-byte aligned spare words behind the queue (allocated in ctx.hip)
   a.sdf_trunc = ip->sdf_truncation; a.max_dist = ip->max_integrate_dist;
   a.has_color = has_color; a.color_angled = use_angle_weight_color;
@@ -709,7 +786,16 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   if (!grid_cap) { const char* e = getenv("KF_INTEGRATE_GRID"); grid_cap = e ? (unsigned)atoi(e) : 8192u; if (grid_cap < 64u || grid_cap > 65536u) grid_cap = 8192u; }
   unsigned grid = (unsigned)(c->n_stored_bricks < grid_cap ? c->n_stored_bricks : grid_cap);
   kf_evt_begin(c, KF_STAGE_INTEGRATE_KERNEL);
-  if (has_color) hipLaunchKernelGGL((k_integrate_bricks<true, 1>), dim3(grid), dim3(256), 0, c->stream, a);
+  static int color_pairs = -1;                            // 1 (default): colour through the packed-pair kernel; 0: the scalar kernel (A/B)
+  if (color_pairs < 0) { const char* e = getenv("KF_INTEGRATE_COLOR_PAIRS"); color_pairs = e ? atoi(e) : 1; }
+  if (has_color && color_pairs) {
+    static int cbr = -1;                                   // bricks in flight per workgroup of the colour variant (KF_INTEGRATE_BR overrides)
+    if (cbr < 0) { const char* e = getenv("KF_INTEGRATE_BR"); cbr = e ? atoi(e) : 2; if (cbr != 1 && cbr != 2 && cbr != 4) cbr = 2; }
+    if (cbr == 1) hipLaunchKernelGGL((k_integrate_pairs<1, false, true>), dim3(grid), dim3(256), 0, c->stream, a);
+    else if (cbr == 2) hipLaunchKernelGGL((k_integrate_pairs<2, false, true>), dim3(grid), dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_integrate_pairs<4, false, true>), dim3(grid), dim3(256), 0, c->stream, a);
+  }
+  else if (has_color) hipLaunchKernelGGL((k_integrate_bricks<true, 1>), dim3(grid), dim3(256), 0, c->stream, a);
   else {
     // bricks in flight per workgroup: 2, or 4 when the stored volume is large enough for the queue to hold >~100k bricks
     // (measured: 512^3 24 us with 2 vs 25 us with 4; 1024^3 378 us with 2 vs 358 us with 4).  KF_INTEGRATE_BR overrides.

@@ -381,20 +381,26 @@ __device__ __forceinline__ void kf_interpolate_sdf_pair(const KfVolume& v, float
   ok1 = kf_interp_finish(i1, q1, d1); ok2 = kf_interp_finish(i2, q2, d2);
 }
 
-// tsdfVolume.h:123-148 (float -> uchar truncation)
+// tsdfVolume.h:123-148 (float -> uchar truncation).  The sixteen loads go out together; the reference's early-outs (a voxel with weight 0)
+// are pure, so testing them afterwards, in its order, gives the same verdict -- as eight `if (weight == 0) return` in a row each load
+// waited for its predecessor's verdict (eight dependent round trips per coloured hit).
 __device__ __forceinline__ bool kf_interpolate_color(const KfVolume& v, float3 pos, uchar4& out) {
   int3 g; float a, b, c;
   if (!kf_interp_params(v, pos, g, a, b, c)) return false;
   if (!kf_z_stored(v, g.z) || !kf_z_stored(v, g.z + 1)) return false;
   float ia = 1 - a, ib = 1 - b, ic = 1 - c;
+  float wgt[8]; uchar4 col[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const size_t idx = kf_vox_index(v, g.x + (k >> 2), g.y + ((k >> 1) & 1), g.z + (k & 1));
+    wgt[k] = v.tw[idx].y; col[k] = v.color[idx];
+  }
   float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    size_t idx = kf_vox_index(v, g.x + (k >> 2), g.y + ((k >> 1) & 1), g.z + (k & 1));
-    if (v.tw[idx].y == 0.f) return false;
-    uchar4 col = v.color[idx];
+    if (wgt[k] == 0.f) return false;
     float wa = (k >> 2) ? a : ia, wb = ((k >> 1) & 1) ? b : ib, wc = (k & 1) ? c : ic;
-    float t0 = (float)col.x * wa * wb * wc, t1 = (float)col.y * wa * wb * wc, t2 = (float)col.z * wa * wb * wc;
+    float t0 = (float)col[k].x * wa * wb * wc, t1 = (float)col[k].y * wa * wb * wc, t2 = (float)col[k].z * wa * wb * wc;
     acc[0] = (k == 0) ? t0 : acc[0] + t0; acc[1] = (k == 0) ? t1 : acc[1] + t1; acc[2] = (k == 0) ? t2 : acc[2] + t2;
   }
   out = make_uchar4((unsigned char)acc[0], (unsigned char)acc[1], (unsigned char)acc[2], 0);

@@ -74,6 +74,76 @@ __device__ __forceinline__ void rc_skip_cell(float3 pos, float3 dir, float3 inv_
   do { t_prev = t; t += inc; } while (t < t_exit);      // the reference's own repeated addition: identical sample parameters
 }
 
+// The march of one ray over the samples t_k in [t, t_end): the reference's loop (raySample :65-119) with the two empty-space levels.
+// `t`, `t_prev`, `have_last`, `last_sdf` carry the reference's per-ray state in; on return t_cross < +inf names the first crossing of
+// the range (with t_cross_prev the sample before it).  Whether sample k is a crossing depends on samples k-1 and k only (the previous
+// sample's tsdf is fetched on demand), so a ray's range may be marched in pieces by different lanes: the first crossing of the ray
+// is the first piece's that has one.
+struct RcRay { float3 org, dir, inv_dir; };
+__device__ __forceinline__ void rc_march(const RaycastArgs& a, const KfVolume& v, const unsigned* s_macro, const unsigned* s_neg, bool neg_in_lds, const RcRay& ray,
+                                         const KfRecip& rS, float t_end, float& t, float& t_prev, bool& have_last, float& last_sdf,
+                                         float& t_cross, float& t_cross_prev, int& n_iter, int& n_samp) {
+  const float3 org = ray.org, dir = ray.dir, inv_dir = ray.inv_dir;
+  const int R = v.res;
+  const float rf = (float)R;
+  const int zs0 = v.bz0 * KF_BRICK, zs1 = v.bz1 * KF_BRICK;
+  const float mcell = (float)KF_MACRO * v.cell, meps = 1e-4f * mcell;
+  const float bcell = (float)KF_BRICK * v.cell, beps = 1e-3f * bcell;
+  const int nm = v.nm;
+    while (t < t_end) {
+    ++n_iter;
+    const float3 pos = kf_add(org, kf_scale(dir, t));
+    // the sample's own voxel -- tsdfvolume::getVoxel(world) tsdfVolume.h:81-97: nearest voxel, index clamped
+    int gx = kf_f2i(kf_div(pos.x * rf, rS)), gy = kf_f2i(kf_div(pos.y * rf, rS)), gz = kf_f2i(kf_div(pos.z * rf, rS));
+    gx = max(0, min(gx, R - 1)); gy = max(0, min(gy, R - 1)); gz = max(0, min(gz, R - 1));
+    // level 1: a 32^3-voxel macro cell without any negative voxel -> none of the samples inside it can be the negative
+    // side of a crossing: walk to its far side.  The cell is the VOXEL's macro cell (g >> 5), like the brick level below:
+    // picking it from the position with a different rounding could disagree with the voxel index at a cell face and skip
+    // a sample whose voxel lies in the neighbouring (non-empty) cell.
+    // level 2: only samples whose voxel this context OWNS can be its crossing candidates (the whole volume on one GPU; with
+    // z-slabs the neighbour's layers are stored as halo and serve the previous-sample / trilinear / gradient reads only); a brick
+    // that never held a negative tsdf cannot hold the negative sample of a crossing either.
+    // Both levels take ONE code path with selected parameters: the lanes of
+    // a wave sit in different states, and a wave executes the union of the paths its lanes take on every trip.
+    const int mx = gx >> 5, my = gy >> 5, mz = gz >> 5;
+    const bool macro_empty = !rc_bit(s_macro, (unsigned)((mz * nm + my) * nm + mx));
+    const bool owned = gz >= v.own_z0 && gz < v.own_z1;
+    size_t slot = 0; bool has_neg = false;
+    if (!macro_empty && owned) {
+      slot = kf_brick_slot(v, gx >> 3, gy >> 3, gz >> 3);
+      has_neg = neg_in_lds ? rc_bit(s_neg, (unsigned)slot) : (v.flags[slot] & KF_FLAG_HASNEG) != 0;
+    }
+    if (!has_neg) {
+      // macro cell: walk to its far side; owned brick with the table an LDS read away: brick by brick is cheaper than sample by
+      // sample (the cell is the VOXEL's brick: if rounding put pos a hair outside it, the walk is merely shorter, never past the
+      // far face); otherwise one sample
+      const bool walk = macro_empty || (owned && neg_in_lds);
+      if (walk) {
+        const float edge = macro_empty ? mcell : bcell, eps = macro_empty ? meps : beps;
+        const float cx = macro_empty ? (float)mx * mcell : (float)(gx >> 3) * bcell, cy = macro_empty ? (float)my * mcell : (float)(gy >> 3) * bcell,
+                    cz = macro_empty ? (float)mz * mcell : (float)(gz >> 3) * bcell;
+        rc_skip_cell(pos, dir, inv_dir, cx, cy, cz, edge, eps, a.inc, t_end, t, t_prev);
+      } else { t_prev = t; t += a.inc; }
+      have_last = false;
+      continue;
+    }
+    ++n_samp;
+    const float sdf = v.tw[slot * KF_BRICK_VOX + (size_t)(((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7))].x;
+    if (sdf < 0.0f) {
+      if (!have_last) {                                                    // the previous sample's tsdf was never fetched: fetch it now
+        const float3 last_pos = kf_add(org, kf_scale(dir, t_prev));        // recomputed exactly as the march computed it
+        int lx = kf_f2i(kf_div(last_pos.x * rf, rS)), ly = kf_f2i(kf_div(last_pos.y * rf, rS)), lz = kf_f2i(kf_div(last_pos.z * rf, rS));
+        lx = max(0, min(lx, R - 1)); ly = max(0, min(ly, R - 1)); lz = max(0, min(lz, R - 1));
+        last_sdf = (lz >= zs0 && lz < zs1) ? v.tw[kf_vox_index(v, lx, ly, lz)].x : 0.f;
+        have_last = true;
+      }
+      if (last_sdf > 0.0f) { t_cross = t; t_cross_prev = t_prev; break; }  // zero crossing :83
+    }
+    last_sdf = sdf; have_last = true; t_prev = t;
+    t += a.inc;
+  }
+}
+
 __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
   const KfVolume& v = a.vol;
   // Two packed tables live in LDS so that the empty-space walk costs LDS reads instead of dependent L2 round trips (the
@@ -107,15 +177,16 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
     __syncthreads();
   }
   const bool neg_in_lds = a.neg_words != 0;
-  // a workgroup is a 32x16 pixel tile, a wave an 8x8 patch of it
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // a workgroup is a 32x16 pixel tile, a wave an 8x8 patch of it
   const int x = blockIdx.x * 32 + (wave & 3) * 8 + (lane & 7), y = blockIdx.y * 16 + (wave >> 2) * 8 + (lane >> 3);
   if (x >= a.cam.cols || y >= a.cam.rows) return;
   if (KF_EXP_MODE(a) == 2 && ((blockIdx.x + blockIdx.y) & 1)) return;      // timing experiment: half the rays (latency- or throughput-bound?)
   const int pix = y * a.cam.cols + x;
+  const float inf = __builtin_huge_valf();
   float4 out_v = make_float4(0.f, 0.f, 0.f, 0.f), out_n = make_float4(0.f, 0.f, 0.f, 0.f);
   uchar4 out_c = make_uchar4(0, 0, 0, 0);
-  float t_cross = __builtin_huge_valf(), t_cross_prev = 0.f;
+  float t_cross = inf, t_cross_prev = 0.f;
   const float* T = a.pose ? a.pose : a.pose_val.m;
   // raycastKernel :136-150
   const float3 cam_dir = kf_normalize(kf_depth_to_skeleton((unsigned)x, (unsigned)y, 1.0f, a.cam));
@@ -138,84 +209,30 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
   if (tmin < tmax) {
     // raySample :65-119
     const int R = v.res;
-    const float rf = (float)R;
     const KfRecip rS = kf_recip(S);                                       // `worldPos.x*_resolution.x/_size.x`: shared divisor
     const KfRecip rcell = kf_recip(v.cell);
-    const int zs0 = v.bz0 * KF_BRICK, zs1 = v.bz1 * KF_BRICK;
     float t = tmin, t_prev = tmin;
     float last_sdf = 0.f; bool have_last = true;
-    const float mcell = (float)KF_MACRO * v.cell, meps = 1e-4f * mcell;
-    const float bcell = (float)KF_BRICK * v.cell, beps = 1e-3f * bcell;
-    const float3 inv_dir = kf3(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
-    const int nm = v.nm;
+    RcRay ray; ray.org = org; ray.dir = dir; ray.inv_dir = kf3(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
     // z-slabs: only samples inside the owned layers can be this context's candidates, so the march is clipped to the ray's
     // passage through them (one cell of margin on either side); the parameter still reaches the first such sample by the
     // reference's repeated addition, and the previous sample is fetched lazily like after any other skip
-    float t_end = tmax;
+    float t_end = tmax, t_first = tmin;
     if (v.own_z0 > 0 || v.own_z1 < R) {
-      const float za = ((float)(v.own_z0 - 1) * v.cell - org.z) * inv_dir.z, zb = ((float)(v.own_z1 + 1) * v.cell - org.z) * inv_dir.z;
+      const float za = ((float)(v.own_z0 - 1) * v.cell - org.z) * ray.inv_dir.z, zb = ((float)(v.own_z1 + 1) * v.cell - org.z) * ray.inv_dir.z;
       const float t_in = fminf(za, zb), t_out = fmaxf(za, zb);
       t_end = fminf(tmax, t_out);
-      const float t_first = fminf(t_in - 1e-6f * fabsf(t_in), t_end);
-      if (t < t_first) { do { t_prev = t; t += a.inc; } while (t < t_first); have_last = false; }
+      t_first = fmaxf(tmin, fminf(t_in - 1e-6f * fabsf(t_in), t_end));
     }
-    while (t < t_end) {
-      ++n_iter;
-      const float3 pos = kf_add(org, kf_scale(dir, t));
-      // the sample's own voxel -- tsdfvolume::getVoxel(world) tsdfVolume.h:81-97: nearest voxel, index clamped
-      int gx = kf_f2i(kf_div(pos.x * rf, rS)), gy = kf_f2i(kf_div(pos.y * rf, rS)), gz = kf_f2i(kf_div(pos.z * rf, rS));
-      gx = max(0, min(gx, R - 1)); gy = max(0, min(gy, R - 1)); gz = max(0, min(gz, R - 1));
-      // level 1: a 32^3-voxel macro cell without any negative voxel -> none of the samples inside it can be the negative
-      // side of a crossing: walk to its far side.  The cell is the VOXEL's macro cell (g >> 5), like the brick level below:
-      // picking it from the position with a different rounding could disagree with the voxel index at a cell face and skip
-      // a sample whose voxel lies in the neighbouring (non-empty) cell.
-      {
-        const int mx = gx >> 5, my = gy >> 5, mz = gz >> 5;
-        if (!rc_bit(s_macro, (unsigned)((mz * nm + my) * nm + mx))) {
-          rc_skip_cell(pos, dir, inv_dir, (float)mx * mcell, (float)my * mcell, (float)mz * mcell, mcell, meps, a.inc, t_end, t, t_prev);
-          have_last = false;
-          continue;
-        }
-      }
-      // only samples whose voxel this context OWNS can be its crossing candidates (the whole volume on one GPU; with
-      // z-slabs the neighbour's layers are stored as halo and serve the previous-sample / trilinear / gradient reads only)
-      const bool owned = gz >= v.own_z0 && gz < v.own_z1;
-      size_t slot = 0; bool has_neg = false;
-      if (owned) {
-        slot = kf_brick_slot(v, gx >> 3, gy >> 3, gz >> 3);
-        has_neg = neg_in_lds ? rc_bit(s_neg, (unsigned)slot) : (v.flags[slot] & KF_FLAG_HASNEG) != 0;
-      }
-      if (!has_neg) {                                                       // tsdf >= 0 everywhere in this 8^3 brick (or not ours)
-        if (owned && neg_in_lds) {
-          // the table is an LDS read away, so walking brick by brick is cheaper than sample by sample.  The cell is the
-          // VOXEL's brick: if rounding put pos a hair outside it, the walk is merely shorter (never past the far face).
-          rc_skip_cell(pos, dir, inv_dir, (float)(gx >> 3) * bcell, (float)(gy >> 3) * bcell, (float)(gz >> 3) * bcell, bcell, beps, a.inc, t_end, t, t_prev);
-        } else { t_prev = t; t += a.inc; }
-        have_last = false;
-        continue;
-      }
-      ++n_samp;
-      const float sdf = v.tw[slot * KF_BRICK_VOX + (size_t)(((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7))].x;
-      if (sdf < 0.0f) {
-        if (!have_last) {                                                    // the previous sample's tsdf was never fetched: fetch it now
-          const float3 last_pos = kf_add(org, kf_scale(dir, t_prev));        // recomputed exactly as the march computed it
-          int lx = kf_f2i(kf_div(last_pos.x * rf, rS)), ly = kf_f2i(kf_div(last_pos.y * rf, rS)), lz = kf_f2i(kf_div(last_pos.z * rf, rS));
-          lx = max(0, min(lx, R - 1)); ly = max(0, min(ly, R - 1)); lz = max(0, min(lz, R - 1));
-          last_sdf = (lz >= zs0 && lz < zs1) ? v.tw[kf_vox_index(v, lx, ly, lz)].x : 0.f;
-          have_last = true;
-        }
-        if (last_sdf > 0.0f) { t_cross = t; t_cross_prev = t_prev; break; }  // zero crossing :83
-      }
-      last_sdf = sdf; have_last = true; t_prev = t;
-      t += a.inc;
-    }
+    if (t < t_first) { do { t_prev = t; t += a.inc; } while (t < t_first); have_last = false; }
+    rc_march(a, v, s_macro, s_neg, neg_in_lds, ray, rS, t_end, t, t_prev, have_last, last_sdf, t_cross, t_cross_prev, n_iter, n_samp);
 #ifdef KF_EXPERIMENTS
     st2 = __builtin_amdgcn_s_memtime();
 #endif
     // The crossing is evaluated HERE, after the march loop, not inside it: lanes of a wave meet their crossings at
     // different iterations, and inside the loop the 64-gather evaluation would run once per distinct iteration with a
     // handful of active lanes each time.  After the loop every lane that found a crossing evaluates together.
-    if (t_cross < __builtin_huge_valf() && KF_EXP_MODE(a) != 1) {
+    if (t_cross < inf && KF_EXP_MODE(a) != 1) {
       const float3 pos = kf_add(org, kf_scale(dir, t_cross)), last_pos = kf_add(org, kf_scale(dir, t_cross_prev));
       float ftdt, ft; bool ok_cur, ok_last;
       kf_interpolate_sdf_pair(v, pos, last_pos, rS, rcell, ok_cur, ftdt, ok_last, ft);
@@ -229,7 +246,7 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
           out_n = make_float4(grad.x, grad.y, grad.z, 0.f);
         }
       }
-    } else if (t_cross < __builtin_huge_valf()) out_v = make_float4(t_cross, 0.f, 0.f, 1.f);
+    } else if (t_cross < inf) out_v = make_float4(t_cross, 0.f, 0.f, 1.f);
   }
 #ifdef KF_EXPERIMENTS
   if (KF_EXP_MODE(a) == 3) {                                                // diagnostics: shader-clock ticks of the three phases, loop trips
@@ -242,9 +259,9 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
   if (a.work) {
     // what the REFERENCE's march reads for this ray (raycastingVolume.cu:65-119): one voxel per sample from t_min up to the
     // crossing (or t_max); a crossing is evaluated with 2 + 6 trilinear look-ups of 8 voxels each
-    const float t_stop = t_cross < __builtin_huge_valf() ? t_cross : ref_tmax;
+    const float t_stop = t_cross < inf ? t_cross : ref_tmax;
     const float n_s = (ref_tmin < ref_tmax) ? floorf((t_stop - ref_tmin) / a.inc) + 1.f : 0.f;
-    const float steps = kf_wave_sum(n_s), hits = kf_wave_sum(t_cross < __builtin_huge_valf() ? 1.f : 0.f);
+    const float steps = kf_wave_sum(n_s), hits = kf_wave_sum(t_cross < inf ? 1.f : 0.f);
     if ((threadIdx.x & 63) == 0) {
       const unsigned sh = ((blockIdx.y * gridDim.x + blockIdx.x) * 8u + (threadIdx.x >> 6)) & 63u;
       atomicAdd(&a.work->rc_steps[sh * 16], (unsigned long long)steps);
@@ -272,10 +289,9 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
   const size_t macro_bytes = (((((size_t)c->vol.nm * c->vol.nm * c->vol.nm + 31) / 32) + 3) & ~(size_t)3) * 4, neg_bytes = kf_negbit_words(c->n_stored_bricks) * 4;
   a.neg_words = (macro_bytes + neg_bytes <= RAYCAST_LDS_BYTES) ? (int)(neg_bytes / 4) : 0;
   if (macro_bytes > RAYCAST_LDS_BYTES) return KF_ERR_STATE;
-  dim3 grid(kf_div_up(c->cols, 32), kf_div_up(c->rows, 16));
   kf_evt_begin(c, KF_STAGE_RAYCAST);
   kf_evt_begin(c, KF_STAGE_RAYCAST_KERNEL);
-  hipLaunchKernelGGL(k_raycast, grid, dim3(RAYCAST_THREADS), macro_bytes + (size_t)a.neg_words * 4, c->stream, a);
+  hipLaunchKernelGGL(k_raycast, dim3(kf_div_up(c->cols, 32), kf_div_up(c->rows, 16)), dim3(RAYCAST_THREADS), macro_bytes + (size_t)a.neg_words * 4, c->stream, a);
   kf_evt_end(c, KF_STAGE_RAYCAST_KERNEL);
   kf_evt_end(c, KF_STAGE_RAYCAST);
   return (int)hipGetLastError();

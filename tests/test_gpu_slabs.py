@@ -1,4 +1,3 @@
-    assert lib.kf_sdf_partition_step(thin.h, 0, C.byref(sp), C.byref(thin.cam), C.c_void_p(sums[0].data_ptr())) == 1001      # KF_ERR_ARG
 """GPU (one device): N z-slab contexts, merged exactly as SlabPipeline merges them over RCCL, reproduce the whole-volume
 context bit for bit -- TSDF planes, update counts, raycast maps, tracked pose, marching-cubes triangle sequence."""
 import numpy as np
@@ -316,7 +315,7 @@ def test_sdf_tracker_on_slabs_matches_whole_volume_and_oracle(world):
         o_pose = pose_w.copy()
     # a halo thinner than the lookups reach is refused
     thin = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, slab=PL.slab_ranges(res, 2)[1], halo=0)
-    assert lib.kf_sdf_partition_step(thin.h, 0, C.byref(sp), C.byref(thin.cam), C.c_void_p(sums[0].data_ptr())) == K.load().kf_sdf_partition_step(thin.h, 0, C.byref(sp), C.byref(thin.cam), C.c_void_p(sums[0].data_ptr())) != 0
+    assert lib.kf_sdf_partition_step(thin.h, 0, C.byref(sp), C.byref(thin.cam), C.c_void_p(sums[0].data_ptr())) == 1001      # KF_ERR_ARG
     thin.close()
     for c in [whole] + slabs:
         c.close()

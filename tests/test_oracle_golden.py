@@ -165,3 +165,21 @@ def test_float_to_int_follows_the_cuda_path():
     assert O.to_int(1e20) == 2**31 - 1 and O.to_int(float("inf")) == 2**31 - 1
     assert O.to_int(-1e20) == -2**31 and O.to_int(float("-inf")) == -2**31
     assert O.to_int(-3.99) == -3 and O.to_int(3.99) == 3 and O.to_int(2147483647.5) == 2**31 - 1
+
+
+def test_color_weight_fp32_form_equals_reference_double_form():
+    """integrateVolume.cu:72 forms the colour weight in double -- fminf(1.0, abs(normalz) / 0.75) * 2.0 -- and narrows it.  The HIP kernel
+    uses 2.0f * fminf(1.0f, |nz| / 0.75f): the narrowed double quotient equals the correctly rounded fp32 quotient for EVERY float (the exact
+    value 4|nz|/3 never comes within double rounding's reach of a float midpoint); checked over all mantissas of two binades (scaling by
+    two changes nothing in the normal range), all denormals, and random values across the exponent range."""
+    def mismatches(x):
+        x = x.astype(np.float32)
+        ref = np.minimum(np.float32(1.0), (x.astype(np.float64) / 0.75).astype(np.float32)).astype(np.float64) * 2.0
+        got = np.float32(2.0) * np.minimum(np.float32(1.0), x / np.float32(0.75))
+        return int(np.count_nonzero(ref.astype(np.float32).view(np.uint32) != got.astype(np.float32).view(np.uint32)))
+    m = np.arange(2 ** 23, dtype=np.uint32)
+    assert mismatches((m + np.uint32(0x3F000000)).view(np.float32)) == 0        # [0.5, 1)
+    assert mismatches((m + np.uint32(0x3F800000)).view(np.float32)) == 0        # [1, 2)
+    assert mismatches(m.view(np.float32)) == 0                                  # zero and the denormals
+    rng = np.random.default_rng(5)
+    assert mismatches(np.exp(rng.uniform(-80, 3, 2_000_000))) == 0
