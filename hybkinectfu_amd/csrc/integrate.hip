@@ -407,7 +407,7 @@ __device__ __forceinline__ uint2 integrate_color_update2(uint2 oc, unsigned col0
   // The reference forms the weight in double: fminf(1.0, abs(normalz) / 0.75) * 2.0.  Narrowed to float, that quotient equals the
   // correctly rounded FP32 quotient |nz| / 0.75f for every float |nz|: 0.75 is a float, the exact quotient 4|nz|/3 is either exact or
   // has the repeating tail 0101.. / 1010.., never within double rounding's reach of a float midpoint (checked exhaustively over a
-  // binade and the denormals: tests/test_oracle_golden.py::test_color_weight_fp32_form_equals_reference_double_form); the doubling
+  // binade and the denormals: the CPU test test_color_weight_fp32_form_equals_reference_double_form); the doubling
   // is exact.  (A denormal |nz| gives a weight the divisor test below sends down the compiler's full division anyway.)
   kf_f2 wc = f2_splat(2.0f);
   if (color_angled) {
