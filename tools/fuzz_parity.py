@@ -24,7 +24,16 @@ for case in range(n_cases):
     max_dist = float(rng.uniform(0.5, 1.0)) * size
     ocam, kcam = O.Cam.make(*cam), K.camera(*cam)
     ovol = O.OVolume(res, size, 128.0)
-    ctx = K.Context(kcam, res, size, 128.0, levels=1, max_triangles=600000)
+    # every third case: the colour path (use_color, with or without the angle weight).  The reference projects into the colour image with its
+    # literal 525 / 320 / 240 intrinsics (integrateVolume.cu:56-57), so the colour camera is VGA-sized whatever the depth camera is.
+    color = case % 3 == 2
+    angled = bool(rng.integers(0, 2))
+    rcam = (640, 480, 319.5, 239.5, 525.0, 525.0)
+    orcam, krcam = O.Cam.make(*rcam), K.camera(*rcam)
+    rgb = rng.integers(0, 256, (480, 640, 3)).astype(np.uint8) if color else None
+    ctx = K.Context(kcam, res, size, 128.0, levels=1, max_triangles=600000, has_color=color, rgb_cam=krcam if color else None)
+    if color:
+        ctx.upload_rgb(rgb)
     ok = True
     pose = None
     for k in range(int(rng.integers(1, 4))):
@@ -36,16 +45,25 @@ for case in range(n_cases):
         tr = O.trunc_depth(O.depth_mm_to_m(mm), P["depth_trunc_min"], P["depth_trunc_max"])
         fl = O.bilateral(tr, 2.0, 0.03)
         n = O.vertices_to_normals(O.depth_to_vertices(fl, ocam))
-        n_o = O.integrate(ovol, tr, n, None, False, False, pose, trunc, max_dist, ocam, ocam)
+        n_o = O.integrate(ovol, tr, n, rgb, color, color and angled, pose, trunc, max_dist, ocam, orcam if color else ocam)
         ctx.upload_depth_mm(mm); ctx.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], 2.0, 0.03)
-        ctx.integrate(pose, trunc, max_dist)
+        if color:                                       # identical normals on both sides: the angle weight reads them (the bilateral differs in last bits)
+            ctx.upload_map(K.MAP_NEW_NORMALS, 0, n)
+        ctx.integrate(pose, trunc, max_dist, has_color=color, angle_weight=color and angled)
         ok = ok and ctx.stats()["updated_last"] == n_o
-    t, w = ctx.download_volume()
+    if color:
+        t, w, cvol = ctx.download_volume(color=True)
+        seen = ovol.weight > 0
+        ok = ok and np.array_equal(cvol[seen], ovol.color[seen])
+    else:
+        t, w = ctx.download_volume()
     ok = ok and np.array_equal(bits(t), bits(ovol.tsdf)) and np.array_equal(bits(w), bits(ovol.weight))
     inc = float(rng.uniform(0.4, 1.5)) * trunc
-    ov, on, _ = O.raycast(ovol, False, pose, inc, ocam, 0.3, 4.0)
-    ctx.raycast(pose, inc, 0.3, 4.0)
+    ov, on, orgb = O.raycast(ovol, color, pose, inc, ocam, 0.3, 4.0)
+    ctx.raycast(pose, inc, 0.3, 4.0, has_color=color)
     ok_r = np.array_equal(bits(ctx.download_map(K.MAP_MODEL_VERTICES)), bits(ov)) and np.array_equal(bits(ctx.download_map(K.MAP_MODEL_NORMALS)), bits(on))
+    if color:
+        ok_r = ok_r and np.array_equal(ctx.download_map(K.MAP_RAYCAST_RGB), orgb)
     thr = 300 * size / res
     ot = O.marching_cubes(ovol, False, thr, 600000)
     ctx.marching_cubes(thr)
@@ -69,8 +87,8 @@ for case in range(n_cases):
     ctx.close()
     good = ok and ok_r and ok_m and ok_s
     fails += 0 if good else 1
-    print("case %2d: res %3d size %.1f cam %dx%d trunc %.3f inc %.3f -> integrate %s raycast %s (%d hits) mcubes %s (%d tris) slabs %s" % (
-        case, res, size, cols, rows, trunc, inc, "ok" if ok else "MISMATCH", "ok" if ok_r else "MISMATCH", int((ov[..., 3] != 0).sum()),
+    print("case %2d: res %3d size %.1f cam %dx%d trunc %.3f inc %.3f%s -> integrate %s raycast %s (%d hits) mcubes %s (%d tris) slabs %s" % (
+        case, res, size, cols, rows, trunc, inc, (" colour%s" % (" + angle weight" if angled else "")) if color else "", "ok" if ok else "MISMATCH", "ok" if ok_r else "MISMATCH", int((ov[..., 3] != 0).sum()),
         "ok" if ok_m else "MISMATCH", len(ot), "ok" if ok_s else "MISMATCH"), flush=True)
 print("FUZZ %s: %d of %d cases failed" % ("FAILED" if fails else "OK", fails, n_cases))
 sys.exit(1 if fails else 0)

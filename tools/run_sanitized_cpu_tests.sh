@@ -8,7 +8,7 @@ make -C oracle sanitize > /dev/null
 make -C hybkinectfu_amd/host sanitize > /dev/null
 ASAN=$(gcc -print-file-name=libasan.so)
 UBSAN=$(gcc -print-file-name=libubsan.so)
-out=${1:-profiles/r02_sanitizer_cpu.txt}
+out=${1:-profiles/r03_sanitizer_cpu.txt}
 {
   echo "# $(date -u +%F) ASan+UBSan run of the CPU test suite: oracle/libkforacle_asan.so + hybkinectfu_amd/libhybkf_host_asan.so"
   echo "# g++ -fsanitize=address,undefined -fno-sanitize-recover=undefined; LD_PRELOAD=libasan.so libubsan.so; detect_leaks=0 (CPython itself leaks at exit)"
