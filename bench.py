@@ -363,6 +363,17 @@ def per_rank_leg(pipe, run, barrier, dist, world, rank, first, n_frames):
                      "with the next frame's preprocess enqueued behind the first all-reduce)")
 
 
+def balanced_ranges(args, kcam, res, size, wl, world, device, first_frame_ptr):
+    """z-slab boundaries of a run: equal thickness, or (default for N > 1) chosen so that the busiest rank fuses as little as possible, from a
+    one-frame probe of the work per z-layer in a 256^3 volume of the same extent (pipeline.probe_layer_work; every rank computes the same)."""
+    from hybkinectfu_amd import pipeline as PL
+    if world == 1 or args.slab_balance == "equal":
+        return None
+    inc = P["raycast_increment_factor"] * P["integrate_sdf_trunc"]
+    work = PL.probe_layer_work(kcam, res, size, wl, first_frame_ptr, device=device)
+    return PL.slab_ranges(res, world, work, halo=PL.slab_halo_layers(res, size, inc))
+
+
 def slab_block(name, args, world, rank, device, dist, n_frames, warmup, n_unique):
     """A short run of workload `name` on the z-slab pipeline of THIS process group (the N > 1 line's C5 block): frames/s over
     n_frames - warmup frames, per-rank statistics, lock-step check, and the mesh extraction of every rank's slab."""
@@ -375,7 +386,8 @@ def slab_block(name, args, world, rank, device, dist, n_frames, warmup, n_unique
     dev_frames = torch.from_numpy(frames.astype(np.int16)).cuda()
     fb = cam[0] * cam[1] * 2
     pipe = SlabPipeline(K.camera(*cam), res, size, wl, rank=rank, world=world, device=device, icp_mode=args.icp_mode, tracker=args.tracker,
-                        max_triangles=(16_000_000 // world + 1_000_000 if wl.get("extract_mesh") else 0))
+                        max_triangles=(16_000_000 // world + 1_000_000 if wl.get("extract_mesh") else 0),
+                        ranges=balanced_ranges(args, K.camera(*cam), res, size, wl, world, device, dev_frames.data_ptr()))
 
     def run(first, count):
         for k in range(first, first + count):
@@ -397,6 +409,7 @@ def slab_block(name, args, world, rank, device, dist, n_frames, warmup, n_unique
     lost = pipe.stats()["frames_lost"] - s0["frames_lost"]
     out = dict(workload=wl["desc"], value=round((n_frames - warmup) / dt, 2), unit="frames/s", steps=n_frames - warmup, warmup=warmup,
                ms_per_step=round(1000.0 * dt / (n_frames - warmup), 4), frames_lost=int(lost), halo_layers=int(pipe.halo),
+               slab_ranges=[list(r) for r in pipe.ranges], slab_balance=args.slab_balance,
                unique_frames=n_unique, per_rank=per_rank_leg(pipe, run, barrier, dist, world, rank, n_frames, 10))
     out["lockstep"] = pipe.verify_lockstep()
     if wl.get("extract_mesh"):
@@ -428,6 +441,9 @@ def main():
                     help="frames fused before the warm-up (e.g. 160 = past max_weight: the timed frames then run the saturation-aware kernels; "
                          "used to profile that regime -- the default 0 keeps warm-up + steps inside the early regime)")
     ap.add_argument("--tracker", default="icp", choices=["icp", "sdf"], help="z-slab pipeline only: CameraPoseFinderICP (default) or CameraPoseFinderSDF on slabs")
+    ap.add_argument("--slab-balance", default="probe", choices=["probe", "equal"],
+                    help="N > 1: slab boundaries from a one-frame low-resolution probe of the work per z-layer (default: the busiest rank sets the frame time, "
+                         "and equal z-slabs are unequally busy) or equal thickness")
     ap.add_argument("--no-c5", action="store_true", help="N > 1: skip the short C5 block (2048^3 @ 8 m, 1280x960) that follows the C4 measurement")
     ap.add_argument("--config", default="auto", choices=["auto", "c1", "c2", "c3", "c4", "c5"],
                     help="auto: C2 (512^3 @ 4 m) on 1 GPU, C4 (1024^3 @ 6 m, z-slabs) on N > 1, as BASELINE.json's metric states; "
@@ -480,6 +496,8 @@ def main():
             dist.init_process_group("gloo")
 
     wl = workload(world, args.config)
+    if args.tracker == "sdf":
+        wl = dict(wl, tracker="sdf")
     cam, res, size = wl["cam"], wl["res"], wl["size"]
     kcam = K.camera(*cam)
     period = 100
@@ -495,7 +513,8 @@ def main():
     else:
         from hybkinectfu_amd.pipeline import SlabPipeline as Pipe
         pipe = Pipe(kcam, res, size, wl, rank=rank, world=world, device=device, icp_mode=args.icp_mode, tracker=args.tracker,
-                    max_triangles=(16_000_000 // world + 1_000_000 if wl.get("extract_mesh") else 0))
+                    max_triangles=(16_000_000 // world + 1_000_000 if wl.get("extract_mesh") else 0),
+                    ranges=balanced_ranges(args, kcam, res, size, wl, world, device, dev_frames.data_ptr()))
 
     def run(first, count):
         # --prefetch: frame k+1 is preprocessed on the context's side stream while frame k is tracked (kf_prefetch_frame)
@@ -620,8 +639,11 @@ def main():
                            world_size=(dist.get_world_size() if dist is not None else 1),
                            backend=("none" if dist is None else ("rccl" if args.backend == "nccl" else "gloo (rehearsal: host-staged collectives, ranks may share a GPU)")),
                            partition="none" if not slab else
-                           "z-slab x%d; %d halo layers per side RE-INTEGRATED by both neighbours (recomputed, not exchanged over xGMI); "
-                           "raycast merge = MIN all-reduce (t, 1.2 MB) + integer SUM all-reduce (vertex+normal, 7.4 MB); ICP %s" % (world, pipe.halo, args.icp_mode)),
+                           "z-slab x%d (boundaries: %s); %d halo layers per side RE-INTEGRATED by both neighbours (recomputed, not exchanged over xGMI); "
+                           "raycast merge = MIN all-reduce (t, 1.2 MB) + integer SUM all-reduce (vertex+normal, 7.4 MB); ICP %s"
+                           % (world, "balanced from a one-frame 256^3 probe of the work per z-layer" if (world > 1 and args.slab_balance == "probe") else "equal thickness",
+                              pipe.halo, args.icp_mode),
+                           slab_ranges=([list(r) for r in pipe.ranges] if slab else None)),
                roofline=roofline)
     if mesh is not None:
         out["mesh_extraction"] = mesh

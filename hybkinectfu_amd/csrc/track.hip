@@ -1072,6 +1072,7 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
 // kf_icp_partition_finish) consumes it.  Every rank applies the identical all-reduced system, so the poses agree bitwise.
 extern "C" int kf_icp_partition_begin(kf_ctx* c, uint32_t frame_id) {
   if (!c) return KF_ERR_ARG;
+  if (frame_id != 0) kf_evt_begin(c, KF_STAGE_TRACK);       // (the stage timer runs from here to kf_icp_partition_finish: it includes the caller's all-reduces)
   return kf_launch_pyramids_and_begin(c, frame_id == 0 ? 0 : 1);
 }
 static int icp_iters(int levels, int iters[KF_MAX_LEVELS]) {                // ICP.cpp:14-35
@@ -1115,6 +1116,7 @@ extern "C" int kf_icp_partition_finish(kf_ctx* c, const kf_icp_params* icp, cons
   a.use_state = 1; a.consume = 1; a.step = icp_iters(c->levels, iters); a.ext_prev = dev_sums;
   set_thresholds(a, icp->dist_thres, icp->norm_sin_thres, icp->dist_shake, icp->angle_shake); a.partials = c->icp_partials; a.track = c->track;
   hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, a);
+  kf_evt_end(c, KF_STAGE_TRACK);
   return (int)hipGetLastError();
 }
 
@@ -1163,6 +1165,7 @@ extern "C" int kf_sdf_track(kf_ctx* c, uint32_t frame_id, const kf_sdf_tracker_p
 extern "C" int kf_sdf_partition_begin(kf_ctx* c, uint32_t frame_id) {
   if (!c) return KF_ERR_ARG;
   c->last_track_form = 0;
+  if (frame_id != 0) kf_evt_begin(c, KF_STAGE_TRACK);       // (ends in kf_sdf_partition_finish: the caller's all-reduces are inside)
   hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, frame_id == 0 ? 0 : 1, c->grid_barrier);
   return (int)hipGetLastError();
 }
@@ -1199,6 +1202,7 @@ extern "C" int kf_sdf_partition_finish(kf_ctx* c, const kf_sdf_tracker_params* s
   if (st) return st;
   a.consume = sp->max_iter_nums > 0; a.step = (int)sp->max_iter_nums; a.ext_prev = dev_sums;
   hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, a);
+  kf_evt_end(c, KF_STAGE_TRACK);
   return (int)hipGetLastError();
 }
 

@@ -61,16 +61,78 @@ class SingleGpuPipeline:
 # ---------------------------------------------------------------------------------------------------------------------------
 
 
-def slab_ranges(res, world):
-    """Owned z range [z0, z1) of every rank: contiguous, brick (8-layer) aligned, sizes differing by at most one brick."""
+def slab_ranges(res, world, layer_work=None, halo=0):
+    """Owned z range [z0, z1) of every rank: contiguous, brick (8-layer) aligned, every rank at least one brick layer.
+
+    Without `layer_work`: equal thickness (sizes differing by at most one brick).  With it -- the work (voxels fused per frame) of every
+    8-voxel brick layer, e.g. from probe_layer_work -- the boundaries that minimise the BUSIEST rank's work, halo layers (re-integrated by
+    both neighbours) included: equal z-slabs are unequally busy (the nearest sees a narrow frustum, the farthest may lie behind every
+    surface: 15 / 45 / 38 / 2 % on four ranks at 1024^3 @ 6 m), and a frame lasts as long as the busiest rank needs.  Exact: a dynamic
+    programme over the (rank, boundary) pairs; deterministic, so every rank derives the same ranges from the same probe."""
     nb = res // 8
-    base, extra = divmod(nb, world)
-    out, b = [], 0
-    for r in range(world):
-        n = base + (1 if r < extra else 0)
-        out.append((b * 8, (b + n) * 8))
-        b += n
-    return out
+    if world > nb:
+        raise ValueError("more ranks (%d) than brick layers (%d)" % (world, nb))
+    if layer_work is None:
+        base, extra = divmod(nb, world)
+        out, b = [], 0
+        for r in range(world):
+            n = base + (1 if r < extra else 0)
+            out.append((b * 8, (b + n) * 8))
+            b += n
+        return out
+    w = [float(x) for x in layer_work]
+    if len(w) != nb:
+        raise ValueError("layer_work needs one entry per brick layer (%d), got %d" % (nb, len(w)))
+    hb = (int(halo) + 7) // 8
+    pre = [0.0]
+    for x in w:
+        pre.append(pre[-1] + x)
+    eps = 1e-9 * (pre[-1] + 1.0)          # a tiny cost per layer: ties resolve towards even thickness, empty regions are still shared out
+
+    def cost(i, j):                       # work of a rank owning brick layers [i, j): own + halo layers
+        lo, hi = max(0, i - hb), min(nb, j + hb)
+        return pre[hi] - pre[lo] + eps * (j - i) * (j - i)
+    INF = float("inf")
+    best = [[INF] * (nb + 1) for _ in range(world + 1)]
+    cut = [[0] * (nb + 1) for _ in range(world + 1)]
+    best[0][0] = 0.0
+    for r in range(1, world + 1):
+        for j in range(r, nb - (world - r) + 1):
+            for i in range(r - 1, j):
+                if best[r - 1][i] == INF:
+                    continue
+                c = max(best[r - 1][i], cost(i, j))
+                if c < best[r][j]:
+                    best[r][j], cut[r][j] = c, i
+    bounds, j = [nb], nb
+    for r in range(world, 0, -1):
+        j = cut[r][j]
+        bounds.append(j)
+    bounds.reverse()
+    return [(bounds[r] * 8, bounds[r + 1] * 8) for r in range(world)]
+
+
+def probe_layer_work(kcam, res, size, wl, dev_mm_ptr, device=0, probe_res=256):
+    """Voxels one frame fuses per 8-voxel brick layer of the res^3 volume, estimated from ONE integrate of that frame into a low-resolution
+    volume of the same extent (probe_res^3: a few milliseconds and a 67 MB read-back at 256^3) -- the input of slab_ranges' balancing.
+    Every rank runs the same probe on the same frame and gets the same numbers."""
+    import numpy as np
+    wl = wl or {}
+    pres = min(int(probe_res), int(res))
+    ctx = K.Context(kcam, pres, size, P["volume_max_weight"], levels=3, device=device)
+    ctx.set_pose(S.pose0(size))
+    ctx.set_depth_mm_device(dev_mm_ptr)
+    ctx.preprocess(P["depth_trunc_min"], wl.get("trunc_max", P["depth_trunc_max"]), P["filter_sigma_pixel"], P["filter_sigma_depth"])
+    ctx.integrate(S.pose0(size), P["integrate_sdf_trunc"], wl.get("integ_dist", P["integrate_depth_trunc"]))
+    _, w = ctx.download_volume()
+    ctx.close()
+    per_layer = (w > 0).reshape(pres, -1).sum(axis=1).astype(np.float64)           # voxels fused per probe z-layer
+    nb = res // 8
+    scale = (res / float(pres)) ** 3                                               # voxel count at full resolution
+    edges = np.linspace(0, pres, nb + 1)
+    cum = np.concatenate([[0.0], np.cumsum(per_layer)])
+    work = np.diff(np.interp(edges, np.arange(pres + 1), cum)) * scale
+    return work.tolist()
 
 
 def merge_candidates(t, v, n, all_reduce_min, all_reduce_sum_i32):
@@ -146,7 +208,7 @@ class SlabPipeline:
     by SlabExchange's two all-reduces.
     """
 
-    def __init__(self, kcam, res, size, wl=None, rank=0, world=1, device=0, max_triangles=0, icp_mode="replicated", tracker="icp"):
+    def __init__(self, kcam, res, size, wl=None, rank=0, world=1, device=0, max_triangles=0, icp_mode="replicated", tracker="icp", ranges=None):
         import torch
         import torch.distributed as dist
         self.icp_mode = icp_mode            # "replicated" (default, faster at VGA) or "allreduce" (pixels split over the ranks)
@@ -157,8 +219,9 @@ class SlabPipeline:
         self.trunc_max = wl.get("trunc_max", P["depth_trunc_max"])
         self.integ_dist = wl.get("integ_dist", P["integrate_depth_trunc"])
         self.inc = P["raycast_increment_factor"] * P["integrate_sdf_trunc"]
-        self.slab = slab_ranges(res, world)[rank]
         self.halo = slab_halo_layers(res, size, self.inc)
+        self.ranges = list(ranges) if ranges is not None else slab_ranges(res, world)        # ranges: e.g. slab_ranges(res, world, probe_layer_work(...), halo)
+        self.slab = self.ranges[rank]
         self.ctx = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=max_triangles, device=device,
                              slab=self.slab, halo=self.halo)
         self.ctx.set_pose(S.pose0(size))

@@ -13,17 +13,25 @@ pytestmark = pytest.mark.gpu
 P = S.STOCK
 
 
-@pytest.mark.parametrize("world,maxw,frames", [(2, P["volume_max_weight"], 3), (4, P["volume_max_weight"], 3),
-                                               (2, 3.0, 9)])       # max_weight 3: from frame 3 on the saturation-aware fusion runs in every context
-def test_slabs_equal_whole_volume(world, maxw, frames):
+@pytest.mark.parametrize("world,maxw,frames,balanced", [(2, P["volume_max_weight"], 3, False), (4, P["volume_max_weight"], 3, False),
+                                                        (2, 3.0, 9, False),       # max_weight 3: from frame 3 on the saturation-aware fusion runs in every context
+                                                        (3, P["volume_max_weight"], 3, True)])   # unequal slabs from the one-frame work probe (bench.py's default for N > 1)
+def test_slabs_equal_whole_volume(world, maxw, frames, balanced):
     cam = S.vga_camera()
     kcam = K.camera(*cam)
     size, res = 3.0, 128
     trunc = 5 * size / res
     inc = 0.7 * trunc
+    halo = PL.slab_halo_layers(res, size, inc)
+    ranges = PL.slab_ranges(res, world)
+    if balanced:
+        first = torch.from_numpy(S.render_depth_mm(S.trajectory_pose(0, size), cam, size).astype(np.int16)).cuda()
+        work = PL.probe_layer_work(kcam, res, size, None, first.data_ptr(), probe_res=64)
+        ranges = PL.slab_ranges(res, world, work, halo=halo)
+        assert ranges != PL.slab_ranges(res, world) and ranges[0][0] == 0 and ranges[-1][1] == res      # the probe moved the boundaries
+        assert abs(sum(work) - 2.0e6) < 1.9e6                                                          # a plausible voxel count (one VGA frame into 128^3 @ 3 m)
     whole = K.Context(kcam, res, size, maxw, levels=3, max_triangles=600000)
-    slabs = [K.Context(kcam, res, size, maxw, levels=3, max_triangles=600000, slab=r, halo=PL.slab_halo_layers(res, size, inc))
-             for r in PL.slab_ranges(res, world)]
+    slabs = [K.Context(kcam, res, size, maxw, levels=3, max_triangles=600000, slab=r, halo=halo) for r in ranges]
     dev = torch.device("cuda", 0)
     bufs = [(torch.empty((cam[1], cam[0]), dtype=torch.float32, device=dev), torch.empty((cam[1], cam[0], 4), dtype=torch.float32, device=dev),
              torch.empty((cam[1], cam[0], 4), dtype=torch.float32, device=dev)) for _ in slabs]
@@ -65,7 +73,7 @@ def test_slabs_equal_whole_volume(world, maxw, frames):
             c.sync()
     # volumes: owned layers of every slab equal the whole volume; update counts add up over the owned layers
     tw, ww = whole.download_volume()
-    for c, (z0, z1) in zip(slabs, PL.slab_ranges(res, world)):
+    for c, (z0, z1) in zip(slabs, ranges):
         t, w = c.download_volume(z0, z1)
         assert np.array_equal(t.view(np.uint32), tw[z0:z1].view(np.uint32)) and np.array_equal(w, ww[z0:z1])
     assert sum(c.stats()["weight_gt0"] for c in slabs) == whole.stats()["weight_gt0"]

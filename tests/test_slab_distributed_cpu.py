@@ -139,3 +139,35 @@ def test_halo_follows_ray_increment():
     assert PL.slab_halo_layers(2048, 4.0, 0.035) == 24
     assert PL.slab_halo_layers(512, 4.0, 0.035) == 8
     assert PL.slab_halo_layers(2048, 8.0, 0.035) == 16
+
+
+def test_balanced_slab_ranges_minimise_the_busiest_rank():
+    """pipeline.slab_ranges with per-layer work: contiguous brick-aligned cover, every rank at least one brick layer, and the busiest rank
+    (own + halo layers) never busier than under equal thickness -- the dynamic programme is exact, checked against brute force on a small case."""
+    import itertools
+    import numpy as np
+    from hybkinectfu_amd import pipeline as PL
+    rng = np.random.default_rng(3)
+    for res, world, halo in ((1024, 4, 8), (1024, 8, 8), (512, 2, 8), (2048, 8, 24), (64, 8, 0), (128, 3, 16)):
+        nb = res // 8
+        z = (np.arange(nb) + 0.5) / nb
+        work = np.where(z < 0.75, (z + 0.05) ** 2, 0.0) * rng.uniform(0.8, 1.2, nb)
+        hb = (halo + 7) // 8
+
+        def busiest(ranges):
+            return max(work[max(0, a // 8 - hb):min(nb, b // 8 + hb)].sum() for a, b in ranges)
+        bal, eq = PL.slab_ranges(res, world, work.tolist(), halo=halo), PL.slab_ranges(res, world)
+        for ranges in (bal, eq):
+            assert ranges[0][0] == 0 and ranges[-1][1] == res and all(a % 8 == 0 and b % 8 == 0 and b > a for a, b in ranges)
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+        assert busiest(bal) <= busiest(eq) * (1 + 1e-9)
+    # brute force on 12 brick layers, 4 ranks
+    res, world = 96, 4
+    work = rng.uniform(0.0, 1.0, 12); work[8:] = 0.0
+    bal = PL.slab_ranges(res, world, work.tolist(), halo=8)
+    best = min(max(work[max(0, c[i] - 1):min(12, c[i + 1] + 1)].sum() for i in range(world))
+               for cuts in itertools.combinations(range(1, 12), world - 1) for c in [(0,) + cuts + (12,)])
+    got = max(work[max(0, a // 8 - 1):min(12, b // 8 + 1)].sum() for a, b in bal)
+    assert got <= best * (1 + 1e-6)
+    with pytest.raises(ValueError):
+        PL.slab_ranges(64, 9)
