@@ -29,7 +29,7 @@ def test_slabs_equal_whole_volume(world, maxw, frames, balanced):
         work = PL.probe_layer_work(kcam, res, size, None, first.data_ptr(), probe_res=64)
         ranges = PL.slab_ranges(res, world, work, halo=halo)
         assert ranges != PL.slab_ranges(res, world) and ranges[0][0] == 0 and ranges[-1][1] == res      # the probe moved the boundaries
-        assert abs(sum(work) - 2.0e6) < 1.9e6                                                          # a plausible voxel count (one VGA frame into 128^3 @ 3 m)
+        assert 1.0e4 < sum(work) < 2.1e6 and len(work) == res // 8                                      # a plausible voxel count per frame (128^3 holds 2.1 M voxels)
     whole = K.Context(kcam, res, size, maxw, levels=3, max_triangles=600000)
     slabs = [K.Context(kcam, res, size, maxw, levels=3, max_triangles=600000, slab=r, halo=halo) for r in ranges]
     dev = torch.device("cuda", 0)
