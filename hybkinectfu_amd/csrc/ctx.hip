@@ -531,6 +531,19 @@ void kf_evt_begin(kf_ctx* c, int s) {
   if (!c->ev[s][0][c->ev_n[s]]) { (void)hipEventCreate(&c->ev[s][0][c->ev_n[s]]); (void)hipEventCreate(&c->ev[s][1][c->ev_n[s]]); }
   (void)hipEventRecord(c->ev[s][0][c->ev_n[s]], c->stream);
 }
+// A kernel timed by its OWN dispatch: the event pair is handed to hipExtLaunchKernelGGL, which stamps it with the dispatch's start and end
+// (what rocprofv3 reports as the kernel's duration) instead of two separate event records around the launch -- those add the records' own
+// latency, ~3-5 us, which is a quarter of a 19 us kernel.  Returns false when this interval is not sampled (launch plainly); on true the
+// caller launches with (*e0, *e1) and then calls kf_evt_attached_done.
+bool kf_evt_attach(kf_ctx* c, int s, hipEvent_t* e0, hipEvent_t* e1) {
+  if (!(c->timers_enabled & (1 << s))) return false;
+  if ((c->ev_seen[s]++ % c->timers_period) != 0) return false;
+  if (c->ev_n[s] == 64) evt_fold(c, s);
+  if (!c->ev[s][0][c->ev_n[s]]) { (void)hipEventCreate(&c->ev[s][0][c->ev_n[s]]); (void)hipEventCreate(&c->ev[s][1][c->ev_n[s]]); }
+  *e0 = c->ev[s][0][c->ev_n[s]]; *e1 = c->ev[s][1][c->ev_n[s]];
+  return true;
+}
+void kf_evt_attached_done(kf_ctx* c, int s) { c->ev_n[s] += 1; }
 void kf_evt_end(kf_ctx* c, int s) {
   if (!(c->timers_enabled & (1 << s)) || !c->ev_open[s]) return;
   c->ev_open[s] = 0;

@@ -12,6 +12,7 @@
 //     updated-voxel count and the tsdf/weight bits match the CPU oracle exactly;
 //   * per-brick flags (observed / has-negative) are maintained here; raycast and marching cubes use them to skip space.
 #include "kf_internal.h"
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 
 struct IntegrateArgs {
@@ -785,17 +786,21 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   static unsigned grid_cap = 0;                          // workgroups walking the queue: tuning knob
   if (!grid_cap) { const char* e = getenv("KF_INTEGRATE_GRID"); grid_cap = e ? (unsigned)atoi(e) : 8192u; if (grid_cap < 64u || grid_cap > 65536u) grid_cap = 8192u; }
   unsigned grid = (unsigned)(c->n_stored_bricks < grid_cap ? c->n_stored_bricks : grid_cap);
-  kf_evt_begin(c, KF_STAGE_INTEGRATE_KERNEL);
+  // the roofline kernel's live timer: the event pair rides on the dispatch itself (kf_evt_attach), so what is measured is the kernel, as rocprofv3 sees it
+  hipEvent_t ke0 = nullptr, ke1 = nullptr;
+  const bool timed = kf_evt_attach(c, KF_STAGE_INTEGRATE_KERNEL, &ke0, &ke1);
+#define FUSE_LAUNCH(K) do { if (timed) hipExtLaunchKernelGGL(K, dim3(grid), dim3(256), 0, c->stream, ke0, ke1, 0, a); \
+                            else hipLaunchKernelGGL(K, dim3(grid), dim3(256), 0, c->stream, a); } while (0)
   static int color_pairs = -1;                            // 1 (default): colour through the packed-pair kernel; 0: the scalar kernel (A/B)
   if (color_pairs < 0) { const char* e = getenv("KF_INTEGRATE_COLOR_PAIRS"); color_pairs = e ? atoi(e) : 1; }
   if (has_color && color_pairs) {
     static int cbr = -1;                                   // bricks in flight per workgroup of the colour variant (KF_INTEGRATE_BR overrides)
     if (cbr < 0) { const char* e = getenv("KF_INTEGRATE_BR"); cbr = e ? atoi(e) : 2; if (cbr != 1 && cbr != 2 && cbr != 4) cbr = 2; }
-    if (cbr == 1) hipLaunchKernelGGL((k_integrate_pairs<1, false, true>), dim3(grid), dim3(256), 0, c->stream, a);
-    else if (cbr == 2) hipLaunchKernelGGL((k_integrate_pairs<2, false, true>), dim3(grid), dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL((k_integrate_pairs<4, false, true>), dim3(grid), dim3(256), 0, c->stream, a);
+    if (cbr == 1) FUSE_LAUNCH((k_integrate_pairs<1, false, true>));
+    else if (cbr == 2) FUSE_LAUNCH((k_integrate_pairs<2, false, true>));
+    else FUSE_LAUNCH((k_integrate_pairs<4, false, true>));
   }
-  else if (has_color) hipLaunchKernelGGL((k_integrate_bricks<true, 1>), dim3(grid), dim3(256), 0, c->stream, a);
+  else if (has_color) FUSE_LAUNCH((k_integrate_bricks<true, 1>));
   else {
     // bricks in flight per workgroup: 2, or 4 when the stored volume is large enough for the queue to hold >~100k bricks
     // (measured: 512^3 24 us with 2 vs 25 us with 4; 1024^3 378 us with 2 vs 358 us with 4).  KF_INTEGRATE_BR overrides.
@@ -805,26 +810,27 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
     static int pairs = -1;                               // 1 (default): the packed-pair kernel; 0: the scalar one (A/B and colour path)
     if (pairs < 0) { const char* e = getenv("KF_INTEGRATE_PAIRS"); pairs = e ? atoi(e) : 1; }
 #ifdef KF_EXPERIMENTS
-    if (a.exp_mode == 4) hipLaunchKernelGGL((k_exp_brick_rmw<4, 0>), dim3(grid), dim3(256), 0, c->stream, a);
-    else if (a.exp_mode == 5) hipLaunchKernelGGL((k_exp_brick_rmw<4, 1>), dim3(grid), dim3(256), 0, c->stream, a);
-    else if (a.exp_mode == 6) hipLaunchKernelGGL((k_exp_brick_rmw<4, 2>), dim3(grid), dim3(256), 0, c->stream, a);
-    else if (a.exp_mode == 7) hipLaunchKernelGGL((k_exp_brick_rmw<4, 3>), dim3(grid), dim3(256), 0, c->stream, a);
-    else if (a.exp_mode == 12) hipLaunchKernelGGL((k_exp_brick_rmw<4, 4>), dim3(grid), dim3(256), 0, c->stream, a);
+    if (a.exp_mode == 4) FUSE_LAUNCH((k_exp_brick_rmw<4, 0>));
+    else if (a.exp_mode == 5) FUSE_LAUNCH((k_exp_brick_rmw<4, 1>));
+    else if (a.exp_mode == 6) FUSE_LAUNCH((k_exp_brick_rmw<4, 2>));
+    else if (a.exp_mode == 7) FUSE_LAUNCH((k_exp_brick_rmw<4, 3>));
+    else if (a.exp_mode == 12) FUSE_LAUNCH((k_exp_brick_rmw<4, 4>));
     else
 #endif
     if (pairs) {
       if (sat) {
-        if (br == 1) hipLaunchKernelGGL((k_integrate_pairs<1, true>), dim3(grid), dim3(256), 0, c->stream, a);
-        else if (br == 2) hipLaunchKernelGGL((k_integrate_pairs<2, true>), dim3(grid), dim3(256), 0, c->stream, a);
-        else hipLaunchKernelGGL((k_integrate_pairs<4, true>), dim3(grid), dim3(256), 0, c->stream, a);
-      } else if (br == 1) hipLaunchKernelGGL((k_integrate_pairs<1, false>), dim3(grid), dim3(256), 0, c->stream, a);
-      else if (br == 2) hipLaunchKernelGGL((k_integrate_pairs<2, false>), dim3(grid), dim3(256), 0, c->stream, a);
-      else hipLaunchKernelGGL((k_integrate_pairs<4, false>), dim3(grid), dim3(256), 0, c->stream, a);
-    } else if (br == 1) hipLaunchKernelGGL((k_integrate_bricks<false, 1>), dim3(grid), dim3(256), 0, c->stream, a);
-    else if (br == 2) hipLaunchKernelGGL((k_integrate_bricks<false, 2>), dim3(grid), dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL((k_integrate_bricks<false, 4>), dim3(grid), dim3(256), 0, c->stream, a);
+        if (br == 1) FUSE_LAUNCH((k_integrate_pairs<1, true>));
+        else if (br == 2) FUSE_LAUNCH((k_integrate_pairs<2, true>));
+        else FUSE_LAUNCH((k_integrate_pairs<4, true>));
+      } else if (br == 1) FUSE_LAUNCH((k_integrate_pairs<1, false>));
+      else if (br == 2) FUSE_LAUNCH((k_integrate_pairs<2, false>));
+      else FUSE_LAUNCH((k_integrate_pairs<4, false>));
+    } else if (br == 1) FUSE_LAUNCH((k_integrate_bricks<false, 1>));
+    else if (br == 2) FUSE_LAUNCH((k_integrate_bricks<false, 2>));
+    else FUSE_LAUNCH((k_integrate_bricks<false, 4>));
   }
-  kf_evt_end(c, KF_STAGE_INTEGRATE_KERNEL);
+#undef FUSE_LAUNCH
+  if (timed) kf_evt_attached_done(c, KF_STAGE_INTEGRATE_KERNEL);
   kf_evt_end(c, KF_STAGE_INTEGRATE);
   if (c->fuse_calls != 0xFFFFFFFFu) ++c->fuse_calls;
   return (int)hipGetLastError();

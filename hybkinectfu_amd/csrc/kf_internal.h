@@ -178,6 +178,8 @@ enum { KF_STAGE_UPLOAD = 0, KF_STAGE_PREPROCESS = 1, KF_STAGE_TRACK = 2, KF_STAG
        KF_STAGE_INTEGRATE_KERNEL = 5, KF_STAGE_MCUBES = 6, KF_STAGE_RAYCAST_KERNEL = 7 };
 void kf_evt_begin(kf_ctx* c, int stage);
 void kf_evt_end(kf_ctx* c, int stage);
+bool kf_evt_attach(kf_ctx* c, int stage, hipEvent_t* e0, hipEvent_t* e1);     // events stamped by the kernel's own dispatch (hipExtLaunchKernelGGL)
+void kf_evt_attached_done(kf_ctx* c, int stage);
 
 #define KF_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
 
