@@ -72,7 +72,11 @@ int kf_device_shared(int device) {
   KfShmDevice* t = (device >= 0 && device < 64) ? g_shm[device] : nullptr;
   if (!t) return 0;
   const unsigned gen = __atomic_load_n(&t->gen, __ATOMIC_ACQUIRE);
-  if (gen != g_shm_seen_gen[device]) {
+  // rescan when the table changed -- and every 512th call while somebody else is listed: a process that died without unregistering
+  // bumps no generation, and its slot must not keep the survivors on per-step launches for good
+  static unsigned calls[64];
+  const bool periodic = g_shm_others[device] > 0 && (++calls[device] & 511u) == 0u;
+  if (gen != g_shm_seen_gen[device] || periodic) {
     const int me = (int)getpid();
     int others = 0;
     for (int i = 0; i < 62; ++i) { const int p = __atomic_load_n(&t->pids[i], __ATOMIC_RELAXED); if (p != 0 && p != me && pid_alive(p)) ++others; }
