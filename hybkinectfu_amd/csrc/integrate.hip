@@ -384,9 +384,6 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
 // the camera gets a harmless divisor and is masked at the end), and the pixel rounding uses floor(p + 0.5f), which equals the
 // reference's (int)(p + 0.5) in double for every p the bounds test can accept (exact sum below 2^23; checked exhaustively near every
 // binade boundary by the CPU test test_pixel_rounding_floor_form_equals_reference_double_form).
-typedef float kf_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ kf_f2 f2_splat(float a) { kf_f2 r = {a, a}; return r; }
-__device__ __forceinline__ kf_f2 f2_fma(kf_f2 a, kf_f2 b, kf_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 struct KfRecip2 { kf_f2 den, r; };
 __device__ __forceinline__ KfRecip2 kf_recip2(kf_f2 b) {                   // kf_recip on both halves
   kf_f2 r0 = {__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};

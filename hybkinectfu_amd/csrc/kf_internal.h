@@ -224,6 +224,11 @@ __device__ __forceinline__ float3 kf_mat_point3(const float* m, float x, float y
              m[8] * x + m[9] * y + m[10] * z + m[11] * w);
 }
 
+// two fp32 values carried as one operand of gfx950's packed instructions (v_pk_mul / add / fma_f32: one issue slot for both)
+typedef float kf_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ kf_f2 f2_splat(float a) { kf_f2 r = {a, a}; return r; }
+__device__ __forceinline__ kf_f2 f2_fma(kf_f2 a, kf_f2 b, kf_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 // identity the compiler cannot see through: the value becomes lane-varying as far as it knows (no instruction is emitted)
 __device__ __forceinline__ unsigned kf_opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 

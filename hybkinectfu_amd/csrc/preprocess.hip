@@ -79,7 +79,14 @@ __global__ void __launch_bounds__(256) k_bilateral(const float* __restrict__ in,
 // (cleared) tables with fire-and-forget integer atomic maxima -- non-negative floats order like their bit patterns.  That replaces
 // a launch of its own (k_integrate_prepare) in front of every integrate.  acc.tile == nullptr: tables not wanted.
 struct KfTileAccum { int* tile; int off0, w0, off1, w1, n; float max_dist; };   // n: entries of both maxima tables = offset of the minima (0: minima not wanted)
-template <int R>
+// FAST (every sane parameter set; the host decides): an invalid pixel sits in the LDS tile as a huge sentinel instead of 0, so its tap needs
+// no special case -- the squared difference sends the exponent to -inf, exp2 gives exactly +0, and 0 * sentinel adds exactly +0 to the
+// weighted sum -- and the difference / square / exponent of two taps are one packed instruction each.  Tap order and every rounded
+// operation of a valid tap are those of the plain loop: the same bits (per-call kernel == fused kernel stays a bit-exact test), a
+// quarter fewer vector instructions in a kernel that is bound by them (81 taps per pixel).
+#define BIL_SENTINEL 1e18f
+#define BIL_SENTINEL_CUT 1e17f
+template <int R, bool FAST>
 __global__ void __launch_bounds__(256) k_gate_bilateral(const uint16_t* __restrict__ mm, const float* __restrict__ raw_in,
                                                         float* __restrict__ raw_out, float* __restrict__ trunced, float* __restrict__ filtered,
                                                         int cols, int rows, float tmin, float tmax, float ss_inv, float sd_inv, float sigma_depth,
@@ -96,13 +103,14 @@ __global__ void __launch_bounds__(256) k_gate_bilateral(const uint16_t* __restri
       const bool interior = lx >= R && lx < R + BIL_TX && ly >= R && ly < R + BIL_TY;              // written exactly once
       if (interior) { if (mm) raw_out[gy * cols + gx] = d; trunced[gy * cols + gx] = g; }
     }
-    tile[i] = g;
+    tile[i] = (FAST && g == 0.f) ? BIL_SENTINEL : g;
   }
   __syncthreads();
   const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
   const int x = blockIdx.x * BIL_TX + lx, y = blockIdx.y * BIL_TY + ly;
   const bool inside = x < cols && y < rows;
-  const float value = inside ? tile[(ly + R) * TW + lx + R] : 0.f;
+  float value = inside ? tile[(ly + R) * TW + lx + R] : 0.f;
+  if (FAST && value > BIL_SENTINEL_CUT) value = 0.f;       // (the centre pixel itself is invalid)
   if (acc.tile) {                                          // uniform; every lane of the wave takes part in the DPP steps
     float d = (value < acc.max_dist) ? value : 0.f;
     d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0xB1, 0xf, 0xf, true)));    // quad_perm:[1,0,3,2]
@@ -128,26 +136,54 @@ __global__ void __launch_bounds__(256) k_gate_bilateral(const uint16_t* __restri
   float result = value;
   if (value != 0.f) {
     float sum1 = 0.f, sum2 = 0.f;
-    float max_diff = 0.f;                                  // largest |tap - centre| over the valid taps: the 5-sigma test, once
     const float thr = 5 * sigma_depth;
     const float c_ss = ss_inv * KF_LOG2E, c_sd = -(sd_inv * KF_LOG2E);
+    if (FAST) {
+      const kf_f2 v2 = f2_splat(value), csd2 = f2_splat(c_sd);
+      bool over = false;                                   // some VALID tap differs from the centre by more than 5 sigma (:66-69)
 #pragma unroll
-    for (int dy = -R; dy <= R; ++dy) {
-      float row[2 * R + 1];
+      for (int dy = -R; dy <= R; ++dy) {
+        float row[2 * R + 2], dif[2 * R + 2], ex[2 * R + 2];
 #pragma unroll
-      for (int dx = -R; dx <= R; ++dx) row[dx + R] = tile[(ly + R + dy) * TW + lx + R + dx];
+        for (int dx = -R; dx <= R; ++dx) row[dx + R] = tile[(ly + R + dy) * TW + lx + R + dx];
+        row[2 * R + 1] = value;
 #pragma unroll
-      for (int dx = -R; dx <= R; ++dx) {
-        const float tmp = row[dx + R];
-        const bool valid = tmp != 0.f;
-        const float diff = value - tmp;
-        max_diff = fmaxf(max_diff, valid ? fabsf(diff) : 0.f);
-        const float wv = kf_bilateral_weight(diff, (float)(dx * dx + dy * dy), c_ss, c_sd);
-        const float w = valid ? wv : 0.f;                   // an invalid tap adds +0 to both sums: the loop stays straight-line
-        sum1 = __builtin_fmaf(tmp, w, sum1); sum2 += w;
+        for (int k = 0; k <= 2 * R; k += 2) {              // two taps per packed instruction: difference, square, exponent
+          const kf_f2 t2 = {row[k], row[k + 1]};
+          const kf_f2 sp = {-((float)((k - R) * (k - R) + dy * dy) * c_ss), -((float)((k + 1 - R) * (k + 1 - R) + dy * dy) * c_ss)};
+          const kf_f2 d2 = v2 - t2;
+          const kf_f2 e2 = f2_fma(d2 * d2, csd2, sp);
+          dif[k] = d2.x; dif[k + 1] = d2.y; ex[k] = e2.x; ex[k + 1] = e2.y;
+        }
+#pragma unroll
+        for (int k = 0; k <= 2 * R; ++k) {                 // the sums in the plain loop's tap order
+          const float ad = fabsf(dif[k]);
+          over = over || (ad > thr && ad < BIL_SENTINEL_CUT);
+          const float w = __builtin_amdgcn_exp2f(ex[k]);
+          sum1 = __builtin_fmaf(row[k], w, sum1); sum2 += w;
+        }
       }
+      if (!over && sum2 > 0.f) result = sum1 / sum2;
+    } else {
+      float max_diff = 0.f;                                // largest |tap - centre| over the valid taps: the 5-sigma test, once
+#pragma unroll
+      for (int dy = -R; dy <= R; ++dy) {
+        float row[2 * R + 1];
+#pragma unroll
+        for (int dx = -R; dx <= R; ++dx) row[dx + R] = tile[(ly + R + dy) * TW + lx + R + dx];
+#pragma unroll
+        for (int dx = -R; dx <= R; ++dx) {
+          const float tmp = row[dx + R];
+          const bool valid = tmp != 0.f;
+          const float diff = value - tmp;
+          max_diff = fmaxf(max_diff, valid ? fabsf(diff) : 0.f);
+          const float wv = kf_bilateral_weight(diff, (float)(dx * dx + dy * dy), c_ss, c_sd);
+          const float w = valid ? wv : 0.f;                 // an invalid tap adds +0 to both sums: the loop stays straight-line
+          sum1 = __builtin_fmaf(tmp, w, sum1); sum2 += w;
+        }
+      }
+      if (!(max_diff > thr) && sum2 > 0.f) result = sum1 / sum2;
     }
-    if (!(max_diff > thr) && sum2 > 0.f) result = sum1 / sum2;
   }
   filtered[y * cols + x] = result;
 }
@@ -334,8 +370,12 @@ static int launch_fused_preprocess(kf_ctx* c, hipStream_t stream, const uint16_t
     acc.off0 = 0; acc.w0 = kf_div_up(c->cols, 8); acc.off1 = acc.w0 * kf_div_up(c->rows, 8); acc.w1 = kf_div_up(c->cols, 16);
     acc.n = kf_sat_regime(c) ? c->n_tile_floats : 0;         // the minima only matter once saturated free space can exist
   }
-  hipLaunchKernelGGL(k_gate_bilateral<4>, grid, dim3(256), 0, stream, mm, raw_in, raw_out, trunced, filtered, c->cols, c->rows, tmin, tmax,
-                     ss_inv, sd_inv, sigma_depth, acc);
+  // the sentinel form needs every valid depth far below the sentinel and the sentinel's tap weight to underflow to exactly zero
+  const bool fast = tmax < 1e15f && sd_inv * KF_LOG2E > 1e-30f && sd_inv * KF_LOG2E < 1e30f;
+  if (fast) hipLaunchKernelGGL((k_gate_bilateral<4, true>), grid, dim3(256), 0, stream, mm, raw_in, raw_out, trunced, filtered, c->cols, c->rows, tmin, tmax,
+                               ss_inv, sd_inv, sigma_depth, acc);
+  else hipLaunchKernelGGL((k_gate_bilateral<4, false>), grid, dim3(256), 0, stream, mm, raw_in, raw_out, trunced, filtered, c->cols, c->rows, tmin, tmax,
+                          ss_inv, sd_inv, sigma_depth, acc);
   dim3 grid2(kf_div_up(c->cols, 64), kf_div_up(c->rows, 4));
   hipLaunchKernelGGL(k_vertices_normals, grid2, dim3(256), 0, stream, filtered, v0, n0, to_cam(cam));
   return (int)hipGetLastError();
