@@ -512,3 +512,42 @@ def test_work_counters_match_the_oracle_march():
     assert cnt[7] == 1 and cnt[6] == 1 and ms[7] > 0 and ms[6] > 0
     ctx.stage_timers(0)
     ctx.close()
+
+
+@pytest.mark.parametrize("angled", [False, True])
+def test_integrate_color_vga_color_camera_bit_exact(angled):
+    """The colour path where it actually lands: the reference projects voxels into the colour image with its literal 525 / 320 / 240
+    intrinsics (integrateVolume.cu:56-57), so only a VGA-sized colour camera sees most of them (test_integrate_color_bit_exact's 64x48
+    colour image rejects almost every voxel at the window test).  Packed-pair colour fusion (k_integrate_pairs<.., COLOR>) against the oracle:
+    update counts, tsdf / weight planes, colour bytes of every observed voxel, raycast colour map; with and without the angle weight; three
+    frames so that the running average sees old weights 0, 1, 2."""
+    size, res, cam = 3.0, 64, mid_cam()
+    rcam = (640, 480, 319.5, 239.5, 525.0, 525.0)
+    ocam, kcam, orcam, krcam = O.Cam.make(*cam), K.camera(*cam), O.Cam.make(*rcam), K.camera(*rcam)
+    trunc = 5 * size / res
+    ctx = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, has_color=True, rgb_cam=krcam)
+    ovol = O.OVolume(res, size, P["volume_max_weight"])
+    rng = np.random.default_rng(11)
+    n_colored = 0
+    for k in range(3):
+        pose = S.trajectory_pose(3 * k, size).astype(np.float32)
+        mm = S.render_depth_mm(pose, cam, size)
+        d, tr, fl, v, n = oracle_preprocess(mm, ocam)
+        rgb = rng.integers(0, 256, (480, 640, 3)).astype(np.uint8)
+        n_o = O.integrate(ovol, tr, n, rgb, True, angled, pose, trunc, 2.5, ocam, orcam)
+        ctx.upload_depth_mm(mm)
+        ctx.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+        ctx.upload_map(K.MAP_NEW_NORMALS, 0, n)                 # identical normals for the angle weight (the bilateral differs in last bits)
+        ctx.upload_rgb(rgb)
+        ctx.integrate(pose, trunc, 2.5, has_color=True, angle_weight=angled)
+        assert ctx.stats()["updated_last"] == n_o and n_o > 10000
+        n_colored += n_o
+    t, w, c = ctx.download_volume(color=True)
+    assert np.array_equal(bits(t), bits(ovol.tsdf)) and np.array_equal(bits(w), bits(ovol.weight))
+    seen = ovol.weight > 0
+    assert np.array_equal(c[seen], ovol.color[seen]) and int(np.count_nonzero(ovol.color[seen])) > 10000
+    ov, on, orgb = O.raycast(ovol, True, pose, 0.7 * trunc, ocam, 0.3, 4.0)
+    ctx.raycast(pose, 0.7 * trunc, 0.3, 4.0, has_color=True)
+    assert np.array_equal(bits(ctx.download_map(K.MAP_MODEL_VERTICES)), bits(ov))
+    assert np.array_equal(ctx.download_map(K.MAP_RAYCAST_RGB), orgb) and int(np.count_nonzero(orgb)) > 1000
+    ctx.close()
