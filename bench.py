@@ -125,13 +125,13 @@ def single_gpu_reference(name, n_frames=50, warmup=10, n_unique=None, overrides=
     if wl.get("color"):
         pipe.ctx.upload_rgb(np.random.default_rng(1).integers(0, 256, (cam[1], cam[0], 3)).astype(np.uint8))
     for k in range(warmup):
-        pipe.process_frame_device(dev.data_ptr() + at(k) * fb, k)
+        pipe.process_frame_device(dev.data_ptr() + at(k) * fb, k, dev.data_ptr() + at(k + 1) * fb)
     pipe.sync(); torch.cuda.synchronize()
     s0 = pipe.stats()
     pipe.stage_timers((1 << 2) | (1 << 3) | (1 << 4) | (1 << 5) | (4 << 8))
     t0 = time.perf_counter()
     for k in range(warmup, n_frames):
-        pipe.process_frame_device(dev.data_ptr() + at(k) * fb, k)
+        pipe.process_frame_device(dev.data_ptr() + at(k) * fb, k, dev.data_ptr() + at(k + 1) * fb)
     pipe.sync(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms, cnt = pipe.read_stage_ms()
@@ -170,13 +170,13 @@ def steady_state(name, n_timed=100):
     pipe = SingleGpuPipeline(K.camera(*cam), wl["res"], wl["size"], wl, device=torch.cuda.current_device())
     n_pre = int(P["volume_max_weight"]) + 32
     for k in range(n_pre):
-        pipe.process_frame_device(dev.data_ptr() + (k % 100) * fb, k)
+        pipe.process_frame_device(dev.data_ptr() + (k % 100) * fb, k, dev.data_ptr() + ((k + 1) % 100) * fb)
     pipe.sync(); torch.cuda.synchronize()
     s0 = pipe.stats()
     pipe.stage_timers((1 << 5) | (1 << 3) | (4 << 8))
     t0 = time.perf_counter()
     for k in range(n_pre, n_pre + n_timed):
-        pipe.process_frame_device(dev.data_ptr() + (k % 100) * fb, k)
+        pipe.process_frame_device(dev.data_ptr() + (k % 100) * fb, k, dev.data_ptr() + ((k + 1) % 100) * fb)
     pipe.sync(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms, cnt = pipe.read_stage_ms()
@@ -452,7 +452,10 @@ def main():
                     help="multi-GPU tracking: every rank runs the whole ICP (default) or pixels are split and the 27-float system all-reduced")
     ap.add_argument("--no-scaling-reference", action="store_true",
                     help="skip the extra 50-frame run of the multi-GPU workload (C4) on this one GPU that the N=1 line reports beside the headline")
-    ap.add_argument("--prefetch", action="store_true", help="preprocess frame k+1 on a side stream while frame k is tracked (measured neutral at VGA)")
+    ap.add_argument("--prefetch", action="store_true", help="(default now; kept for old command lines)")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="do not hand the pipeline the next frame's address: by default frame k+1's depth conversion + gate + bilateral filter ride in frame k's "
+                         "raycast launch (kf_prefetch_frame, fused form) -- the frames are a resident stream, the work per frame is the same, one frame earlier")
     ap.add_argument("--force-slab", action="store_true", help="run the z-slab pipeline (and its collectives) even with one rank")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL, one GPU per rank (the measured configuration).  gloo: rehearsal only -- ranks may SHARE a GPU "
@@ -520,7 +523,7 @@ def main():
         # --prefetch: frame k+1 is preprocessed on the context's side stream while frame k is tracked (kf_prefetch_frame)
         for k in range(first, first + count):
             # (the z-slab pipeline always gets the hint: it fills the wait for its first all-reduce with the next frame's preprocess)
-            nxt = dev_frames.data_ptr() + ((k + 1) % n_unique) * frame_bytes if (args.prefetch or slab) else None
+            nxt = dev_frames.data_ptr() + ((k + 1) % n_unique) * frame_bytes if (slab or not args.no_prefetch) else None
             pipe.process_frame_device(dev_frames.data_ptr() + (k % n_unique) * frame_bytes, k, nxt)
 
     def barrier():

@@ -1,0 +1,155 @@
+// bilateral_tile.h -- the fused u16 -> f32 + depth gate + bilateral filter of one 64x4 pixel tile (DataPreprocesser.cu:17-79,
+// HybKinectfu.cpp:63-96), shared by k_gate_bilateral (preprocess.hip) and by the raycast launch that carries the NEXT frame's filter along
+// (raycast.hip: k_raycast_prefetch).
+#pragma once
+#include "kf_internal.h"
+
+#define BIL_TX 64
+#define BIL_TY 4
+#define BIL_MAXR 8
+
+// Bilateral tap weight exp(-(space2 * ss_inv + diff^2 * sd_inv)) (DataPreprocesser.cu:70-73, __expf there) as ONE hardware exp2: the two
+// factors carry log2(e) already, the sum is a fused multiply-add.  The filter is tolerance-checked (2e-6 relative: the reference's fast
+// intrinsic is not reproducible on any other target anyway); the per-call kernel and the fused one share this function and their tap
+// order, so they still agree bit for bit.
+#define KF_LOG2E 1.44269504f
+__device__ __forceinline__ float kf_bilateral_weight(float diff, float space2, float c_ss, float c_sd) {
+  return __builtin_amdgcn_exp2f(__builtin_fmaf(diff * diff, c_sd, -(space2 * c_ss)));
+}
+
+
+// Fused front end of HybKinectfu::processNewFrame (src/HybKinectfu.cpp:63-110): u16 mm -> f32 m (:73), range gate
+// (DataPreprocesser.cu:17-36) and bilateral filter (:37-79) in ONE launch.  The (64+2R)x(4+2R) gated tile lives in LDS; the
+// R x R tap loop is fully unrolled and branch-free: a zero (invalid or out-of-image) tap gets weight 0 -- adding +0 leaves the
+// reference's running sums bit-identical -- and the reference's early `return` (any tap further than 5 sigma_d away keeps the
+// unfiltered value, :66-69) becomes a flag tested once at the end.
+// The kernel also leaves the TSDF integration's tile maxima behind (integrate.hip: the max, over every 8x8 and 16x16 pixel tile, of
+// the gated depth that can integrate, d < max_dist): the gated tile is in LDS anyway, a wave is one 64-pixel row, so three DPP
+// steps give the max of each 8-pixel group and one more that of each 16-pixel group, and the group leaders merge them into the
+// (cleared) tables with fire-and-forget integer atomic maxima -- non-negative floats order like their bit patterns.  That replaces
+// a launch of its own (k_integrate_prepare) in front of every integrate.  acc.tile == nullptr: tables not wanted.
+struct KfTileAccum { int* tile; int off0, w0, off1, w1, n; float max_dist; };   // n: entries of both maxima tables = offset of the minima (0: minima not wanted)
+// FAST (every sane parameter set; the host decides): an invalid pixel sits in the LDS tile as a huge sentinel instead of 0, so its tap needs
+// no special case -- the squared difference sends the exponent to -inf, exp2 gives exactly +0, and 0 * sentinel adds exactly +0 to the
+// weighted sum -- and the difference / square / exponent of two taps are one packed instruction each.  Tap order and every rounded
+// operation of a valid tap are those of the plain loop: the same bits (per-call kernel == fused kernel stays a bit-exact test), a
+// quarter fewer vector instructions in a kernel that is bound by them (81 taps per pixel).
+#define BIL_SENTINEL 1e18f
+#define BIL_SENTINEL_CUT 1e17f
+struct KfBilateralArgs {
+  const uint16_t* mm; const float* raw_in;       // the frame as u16 millimetres (converted here), or an f32 metre image
+  float* raw_out; float* trunced; float* filtered;
+  int cols, rows;
+  float tmin, tmax, ss_inv, sd_inv, sigma_depth;
+  KfTileAccum acc;
+};
+// tile (bx, by) by 256 threads (tid 0..255) with `tile` their (BIL_TX + 2R) x (BIL_TY + 2R) floats of LDS; every thread of the calling
+// workgroup must come through here (one workgroup barrier inside), whether or not its tile lies in the image
+template <int R, bool FAST>
+__device__ __forceinline__ void kf_bilateral_tile(const KfBilateralArgs& b, int bx, int by, int tid, float* tile) {
+  const uint16_t* __restrict__ mm = b.mm; const float* __restrict__ raw_in = b.raw_in;
+  float* __restrict__ raw_out = b.raw_out; float* __restrict__ trunced = b.trunced; float* __restrict__ filtered = b.filtered;
+  const int cols = b.cols, rows = b.rows;
+  const float tmin = b.tmin, tmax = b.tmax, ss_inv = b.ss_inv, sd_inv = b.sd_inv, sigma_depth = b.sigma_depth;
+  const KfTileAccum acc = b.acc;
+  constexpr int TW = BIL_TX + 2 * R, TH = BIL_TY + 2 * R;
+  const int x0 = bx * BIL_TX - R, y0 = by * BIL_TY - R;
+  for (int i = tid; i < TW * TH; i += 256) {
+    const int lx = i % TW, ly = i / TW, gx = x0 + lx, gy = y0 + ly;
+    float g = 0.f;
+    if (gx >= 0 && gx < cols && gy >= 0 && gy < rows) {
+      const float d = mm ? (float)((double)mm[gy * cols + gx] * 0.001) : raw_in[gy * cols + gx];   // HybKinectfu.cpp:73
+      g = (d < tmax && d > tmin) ? d : 0.f;                                                        // DataPreprocesser.cu:25-33
+      const bool interior = lx >= R && lx < R + BIL_TX && ly >= R && ly < R + BIL_TY;              // written exactly once
+      if (interior) { if (mm) raw_out[gy * cols + gx] = d; trunced[gy * cols + gx] = g; }
+    }
+    tile[i] = (FAST && g == 0.f) ? BIL_SENTINEL : g;
+  }
+  __syncthreads();
+  const int lx = tid & 63, ly = tid >> 6;
+  const int x = bx * BIL_TX + lx, y = by * BIL_TY + ly;
+  const bool inside = x < cols && y < rows;
+  float value = inside ? tile[(ly + R) * TW + lx + R] : 0.f;
+  if (FAST && value > BIL_SENTINEL_CUT) value = 0.f;       // (the centre pixel itself is invalid)
+  if (acc.tile) {                                          // uniform; every lane of the wave takes part in the DPP steps
+    float d = (value < acc.max_dist) ? value : 0.f;
+    d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0xB1, 0xf, 0xf, true)));    // quad_perm:[1,0,3,2]
+    d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x4E, 0xf, 0xf, true)));    // quad_perm:[2,3,0,1]
+    d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x141, 0xf, 0xf, true)));   // row_half_mirror: 8-pixel groups
+    const float d16 = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x140, 0xf, 0xf, true)));   // row_mirror: 16-pixel groups
+    // a group whose leader lies outside the image holds no pixel at all (d == 0): the indices below stay inside the tables
+    if ((lx & 7) == 0 && d > 0.f) atomicMax(acc.tile + acc.off0 + (y >> 3) * acc.w0 + (x >> 3), __float_as_int(d));
+    if ((lx & 15) == 0 && d16 > 0.f) atomicMax(acc.tile + acc.off1 + (y >> 4) * acc.w1 + (x >> 4), __float_as_int(d16));
+    // the tile MINIMA (second half of the buffer, cleared to +inf): 0 as soon as one pixel of the tile cannot integrate (invalid or
+    // beyond max_dist), else the smallest depth -- what lets the cull prove "every voxel of this brick sees free space" (integrate.hip)
+    if (acc.n) {                                             // uniform
+    float m = inside ? ((value != 0.f && value < acc.max_dist) ? value : 0.f) : __builtin_huge_valf();
+    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0xB1, 0xf, 0xf, false)));
+    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0x4E, 0xf, 0xf, false)));
+    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0x141, 0xf, 0xf, false)));
+    const float m16 = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0x140, 0xf, 0xf, false)));
+    if ((lx & 7) == 0 && x < cols && y < rows) atomicMin(acc.tile + acc.n + acc.off0 + (y >> 3) * acc.w0 + (x >> 3), __float_as_int(m));
+    if ((lx & 15) == 0 && x < cols && y < rows) atomicMin(acc.tile + acc.n + acc.off1 + (y >> 4) * acc.w1 + (x >> 4), __float_as_int(m16));
+    }
+  }
+  if (!inside) return;
+  float result = value;
+  if (value != 0.f) {
+    float sum1 = 0.f, sum2 = 0.f;
+    const float thr = 5 * sigma_depth;
+    const float c_ss = ss_inv * KF_LOG2E, c_sd = -(sd_inv * KF_LOG2E);
+    if (FAST) {
+      const kf_f2 v2 = f2_splat(value), csd2 = f2_splat(c_sd);
+      bool over = false;                                   // some VALID tap differs from the centre by more than 5 sigma (:66-69)
+#pragma unroll
+      for (int dy = -R; dy <= R; ++dy) {
+        float row[2 * R + 2], dif[2 * R + 2], ex[2 * R + 2];
+#pragma unroll
+        for (int dx = -R; dx <= R; ++dx) row[dx + R] = tile[(ly + R + dy) * TW + lx + R + dx];
+        row[2 * R + 1] = value;
+#pragma unroll
+        for (int k = 0; k <= 2 * R; k += 2) {              // two taps per packed instruction: difference, square, exponent
+          const kf_f2 t2 = {row[k], row[k + 1]};
+          const kf_f2 sp = {-((float)((k - R) * (k - R) + dy * dy) * c_ss), -((float)((k + 1 - R) * (k + 1 - R) + dy * dy) * c_ss)};
+          const kf_f2 d2 = v2 - t2;
+          const kf_f2 e2 = f2_fma(d2 * d2, csd2, sp);
+          dif[k] = d2.x; dif[k + 1] = d2.y; ex[k] = e2.x; ex[k + 1] = e2.y;
+        }
+#pragma unroll
+        for (int k = 0; k <= 2 * R; ++k) {                 // the sums in the plain loop's tap order
+          const float ad = fabsf(dif[k]);
+          over = over || (ad > thr && ad < BIL_SENTINEL_CUT);
+          const float w = __builtin_amdgcn_exp2f(ex[k]);
+          sum1 = __builtin_fmaf(row[k], w, sum1); sum2 += w;
+        }
+      }
+      if (!over && sum2 > 0.f) result = sum1 / sum2;
+    } else {
+      float max_diff = 0.f;                                // largest |tap - centre| over the valid taps: the 5-sigma test, once
+#pragma unroll
+      for (int dy = -R; dy <= R; ++dy) {
+        float row[2 * R + 1];
+#pragma unroll
+        for (int dx = -R; dx <= R; ++dx) row[dx + R] = tile[(ly + R + dy) * TW + lx + R + dx];
+#pragma unroll
+        for (int dx = -R; dx <= R; ++dx) {
+          const float tmp = row[dx + R];
+          const bool valid = tmp != 0.f;
+          const float diff = value - tmp;
+          max_diff = fmaxf(max_diff, valid ? fabsf(diff) : 0.f);
+          const float wv = kf_bilateral_weight(diff, (float)(dx * dx + dy * dy), c_ss, c_sd);
+          const float w = valid ? wv : 0.f;                 // an invalid tap adds +0 to both sums: the loop stays straight-line
+          sum1 = __builtin_fmaf(tmp, w, sum1); sum2 += w;
+        }
+      }
+      if (!(max_diff > thr) && sum2 > 0.f) result = sum1 / sum2;
+    }
+  }
+  filtered[y * cols + x] = result;
+}
+
+
+// host side (preprocess.hip): the launch arguments for a buffer set, and the vertices + normals launch that follows the filter
+void kf_bilateral_args(kf_ctx* c, const uint16_t* mm, const float* raw_in, float* raw_out, float* trunced, float* filtered,
+                       float tmin, float tmax, float sigma_pixel, float sigma_depth, bool build_tiles, KfBilateralArgs* b, bool* fast);
+int kf_launch_vertices_normals(kf_ctx* c, hipStream_t stream, const float* filtered, float4* v0, float4* n0, const kf_camera_params* cam);

@@ -774,6 +774,7 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   a.sat_cull = (sat && c->tile_min_serial == c->trunc_serial) ? 1 : 0;     // whole-brick retirement needs the minima of THIS depth map
   c->fuse_max_dist = a.max_dist;                         // what the next preprocess builds the tables for
   c->tile_serial = 0; c->tiles_clear = 1;                // the fusion pass below clears the tables behind the cull
+  c->fp_tiles = 0;                                       // (tables a raycast launch may have built for a prefetched frame are cleared with them)
   {
     const int nmxy = (c->vol.nb + 3) >> 2, nmz = ((c->vol.bz1 + 3) >> 2) - (c->vol.bz0 >> 2);
     const unsigned n_macro = (unsigned)nmxy * nmxy * nmz;                      // one wave per macro cell, sixteen per workgroup

@@ -128,6 +128,12 @@ struct kf_ctx {
   float* alt_raw; float* alt_trunced; float* alt_filtered; float4* alt_v0; float4* alt_n0;
   hipStream_t side_stream; hipEvent_t ev_preprocessed, ev_prefetched;
   const uint16_t* prefetch_src; float prefetch_params[4]; int prefetch_valid, prefetch_in_use;
+  // fused form of the prefetch (default): kf_prefetch_frame only records the request; the next kf_raycast_volume launches the raycast with the
+  // next frame's gate + bilateral filter riding along (k_raycast_prefetch) and the vertices / normals launch behind it, on the context's own stream
+  int fp_pending;                     // a request waits for the next raycast
+  const uint16_t* fp_src; float fp_params[4]; kf_camera_params fp_cam;
+  int fp_done;                        // the prefetched set was produced on the context's stream (no event to wait for)
+  int fp_tiles; float fp_tiles_dist; int fp_tiles_min;   // the integrate tile tables were built for the prefetched depth map (distance; minima too)
   float4* new_v[KF_MAX_LEVELS]; float4* new_n[KF_MAX_LEVELS];
   float4* model_v[KF_MAX_LEVELS]; float4* model_n[KF_MAX_LEVELS];
   float* icp_partials;                // KF_ICP_MAX_WG x 32 floats

@@ -5,19 +5,12 @@
 // launch- and latency-bound, not HBM-bound.  Lanes run along x (64 consecutive pixels = 256 B / 1 KiB per wave row),
 // and the pyramid kernel writes level 1 and level 2 of vertices AND normals in one launch (the reference uses 8).
 #include "kf_internal.h"
+#include "bilateral_tile.h"
 #include <string.h>
+#include <stdlib.h>
 
 static inline KfCam to_cam(const kf_camera_params* p) {
   KfCam c; c.cols = (int)p->cols; c.rows = (int)p->rows; c.cx = p->cx; c.cy = p->cy; c.fx = p->fx; c.fy = p->fy; return c;
-}
-
-// Bilateral tap weight exp(-(space2 * ss_inv + diff^2 * sd_inv)) (DataPreprocesser.cu:70-73, __expf there) as ONE hardware exp2: the two
-// factors carry log2(e) already, the sum is a fused multiply-add.  The filter is tolerance-checked (2e-6 relative: the reference's fast
-// intrinsic is not reproducible on any other target anyway); the per-call kernel and the fused one share this function and their tap
-// order, so they still agree bit for bit.
-#define KF_LOG2E 1.44269504f
-__device__ __forceinline__ float kf_bilateral_weight(float diff, float space2, float c_ss, float c_sd) {
-  return __builtin_amdgcn_exp2f(__builtin_fmaf(diff * diff, c_sd, -(space2 * c_ss)));
 }
 
 // DataPreprocesser.cu:17-36: keep d iff trunc_min < d < trunc_max (strict both sides)
@@ -29,9 +22,6 @@ __global__ void __launch_bounds__(256) k_trunc_depth(const float* __restrict__ i
 }
 
 // DataPreprocesser.cu:37-79.  64x4 pixel tile per workgroup, (64+2r)x(4+2r) depth halo staged through LDS.
-#define BIL_TX 64
-#define BIL_TY 4
-#define BIL_MAXR 8
 __global__ void __launch_bounds__(256) k_bilateral(const float* __restrict__ in, float* __restrict__ out, int cols, int rows,
                                                    float ss_inv, float sd_inv, float sigma_depth, int radius) {
   __shared__ float tile[(BIL_TY + 2 * BIL_MAXR) * (BIL_TX + 2 * BIL_MAXR)];
@@ -68,124 +58,11 @@ __global__ void __launch_bounds__(256) k_bilateral(const float* __restrict__ in,
   out[y * cols + x] = result;
 }
 
-// Fused front end of HybKinectfu::processNewFrame (src/HybKinectfu.cpp:63-110): u16 mm -> f32 m (:73), range gate
-// (DataPreprocesser.cu:17-36) and bilateral filter (:37-79) in ONE launch.  The (64+2R)x(4+2R) gated tile lives in LDS; the
-// R x R tap loop is fully unrolled and branch-free: a zero (invalid or out-of-image) tap gets weight 0 -- adding +0 leaves the
-// reference's running sums bit-identical -- and the reference's early `return` (any tap further than 5 sigma_d away keeps the
-// unfiltered value, :66-69) becomes a flag tested once at the end.
-// The kernel also leaves the TSDF integration's tile maxima behind (integrate.hip: the max, over every 8x8 and 16x16 pixel tile, of
-// the gated depth that can integrate, d < max_dist): the gated tile is in LDS anyway, a wave is one 64-pixel row, so three DPP
-// steps give the max of each 8-pixel group and one more that of each 16-pixel group, and the group leaders merge them into the
-// (cleared) tables with fire-and-forget integer atomic maxima -- non-negative floats order like their bit patterns.  That replaces
-// a launch of its own (k_integrate_prepare) in front of every integrate.  acc.tile == nullptr: tables not wanted.
-struct KfTileAccum { int* tile; int off0, w0, off1, w1, n; float max_dist; };   // n: entries of both maxima tables = offset of the minima (0: minima not wanted)
-// FAST (every sane parameter set; the host decides): an invalid pixel sits in the LDS tile as a huge sentinel instead of 0, so its tap needs
-// no special case -- the squared difference sends the exponent to -inf, exp2 gives exactly +0, and 0 * sentinel adds exactly +0 to the
-// weighted sum -- and the difference / square / exponent of two taps are one packed instruction each.  Tap order and every rounded
-// operation of a valid tap are those of the plain loop: the same bits (per-call kernel == fused kernel stays a bit-exact test), a
-// quarter fewer vector instructions in a kernel that is bound by them (81 taps per pixel).
-#define BIL_SENTINEL 1e18f
-#define BIL_SENTINEL_CUT 1e17f
+// kf_preprocess's first launch: u16 -> f32 + gate + bilateral of one 64x4 tile per workgroup (bilateral_tile.h)
 template <int R, bool FAST>
-__global__ void __launch_bounds__(256) k_gate_bilateral(const uint16_t* __restrict__ mm, const float* __restrict__ raw_in,
-                                                        float* __restrict__ raw_out, float* __restrict__ trunced, float* __restrict__ filtered,
-                                                        int cols, int rows, float tmin, float tmax, float ss_inv, float sd_inv, float sigma_depth,
-                                                        KfTileAccum acc) {
-  constexpr int TW = BIL_TX + 2 * R, TH = BIL_TY + 2 * R;
-  __shared__ float tile[TW * TH];
-  const int x0 = blockIdx.x * BIL_TX - R, y0 = blockIdx.y * BIL_TY - R;
-  for (int i = threadIdx.x; i < TW * TH; i += 256) {
-    const int lx = i % TW, ly = i / TW, gx = x0 + lx, gy = y0 + ly;
-    float g = 0.f;
-    if (gx >= 0 && gx < cols && gy >= 0 && gy < rows) {
-      const float d = mm ? (float)((double)mm[gy * cols + gx] * 0.001) : raw_in[gy * cols + gx];   // HybKinectfu.cpp:73
-      g = (d < tmax && d > tmin) ? d : 0.f;                                                        // DataPreprocesser.cu:25-33
-      const bool interior = lx >= R && lx < R + BIL_TX && ly >= R && ly < R + BIL_TY;              // written exactly once
-      if (interior) { if (mm) raw_out[gy * cols + gx] = d; trunced[gy * cols + gx] = g; }
-    }
-    tile[i] = (FAST && g == 0.f) ? BIL_SENTINEL : g;
-  }
-  __syncthreads();
-  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-  const int x = blockIdx.x * BIL_TX + lx, y = blockIdx.y * BIL_TY + ly;
-  const bool inside = x < cols && y < rows;
-  float value = inside ? tile[(ly + R) * TW + lx + R] : 0.f;
-  if (FAST && value > BIL_SENTINEL_CUT) value = 0.f;       // (the centre pixel itself is invalid)
-  if (acc.tile) {                                          // uniform; every lane of the wave takes part in the DPP steps
-    float d = (value < acc.max_dist) ? value : 0.f;
-    d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0xB1, 0xf, 0xf, true)));    // quad_perm:[1,0,3,2]
-    d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x4E, 0xf, 0xf, true)));    // quad_perm:[2,3,0,1]
-    d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x141, 0xf, 0xf, true)));   // row_half_mirror: 8-pixel groups
-    const float d16 = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x140, 0xf, 0xf, true)));   // row_mirror: 16-pixel groups
-    // a group whose leader lies outside the image holds no pixel at all (d == 0): the indices below stay inside the tables
-    if ((lx & 7) == 0 && d > 0.f) atomicMax(acc.tile + acc.off0 + (y >> 3) * acc.w0 + (x >> 3), __float_as_int(d));
-    if ((lx & 15) == 0 && d16 > 0.f) atomicMax(acc.tile + acc.off1 + (y >> 4) * acc.w1 + (x >> 4), __float_as_int(d16));
-    // the tile MINIMA (second half of the buffer, cleared to +inf): 0 as soon as one pixel of the tile cannot integrate (invalid or
-    // beyond max_dist), else the smallest depth -- what lets the cull prove "every voxel of this brick sees free space" (integrate.hip)
-    if (acc.n) {                                             // uniform
-    float m = inside ? ((value != 0.f && value < acc.max_dist) ? value : 0.f) : __builtin_huge_valf();
-    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0xB1, 0xf, 0xf, false)));
-    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0x4E, 0xf, 0xf, false)));
-    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0x141, 0xf, 0xf, false)));
-    const float m16 = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0x140, 0xf, 0xf, false)));
-    if ((lx & 7) == 0 && x < cols && y < rows) atomicMin(acc.tile + acc.n + acc.off0 + (y >> 3) * acc.w0 + (x >> 3), __float_as_int(m));
-    if ((lx & 15) == 0 && x < cols && y < rows) atomicMin(acc.tile + acc.n + acc.off1 + (y >> 4) * acc.w1 + (x >> 4), __float_as_int(m16));
-    }
-  }
-  if (!inside) return;
-  float result = value;
-  if (value != 0.f) {
-    float sum1 = 0.f, sum2 = 0.f;
-    const float thr = 5 * sigma_depth;
-    const float c_ss = ss_inv * KF_LOG2E, c_sd = -(sd_inv * KF_LOG2E);
-    if (FAST) {
-      const kf_f2 v2 = f2_splat(value), csd2 = f2_splat(c_sd);
-      bool over = false;                                   // some VALID tap differs from the centre by more than 5 sigma (:66-69)
-#pragma unroll
-      for (int dy = -R; dy <= R; ++dy) {
-        float row[2 * R + 2], dif[2 * R + 2], ex[2 * R + 2];
-#pragma unroll
-        for (int dx = -R; dx <= R; ++dx) row[dx + R] = tile[(ly + R + dy) * TW + lx + R + dx];
-        row[2 * R + 1] = value;
-#pragma unroll
-        for (int k = 0; k <= 2 * R; k += 2) {              // two taps per packed instruction: difference, square, exponent
-          const kf_f2 t2 = {row[k], row[k + 1]};
-          const kf_f2 sp = {-((float)((k - R) * (k - R) + dy * dy) * c_ss), -((float)((k + 1 - R) * (k + 1 - R) + dy * dy) * c_ss)};
-          const kf_f2 d2 = v2 - t2;
-          const kf_f2 e2 = f2_fma(d2 * d2, csd2, sp);
-          dif[k] = d2.x; dif[k + 1] = d2.y; ex[k] = e2.x; ex[k + 1] = e2.y;
-        }
-#pragma unroll
-        for (int k = 0; k <= 2 * R; ++k) {                 // the sums in the plain loop's tap order
-          const float ad = fabsf(dif[k]);
-          over = over || (ad > thr && ad < BIL_SENTINEL_CUT);
-          const float w = __builtin_amdgcn_exp2f(ex[k]);
-          sum1 = __builtin_fmaf(row[k], w, sum1); sum2 += w;
-        }
-      }
-      if (!over && sum2 > 0.f) result = sum1 / sum2;
-    } else {
-      float max_diff = 0.f;                                // largest |tap - centre| over the valid taps: the 5-sigma test, once
-#pragma unroll
-      for (int dy = -R; dy <= R; ++dy) {
-        float row[2 * R + 1];
-#pragma unroll
-        for (int dx = -R; dx <= R; ++dx) row[dx + R] = tile[(ly + R + dy) * TW + lx + R + dx];
-#pragma unroll
-        for (int dx = -R; dx <= R; ++dx) {
-          const float tmp = row[dx + R];
-          const bool valid = tmp != 0.f;
-          const float diff = value - tmp;
-          max_diff = fmaxf(max_diff, valid ? fabsf(diff) : 0.f);
-          const float wv = kf_bilateral_weight(diff, (float)(dx * dx + dy * dy), c_ss, c_sd);
-          const float w = valid ? wv : 0.f;                 // an invalid tap adds +0 to both sums: the loop stays straight-line
-          sum1 = __builtin_fmaf(tmp, w, sum1); sum2 += w;
-        }
-      }
-      if (!(max_diff > thr) && sum2 > 0.f) result = sum1 / sum2;
-    }
-  }
-  filtered[y * cols + x] = result;
+__global__ void __launch_bounds__(256) k_gate_bilateral(KfBilateralArgs b) {
+  __shared__ float tile[(BIL_TX + 2 * R) * (BIL_TY + 2 * R)];
+  kf_bilateral_tile<R, FAST>(b, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, tile);
 }
 
 // depthToVerticesKernel + verticesToNormalsKernel (VerticesNormalsCalculater.cu:15-66) in one launch: the four neighbour
@@ -357,13 +234,11 @@ extern "C" int kf_calculate_new_normals(kf_ctx* c) {
   return (int)hipGetLastError();
 }
 
-// the two fused launches of kf_preprocess on a given stream and buffer set
-static int launch_fused_preprocess(kf_ctx* c, hipStream_t stream, const uint16_t* mm, const float* raw_in, float* raw_out, float* trunced, float* filtered,
-                                   float4* v0, float4* n0, float tmin, float tmax, float sigma_pixel, float sigma_depth, const kf_camera_params* cam,
-                                   bool build_tiles) {
+// arguments of the fused gate + bilateral launch for a buffer set; *fast: the sentinel form applies (bilateral_tile.h)
+void kf_bilateral_args(kf_ctx* c, const uint16_t* mm, const float* raw_in, float* raw_out, float* trunced, float* filtered,
+                       float tmin, float tmax, float sigma_pixel, float sigma_depth, bool build_tiles, KfBilateralArgs* b, bool* fast) {
   const float sd_inv = (float)(0.5 / (double)(sigma_depth * sigma_depth));
   const float ss_inv = (float)(0.5 / (double)(sigma_pixel * sigma_pixel));
-  dim3 grid(kf_div_up(c->cols, BIL_TX), kf_div_up(c->rows, BIL_TY));
   KfTileAccum acc; memset(&acc, 0, sizeof(acc));
   if (build_tiles) {                                       // layout of the two tables: kf_integrate_volume (integrate.hip)
     acc.tile = reinterpret_cast<int*>(c->tile_max_depth); acc.max_dist = c->fuse_max_dist;
@@ -371,14 +246,25 @@ static int launch_fused_preprocess(kf_ctx* c, hipStream_t stream, const uint16_t
     acc.n = kf_sat_regime(c) ? c->n_tile_floats : 0;         // the minima only matter once saturated free space can exist
   }
   // the sentinel form needs every valid depth far below the sentinel and the sentinel's tap weight to underflow to exactly zero
-  const bool fast = tmax < 1e15f && sd_inv * KF_LOG2E > 1e-30f && sd_inv * KF_LOG2E < 1e30f;
-  if (fast) hipLaunchKernelGGL((k_gate_bilateral<4, true>), grid, dim3(256), 0, stream, mm, raw_in, raw_out, trunced, filtered, c->cols, c->rows, tmin, tmax,
-                               ss_inv, sd_inv, sigma_depth, acc);
-  else hipLaunchKernelGGL((k_gate_bilateral<4, false>), grid, dim3(256), 0, stream, mm, raw_in, raw_out, trunced, filtered, c->cols, c->rows, tmin, tmax,
-                          ss_inv, sd_inv, sigma_depth, acc);
+  *fast = tmax < 1e15f && sd_inv * KF_LOG2E > 1e-30f && sd_inv * KF_LOG2E < 1e30f;
+  b->mm = mm; b->raw_in = raw_in; b->raw_out = raw_out; b->trunced = trunced; b->filtered = filtered; b->cols = c->cols; b->rows = c->rows;
+  b->tmin = tmin; b->tmax = tmax; b->ss_inv = ss_inv; b->sd_inv = sd_inv; b->sigma_depth = sigma_depth; b->acc = acc;
+}
+int kf_launch_vertices_normals(kf_ctx* c, hipStream_t stream, const float* filtered, float4* v0, float4* n0, const kf_camera_params* cam) {
   dim3 grid2(kf_div_up(c->cols, 64), kf_div_up(c->rows, 4));
   hipLaunchKernelGGL(k_vertices_normals, grid2, dim3(256), 0, stream, filtered, v0, n0, to_cam(cam));
   return (int)hipGetLastError();
+}
+// the two fused launches of kf_preprocess on a given stream and buffer set
+static int launch_fused_preprocess(kf_ctx* c, hipStream_t stream, const uint16_t* mm, const float* raw_in, float* raw_out, float* trunced, float* filtered,
+                                   float4* v0, float4* n0, float tmin, float tmax, float sigma_pixel, float sigma_depth, const kf_camera_params* cam,
+                                   bool build_tiles) {
+  dim3 grid(kf_div_up(c->cols, BIL_TX), kf_div_up(c->rows, BIL_TY));
+  KfBilateralArgs b; bool fast;
+  kf_bilateral_args(c, mm, raw_in, raw_out, trunced, filtered, tmin, tmax, sigma_pixel, sigma_depth, build_tiles, &b, &fast);
+  if (fast) hipLaunchKernelGGL((k_gate_bilateral<4, true>), grid, dim3(256), 0, stream, b);
+  else hipLaunchKernelGGL((k_gate_bilateral<4, false>), grid, dim3(256), 0, stream, b);
+  return kf_launch_vertices_normals(c, stream, filtered, v0, n0, cam);
 }
 
 extern "C" int kf_preprocess(kf_ctx* c, float tmin, float tmax, float sigma_pixel, float sigma_depth, const kf_camera_params* cam) {
@@ -387,6 +273,7 @@ extern "C" int kf_preprocess(kf_ctx* c, float tmin, float tmax, float sigma_pixe
   kf_evt_begin(c, KF_STAGE_PREPROCESS);
   const int radius = (int)ceil(2.0 * (double)sigma_pixel);
   const float want[4] = {tmin, tmax, sigma_pixel, sigma_depth};
+  c->fp_pending = 0;                                        // a recorded request no raycast has picked up is void now
   if (c->prefetch_valid && c->pending_mm && c->pending_mm == c->prefetch_src && memcmp(want, c->prefetch_params, sizeof(want)) == 0) {
     // this very frame was preprocessed ahead of time on the side stream (kf_prefetch_frame): adopt its buffers
     float* t;
@@ -396,8 +283,18 @@ extern "C" int kf_preprocess(kf_ctx* c, float tmin, float tmax, float sigma_pixe
     float4* q;
     q = c->new_v[0]; c->new_v[0] = c->alt_v0; c->alt_v0 = q;
     q = c->new_n[0]; c->new_n[0] = c->alt_n0; c->alt_n0 = q;
-    st = (int)hipStreamWaitEvent(c->stream, c->ev_prefetched, 0);
+    if (c->fp_done) {
+      // produced by the previous frame's raycast launch on this very stream: nothing to wait for.  If that launch also built the integrate
+      // tile tables for this depth map (and no integrate has cleared them since), they become current now.
+      st = 0;
+      if (c->fp_tiles && !c->tiles_clear) {
+        c->tile_serial = c->trunc_serial; c->tile_built_dist = c->fp_tiles_dist;
+        if (c->fp_tiles_min) c->tile_min_serial = c->trunc_serial;
+      }
+      c->fp_done = 0; c->fp_tiles = 0;
+    } else st = (int)hipStreamWaitEvent(c->stream, c->ev_prefetched, 0);
     c->pending_mm = nullptr; c->prefetch_valid = 0;
+    if (st == 0) st = kf_pending_depth_consumed(c);
   } else if (radius == 4) {                                    // stock sigma_pixel = 2: two fused launches instead of five
     c->prefetch_valid = 0;
     // the tile tables can ride along when they are clear (the last fusion pass cleared them) and an integration distance is known
@@ -432,16 +329,27 @@ extern "C" int kf_preprocess(kf_ctx* c, float tmin, float tmax, float sigma_pixe
 extern "C" int kf_prefetch_frame(kf_ctx* c, const uint16_t* dev_mm, uint32_t cols, uint32_t rows, float tmin, float tmax,
                                  float sigma_pixel, float sigma_depth, const kf_camera_params* cam) {
   if (!c || !dev_mm || !cam || (int)cols != c->cols || (int)rows != c->rows || (int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
-  c->prefetch_valid = 0;
+  c->prefetch_valid = 0; c->fp_pending = 0; c->fp_done = 0;
   if ((int)ceil(2.0 * (double)sigma_pixel) != 4) return 0;
   KF_CHECK(hipSetDevice(c->cfg.device));
   const size_t npx = (size_t)c->cols * c->rows;
+  if (!c->alt_raw) {
+    KF_CHECK(hipMalloc((void**)&c->alt_raw, npx * 4)); KF_CHECK(hipMalloc((void**)&c->alt_trunced, npx * 4)); KF_CHECK(hipMalloc((void**)&c->alt_filtered, npx * 4));
+    KF_CHECK(hipMalloc((void**)&c->alt_v0, npx * sizeof(float4))); KF_CHECK(hipMalloc((void**)&c->alt_n0, npx * sizeof(float4)));
+  }
+  static int fused = -1;                                   // KF_PREFETCH_FUSED=0: the side-stream form (events between two streams)
+  if (fused < 0) { const char* e = getenv("KF_PREFETCH_FUSED"); fused = e ? atoi(e) : 1; }
+  if (fused) {
+    // only a note: the next kf_raycast_volume* launch carries the filter along and leaves the preprocessed set in the alternate buffers
+    // (they were last read by the frame BEFORE the current one, which lies behind us on the stream)
+    c->fp_src = dev_mm; c->fp_params[0] = tmin; c->fp_params[1] = tmax; c->fp_params[2] = sigma_pixel; c->fp_params[3] = sigma_depth;
+    c->fp_cam = *cam; c->fp_pending = 1;
+    return 0;
+  }
   if (!c->side_stream) {
     KF_CHECK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
     KF_CHECK(hipEventCreateWithFlags(&c->ev_preprocessed, hipEventDisableTiming));
     KF_CHECK(hipEventCreateWithFlags(&c->ev_prefetched, hipEventDisableTiming));
-    KF_CHECK(hipMalloc((void**)&c->alt_raw, npx * 4)); KF_CHECK(hipMalloc((void**)&c->alt_trunced, npx * 4)); KF_CHECK(hipMalloc((void**)&c->alt_filtered, npx * 4));
-    KF_CHECK(hipMalloc((void**)&c->alt_v0, npx * sizeof(float4))); KF_CHECK(hipMalloc((void**)&c->alt_n0, npx * sizeof(float4)));
     KF_CHECK(hipEventRecord(c->ev_preprocessed, c->stream));   // first use: everything enqueued so far
     c->prefetch_in_use = 1;
   }

@@ -12,8 +12,10 @@
 //     interpolation inputs are bit-identical to the reference march;
 //   * bricks are 4 KiB contiguous, so the trilinear taps at the hit (2 + 6 lookups x 8 voxels) touch 1-2 bricks.
 #include "kf_internal.h"
+#include "bilateral_tile.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <string.h>
 
 struct RaycastArgs {
   KfVolume vol;
@@ -145,12 +147,12 @@ __device__ __forceinline__ void rc_march(const RaycastArgs& a, const KfVolume& v
   }
 }
 
-__global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
+// one 32x16 pixel tile (tile_x, tile_y) by the 512 threads of a workgroup; s_tables: the workgroup's dynamic LDS
+__device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, int tile_y, unsigned* s_tables) {
   const KfVolume& v = a.vol;
   // Two packed tables live in LDS so that the empty-space walk costs LDS reads instead of dependent L2 round trips (the
   // march is latency-bound: halving the rays does not shorten it): one bit per 32^3 macro cell of the whole volume
   // (packed here from the byte table), and -- when it fits -- one bit per stored 8^3 brick (KfVolume::negbits).
-  extern __shared__ unsigned s_tables[];
 #ifdef KF_EXPERIMENTS
   const unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -180,9 +182,9 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
   const bool neg_in_lds = a.neg_words != 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // a workgroup is a 32x16 pixel tile, a wave an 8x8 patch of it
-  const int x = blockIdx.x * 32 + (wave & 3) * 8 + (lane & 7), y = blockIdx.y * 16 + (wave >> 2) * 8 + (lane >> 3);
+  const int x = tile_x * 32 + (wave & 3) * 8 + (lane & 7), y = tile_y * 16 + (wave >> 2) * 8 + (lane >> 3);
   if (x >= a.cam.cols || y >= a.cam.rows) return;
-  if (KF_EXP_MODE(a) == 2 && ((blockIdx.x + blockIdx.y) & 1)) return;      // timing experiment: half the rays (latency- or throughput-bound?)
+  if (KF_EXP_MODE(a) == 2 && ((tile_x + tile_y) & 1)) return;      // timing experiment: half the rays (latency- or throughput-bound?)
   const int pix = y * a.cam.cols + x;
   const float inf = __builtin_huge_valf();
   float4 out_v = make_float4(0.f, 0.f, 0.f, 0.f), out_n = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -264,13 +266,36 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
     const float n_s = (ref_tmin < ref_tmax) ? floorf((t_stop - ref_tmin) / a.inc) + 1.f : 0.f;
     const float steps = kf_wave_sum(n_s), hits = kf_wave_sum(t_cross < inf ? 1.f : 0.f);
     if ((threadIdx.x & 63) == 0) {
-      const unsigned sh = ((blockIdx.y * gridDim.x + blockIdx.x) * 8u + (threadIdx.x >> 6)) & 63u;
+      const unsigned sh = ((unsigned)(tile_y * 61 + tile_x) * 8u + (threadIdx.x >> 6)) & 63u;
       atomicAdd(&a.work->rc_steps[sh * 16], (unsigned long long)steps);
       atomicAdd(&a.work->rc_hits[sh * 16], (unsigned long long)hits);
     }
   }
   if (a.out_t) a.out_t[pix] = t_cross;
   if (a.has_color) a.out_rgb[pix] = out_c;
+}
+
+__global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
+  extern __shared__ unsigned s_dyn[];
+  raycast_tile(a, (int)blockIdx.x, (int)blockIdx.y, s_dyn);
+}
+
+// The raycast with the NEXT frame's depth conversion + gate + bilateral filter riding along (kf_prefetch_frame, fused form).  The raycast
+// lasts as long as its slowest waves while the average SIMD is busy for less than half of that; the filter of the frame that comes next
+// depends on nothing this frame computes.  Workgroups [0, n_rc) are the raycast's tiles (dispatched first, higher wave priority), the rest
+// filter two 64x4 tiles each (bilateral_tile.h) and fill the chip as the raycast drains -- no second stream, no events.
+template <bool FAST>
+__global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast_prefetch(RaycastArgs a, KfBilateralArgs b, int rc_gx, int n_rc, int bil_gx, int bil_tiles) {
+  extern __shared__ unsigned s_dyn[];
+  if ((int)blockIdx.x < n_rc) {
+    __builtin_amdgcn_s_setprio(2);
+    raycast_tile(a, (int)blockIdx.x % rc_gx, (int)blockIdx.x / rc_gx, s_dyn);
+  } else {
+    const int half = (int)(threadIdx.x >> 8), t = ((int)blockIdx.x - n_rc) * 2 + half;
+    // a tile index past the last one names a row below the image: its threads touch nothing but still meet the barrier
+    const int tt = t < bil_tiles ? t : bil_tiles;
+    kf_bilateral_tile<4, FAST>(b, tt % bil_gx, tt / bil_gx, (int)(threadIdx.x & 255), reinterpret_cast<float*>(s_dyn) + half * ((BIL_TX + 8) * (BIL_TY + 8)));
+  }
 }
 
 static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, const kf_raycast_params* rp, const kf_camera_params* cam,
@@ -295,7 +320,34 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
     hipEvent_t ke0 = nullptr, ke1 = nullptr;               // the kernel's own timer rides on its dispatch (kf_evt_attach): the kernel as rocprofv3 sees it
     const dim3 grid(kf_div_up(c->cols, 32), kf_div_up(c->rows, 16));
     const size_t lds = macro_bytes + (size_t)a.neg_words * 4;
-    if (kf_evt_attach(c, KF_STAGE_RAYCAST_KERNEL, &ke0, &ke1)) {
+    const bool timed = kf_evt_attach(c, KF_STAGE_RAYCAST_KERNEL, &ke0, &ke1);
+    if (c->fp_pending && c->alt_raw) {
+      // kf_prefetch_frame left a note: the next frame's u16 -> f32 + gate + bilateral rides in this launch (k_raycast_prefetch), its vertices /
+      // normals follow; the set lands in the alternate buffers and kf_preprocess adopts it when it is asked for exactly that frame
+      c->fp_pending = 0;
+      KfBilateralArgs b; bool fast;
+      const bool build_tiles = c->tiles_clear && c->fuse_max_dist > 0.f;      // the fusion pass of this frame has cleared the tables: they can be built for the next depth map
+      kf_bilateral_args(c, c->fp_src, nullptr, c->alt_raw, c->alt_trunced, c->alt_filtered, c->fp_params[0], c->fp_params[1], c->fp_params[2], c->fp_params[3],
+                        build_tiles, &b, &fast);
+      const int bil_gx = kf_div_up(c->cols, BIL_TX), bil_tiles = bil_gx * kf_div_up(c->rows, BIL_TY);
+      const int n_rc = (int)(grid.x * grid.y), n_bil = (bil_tiles + 1) / 2;
+      const size_t lds2 = lds > 2 * (BIL_TX + 8) * (BIL_TY + 8) * sizeof(float) ? lds : 2 * (BIL_TX + 8) * (BIL_TY + 8) * sizeof(float);
+      const dim3 g2((unsigned)(n_rc + n_bil));
+      if (fast) {
+        if (timed) hipExtLaunchKernelGGL(k_raycast_prefetch<true>, g2, dim3(RAYCAST_THREADS), (unsigned)lds2, c->stream, ke0, ke1, 0, a, b, (int)grid.x, n_rc, bil_gx, bil_tiles);
+        else hipLaunchKernelGGL(k_raycast_prefetch<true>, g2, dim3(RAYCAST_THREADS), lds2, c->stream, a, b, (int)grid.x, n_rc, bil_gx, bil_tiles);
+      } else {
+        if (timed) hipExtLaunchKernelGGL(k_raycast_prefetch<false>, g2, dim3(RAYCAST_THREADS), (unsigned)lds2, c->stream, ke0, ke1, 0, a, b, (int)grid.x, n_rc, bil_gx, bil_tiles);
+        else hipLaunchKernelGGL(k_raycast_prefetch<false>, g2, dim3(RAYCAST_THREADS), lds2, c->stream, a, b, (int)grid.x, n_rc, bil_gx, bil_tiles);
+      }
+      if (timed) kf_evt_attached_done(c, KF_STAGE_RAYCAST_KERNEL);
+      const int st = kf_launch_vertices_normals(c, c->stream, c->alt_filtered, c->alt_v0, c->alt_n0, &c->fp_cam);
+      if (st) return st;
+      c->prefetch_src = c->fp_src; memcpy(c->prefetch_params, c->fp_params, sizeof(c->prefetch_params));
+      c->prefetch_valid = 1; c->fp_done = 1;
+      c->fp_tiles = build_tiles ? 1 : 0; c->fp_tiles_dist = c->fuse_max_dist; c->fp_tiles_min = (build_tiles && b.acc.n) ? 1 : 0;
+      if (build_tiles) c->tiles_clear = 0;
+    } else if (timed) {
       hipExtLaunchKernelGGL(k_raycast, grid, dim3(RAYCAST_THREADS), (unsigned)lds, c->stream, ke0, ke1, 0, a);
       kf_evt_attached_done(c, KF_STAGE_RAYCAST_KERNEL);
     } else hipLaunchKernelGGL(k_raycast, grid, dim3(RAYCAST_THREADS), lds, c->stream, a);

@@ -116,9 +116,11 @@ int kf_calculate_new_normals(kf_ctx* ctx);
 /* the four above fused (what HybKinectfu::processNewFrame runs, src/HybKinectfu.cpp:106-110) */
 int kf_preprocess(kf_ctx* ctx, float trunc_min, float trunc_max, float sigma_pixel, float sigma_depth,
                   const kf_camera_params* depth_camera);
-/* No reference counterpart (the reference synchronises after every launch): run kf_preprocess for the NEXT frame -- a device
- * u16 millimetre image, as for kf_set_depth_mm_device -- on a side stream into a second buffer set, concurrently with whatever
- * is enqueued next (meant: right after kf_icp_track / kf_sdf_track, whose persistent loop leaves ~100 CUs idle).  The next
+/* No reference counterpart (the reference synchronises after every launch): have kf_preprocess's work for the NEXT frame -- a device
+ * u16 millimetre image, as for kf_set_depth_mm_device -- done ahead of time into a second buffer set.  Default form: the call only
+ * leaves a note, and the next kf_raycast_volume(_slab) launch carries the next frame's conversion + gate + bilateral filter along as
+ * extra workgroups of the same launch (the vertices / normals launch follows it) -- same stream, no events.  KF_PREFETCH_FUSED=0 selects
+ * the older form: the two preprocess launches on a side stream, concurrent with whatever is enqueued next.  Either way the next
  * kf_set_depth_mm_device(same pointer) + kf_preprocess(same parameters) adopts the result; any other sequence ignores it.
  * Results are bit-identical to the unprefetched path. */
 int kf_prefetch_frame(kf_ctx* ctx, const uint16_t* dev_depth_mm, uint32_t cols, uint32_t rows, float trunc_min, float trunc_max,
