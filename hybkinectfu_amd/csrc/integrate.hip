@@ -841,6 +841,24 @@ __global__ void __launch_bounds__(256) k_selftest_div(unsigned n, unsigned seed,
   // two xorshift draws -> operands in the ranges the kernels use
   unsigned s = seed ^ (i * 2654435761u); s ^= s << 13; s ^= s >> 17; s ^= s << 5;
   unsigned t = s * 1664525u + 1013904223u; t ^= t << 13; t ^= t >> 17; t ^= t << 5;
+  if (mode == 10 || mode == 11) {
+    // the one-instruction float / double -> int conversion against its spelled-out definition: random BIT PATTERNS (every exponent, NaNs,
+    // infinities, denormals) and, in the first lanes, the special values and the neighbours of the saturation thresholds
+    const float specials[16] = {0.f, -0.f, 1.f, -1.f, 0.5f, -0.5f, 2147483520.f, 2147483648.f, -2147483648.f, -2147483904.f, 4294967296.f,
+                                __builtin_huge_valf(), -__builtin_huge_valf(), __builtin_nanf(""), 1e-45f, 16777217.f};
+    bool bad;
+    if (mode == 10) {
+      const float x = i < 16 ? specials[i] : __uint_as_float(s);
+      bad = kf_f2i(x) != kf_f2i_spelled(x);
+    } else {
+      const double specials_d[8] = {2147483647.0, 2147483647.5, 2147483648.0, -2147483648.0, -2147483648.5, -2147483649.0, 1e300, -1e300};
+      double x = i < 16 ? (double)specials[i] : (i < 24 ? specials_d[i - 16] : __longlong_as_double(((long long)s << 32) | (long long)t));
+      if ((i & 3) == 1 && i >= 24) x = (double)__uint_as_float(s) * 1.0000001;      // values near the float range as well
+      bad = kf_to_int(x) != kf_to_int_spelled(x);
+    }
+    if (bad) atomicAdd(mismatches, 1u);
+    return;
+  }
   const float u = (float)(s >> 8) * (1.0f / 16777216.0f), w = (float)(t >> 8) * (1.0f / 16777216.0f);
   float a, b;
   if (mode == 0) { a = (u * 2.f - 1.f) * 8000.f; b = 1e-4f + w * 20.f; }            // pf.x*fx / pf.z

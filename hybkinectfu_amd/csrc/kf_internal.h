@@ -238,21 +238,25 @@ __device__ __forceinline__ kf_f2 f2_fma(kf_f2 a, kf_f2 b, kf_f2 c) { return __bu
 // identity the compiler cannot see through: the value becomes lane-varying as far as it knows (no instruction is emitted)
 __device__ __forceinline__ unsigned kf_opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 
-// (int) of a double / float the way the reference's CUDA path converts (cvt.rzi.s32): truncation, saturating, NaN -> 0 --
-// which is also what gfx950's v_cvt_i32_f64 / v_cvt_i32_f32 do.  Written out (C++ leaves the out-of-range cast undefined,
-// so the compiler may not be handed it).
-__device__ __forceinline__ int kf_to_int(double v) {
+// (int) of a double / float the way the reference's CUDA path converts (cvt.rzi.s32): truncation, saturating, NaN -> 0 -- which is exactly
+// what gfx950's v_cvt_i32_f64 / v_cvt_i32_f32 do, so the conversion IS that one instruction.  (C++ leaves the out-of-range cast undefined,
+// so it cannot be written as a cast; spelled out with comparisons -- kf_to_int_spelled / kf_f2i_spelled, kept for the self-test -- it costs
+// three branches and ten instructions per coordinate, a fifth of a raycast march trip.)  kf_selftest_div modes 10 / 11 compare the two
+// forms on the GPU over random bit patterns and every special value (tests/test_gpu_parity.py::test_exact_division_helper).
+__device__ __forceinline__ int kf_to_int_spelled(double v) {
   if (v != v) return 0;
   if (v >= 2147483648.0) return 2147483647;
   if (v <= -2147483649.0) return (int)0x80000000;
   return (int)v;
 }
-__device__ __forceinline__ int kf_f2i(float v) {
+__device__ __forceinline__ int kf_f2i_spelled(float v) {
   if (v != v) return 0;
   if (v >= 2147483648.f) return 2147483647;
   if (v <= -2147483648.f) return (int)0x80000000;
   return (int)v;
 }
+__device__ __forceinline__ int kf_to_int(double v) { int r; asm("v_cvt_i32_f64_e32 %0, %1" : "=v"(r) : "v"(v)); return r; }
+__device__ __forceinline__ int kf_f2i(float v) { int r; asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(v)); return r; }
 
 // Correctly rounded fp32 quotient a / b for operands in the normal range: the very FMA sequence hipcc emits for `a / b`
 // (v_rcp_f32, two reciprocal refinements, quotient, two residual corrections; LLVM legalizeFDIV32) minus the v_div_scale /

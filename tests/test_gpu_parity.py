@@ -310,6 +310,10 @@ def test_exact_division_helper():
     ctx = K.Context(K.camera(*small_cam()), 32, 3.0, levels=3)
     for mode in range(4):
         assert ctx.selftest_div(1 << 24, 12345 + mode, mode) == 0, mode
+    # the float / double -> int conversion as ONE hardware instruction (v_cvt_i32_f32 / _f64: truncating, saturating, NaN -> 0) against its
+    # spelled-out definition -- the reference's CUDA conversion rule (cvt.rzi.s32): special values + 2^24 random bit patterns each
+    for mode in (10, 11):
+        assert ctx.selftest_div(1 << 24, 777 + mode, mode) == 0, mode
     ctx.close()
 
 
