@@ -146,7 +146,7 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
   if (!cfg || !out) return KF_ERR_ARG;
   *out = nullptr;
   const uint32_t R = cfg->volume.resolution;
-  if (R == 0 || (R % KF_BRICK) != 0) return KF_ERR_ARG;
+  if (R == 0 || (R % KF_BRICK) != 0 || R > 8192u) return KF_ERR_ARG;      // (bricks per axis <= 1024: kf_brick_slot's 24-bit multiplies)
   if (cfg->pyramid_levels < 1 || cfg->pyramid_levels > KF_MAX_LEVELS) return KF_ERR_ARG;
   if (cfg->depth_camera.cols == 0 || cfg->depth_camera.rows == 0) return KF_ERR_ARG;
   uint32_t z0 = cfg->slab_z_begin, z1 = cfg->slab_z_end ? cfg->slab_z_end : R;

@@ -300,11 +300,14 @@ __device__ __forceinline__ int2 kf_project(float3 v, const KfCam& c) {
 }
 
 // ---- volume addressing -------------------------------------------------------------------------------------------
-__device__ __forceinline__ size_t kf_brick_slot(const KfVolume& v, int bx, int by, int bz) {
-  return ((size_t)(bz - v.bz0) * v.nb + by) * v.nb + bx;
+// (24-bit multiplies: v_mad_u32_u24 is a full-rate instruction, a 32- or 64-bit integer multiply is not, and the gather-bound kernels form
+// dozens of these per pixel.  Exact while bricks per axis <= 1024 -- kf_create refuses more --: every factor is below 2^24 and every
+// product below 2^32.  A layer below the stored range gives a meaningless slot, as the 64-bit form did: callers test kf_z_stored first.)
+__device__ __forceinline__ unsigned kf_brick_slot(const KfVolume& v, int bx, int by, int bz) {
+  return __umul24(__umul24((unsigned)(bz - v.bz0), (unsigned)v.nb) + (unsigned)by, (unsigned)v.nb) + (unsigned)bx;
 }
 __device__ __forceinline__ size_t kf_vox_index(const KfVolume& v, int x, int y, int z) {
-  return kf_brick_slot(v, x >> 3, y >> 3, z >> 3) * KF_BRICK_VOX + (size_t)(((z & 7) << 6) | ((y & 7) << 3) | (x & 7));
+  return (size_t)kf_brick_slot(v, x >> 3, y >> 3, z >> 3) * KF_BRICK_VOX + (size_t)(((z & 7) << 6) | ((y & 7) << 3) | (x & 7));
 }
 __device__ __forceinline__ bool kf_z_stored(const KfVolume& v, int z) { return z >= v.bz0 * KF_BRICK && z < v.bz1 * KF_BRICK; }
 

@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(256) MC_COUNT_ATTR k_mc_count(McArgs a) {
       sv[p] = 0;
       int cx, cy, cz;
       if (b < nbat && mc_cell_of(a, a.list[base + b], 8u * k, n_cells, cx, cy, cz))
-        sv[p] = a.surv[kf_brick_slot(a.vol, cx >> 3, cy >> 3, cz >> 3) * 64u + (size_t)(((cz & 7) << 3) | (cy & 7))];
+        sv[p] = a.surv[(size_t)kf_brick_slot(a.vol, cx >> 3, cy >> 3, cz >> 3) * 64u + (size_t)(((cz & 7) << 3) | (cy & 7))];
     }
     if (threadIdx.x < MC_BATCH) s_cnt[threadIdx.x] = 0;
     unsigned nq = 0;

@@ -109,7 +109,7 @@ __device__ __forceinline__ void rc_march(const RaycastArgs& a, const KfVolume& v
     // Both levels take ONE code path with selected parameters: the lanes of
     // a wave sit in different states, and a wave executes the union of the paths its lanes take on every trip.
     const int mx = gx >> 5, my = gy >> 5, mz = gz >> 5;
-    const bool macro_empty = !rc_bit(s_macro, (unsigned)((mz * nm + my) * nm + mx));
+    const bool macro_empty = !rc_bit(s_macro, __umul24(__umul24((unsigned)mz, (unsigned)nm) + (unsigned)my, (unsigned)nm) + (unsigned)mx);
     const bool owned = gz >= v.own_z0 && gz < v.own_z1;
     size_t slot = 0; bool has_neg = false;
     if (!macro_empty && owned) {
@@ -131,7 +131,7 @@ __device__ __forceinline__ void rc_march(const RaycastArgs& a, const KfVolume& v
       continue;
     }
     ++n_samp;
-    const float sdf = v.tw[slot * KF_BRICK_VOX + (size_t)(((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7))].x;
+    const float sdf = v.tw[(size_t)slot * KF_BRICK_VOX + (size_t)(((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7))].x;
     if (sdf < 0.0f) {
       if (!have_last) {                                                    // the previous sample's tsdf was never fetched: fetch it now
         const float3 last_pos = kf_add(org, kf_scale(dir, t_prev));        // recomputed exactly as the march computed it
