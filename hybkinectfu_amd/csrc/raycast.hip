@@ -64,19 +64,6 @@ __device__ __forceinline__ bool gradient_for_point(const KfVolume& v, float3 sam
 // bit `i` of a packed table
 __device__ __forceinline__ bool rc_bit(const unsigned* words, unsigned i) { return (words[i >> 5] >> (i & 31u)) & 1u; }
 
-// Advance t by the reference's own repeated addition (no memory traffic) until the ray is about to leave the axis-aligned
-// cell [c, c + edge) that contains pos; the exit bound is shrunk by eps so rounding can never skip a sample of a neighbour.
-__device__ __forceinline__ void rc_skip_cell(float3 pos, float3 dir, float3 inv_dir, float cx, float cy, float cz, float edge, float eps,
-                                             float inc, float tmax, float& t, float& t_prev) {
-  const float bx = dir.x > 0.f ? cx + edge - eps : cx + eps;
-  const float by = dir.y > 0.f ? cy + edge - eps : cy + eps;
-  const float bz = dir.z > 0.f ? cz + edge - eps : cz + eps;
-  // the exit parameter only has to be conservative (eps and the 1e-6 t margin absorb a few ulps): reciprocals, no divisions
-  const float dt = fminf(fminf((bx - pos.x) * inv_dir.x, (by - pos.y) * inv_dir.y), (bz - pos.z) * inv_dir.z);
-  const float t_exit = fminf(t + dt - 1e-6f * t, tmax);
-  do { t_prev = t; t += inc; } while (t < t_exit);      // the reference's own repeated addition: identical sample parameters
-}
-
 // The march of one ray over the samples t_k in [t, t_end): the reference's loop (raySample :65-119) with the two empty-space levels.
 // `t`, `t_prev`, `have_last`, `last_sdf` carry the reference's per-ray state in; on return t_cross < +inf names the first crossing of
 // the range (with t_cross_prev the sample before it).  Whether sample k is a crossing depends on samples k-1 and k only (the previous
@@ -86,18 +73,27 @@ struct RcRay { float3 org, dir, inv_dir; };
 __device__ __forceinline__ void rc_march(const RaycastArgs& a, const KfVolume& v, const unsigned* s_macro, const unsigned* s_neg, bool neg_in_lds, const RcRay& ray,
                                          const KfRecip& rS, float t_end, float& t, float& t_prev, bool& have_last, float& last_sdf,
                                          float& t_cross, float& t_cross_prev, int& n_iter, int& n_samp) {
-  const float3 org = ray.org, dir = ray.dir, inv_dir = ray.inv_dir;
+  const float3 org = ray.org, dir = ray.dir;
   const int R = v.res;
   const float rf = (float)R;
   const int zs0 = v.bz0 * KF_BRICK, zs1 = v.bz1 * KF_BRICK;
-  const float mcell = (float)KF_MACRO * v.cell, meps = 1e-4f * mcell;
-  const float bcell = (float)KF_BRICK * v.cell, beps = 1e-3f * bcell;
   const int nm = v.nm;
-    while (t < t_end) {
+  // the empty-space walk measures in VOXEL units along each axis: with q the sample's (unrounded) voxel coordinate and `base` the first voxel
+  // of its cell (32 voxels wide for a macro cell, 8 for a brick), the cell's far face lies E - (q - base) voxels ahead for a ray going up
+  // the axis and q - base voxels for one going down: one fused multiply-add per axis with the ray's constants sgn / up, times cell / |dir|
+  const float3 sgn = kf3(dir.x > 0.f ? -1.f : 1.f, dir.y > 0.f ? -1.f : 1.f, dir.z > 0.f ? -1.f : 1.f);
+  const float3 up = kf3(dir.x > 0.f ? 1.f : 0.f, dir.y > 0.f ? 1.f : 0.f, dir.z > 0.f ? 1.f : 0.f);
+  const float3 per_vox = kf3(v.cell * fabsf(ray.inv_dir.x), v.cell * fabsf(ray.inv_dir.y), v.cell * fabsf(ray.inv_dir.z));
+  // `worldPos * resolution / size` (tsdfVolume.h:50-56): for a power-of-two size the quotient is an exact scaling -- the same bits from a product
+  const float inv_size = 1.0f / v.size;
+  const bool pow2 = (__float_as_uint(v.size) & 0x007FFFFFu) == 0u;
+  while (t < t_end) {
     ++n_iter;
     const float3 pos = kf_add(org, kf_scale(dir, t));
     // the sample's own voxel -- tsdfvolume::getVoxel(world) tsdfVolume.h:81-97: nearest voxel, index clamped
-    int gx = kf_f2i(kf_div(pos.x * rf, rS)), gy = kf_f2i(kf_div(pos.y * rf, rS)), gz = kf_f2i(kf_div(pos.z * rf, rS));
+    const float qx = pow2 ? (pos.x * rf) * inv_size : kf_div(pos.x * rf, rS), qy = pow2 ? (pos.y * rf) * inv_size : kf_div(pos.y * rf, rS),
+                qz = pow2 ? (pos.z * rf) * inv_size : kf_div(pos.z * rf, rS);
+    int gx = kf_f2i(qx), gy = kf_f2i(qy), gz = kf_f2i(qz);
     gx = max(0, min(gx, R - 1)); gy = max(0, min(gy, R - 1)); gz = max(0, min(gz, R - 1));
     // level 1: a 32^3-voxel macro cell without any negative voxel -> none of the samples inside it can be the negative
     // side of a crossing: walk to its far side.  The cell is the VOXEL's macro cell (g >> 5), like the brick level below:
@@ -122,10 +118,15 @@ __device__ __forceinline__ void rc_march(const RaycastArgs& a, const KfVolume& v
       // far face); otherwise one sample
       const bool walk = macro_empty || (owned && neg_in_lds);
       if (walk) {
-        const float edge = macro_empty ? mcell : bcell, eps = macro_empty ? meps : beps;
-        const float cx = macro_empty ? (float)mx * mcell : (float)(gx >> 3) * bcell, cy = macro_empty ? (float)my * mcell : (float)(gy >> 3) * bcell,
-                    cz = macro_empty ? (float)mz * mcell : (float)(gz >> 3) * bcell;
-        rc_skip_cell(pos, dir, inv_dir, cx, cy, cz, edge, eps, a.inc, t_end, t, t_prev);
+        const int mask = macro_empty ? ~31 : ~7;
+        const float edge = macro_empty ? 32.f : 8.f, eps = macro_empty ? 3.2e-3f : 8e-3f;       // eps: 1e-4 / 1e-3 of the cell edge, in voxels
+        // the exit parameter only has to be conservative (eps and the 1e-6 t margin absorb a few ulps)
+        const float dx = __builtin_fmaf(qx - (float)(gx & mask), sgn.x, up.x * edge) - eps;
+        const float dy = __builtin_fmaf(qy - (float)(gy & mask), sgn.y, up.y * edge) - eps;
+        const float dz = __builtin_fmaf(qz - (float)(gz & mask), sgn.z, up.z * edge) - eps;
+        const float dt = fminf(fminf(dx * per_vox.x, dy * per_vox.y), dz * per_vox.z);
+        const float t_exit = fminf(t + dt - 1e-6f * t, t_end);
+        do { t_prev = t; t += a.inc; } while (t < t_exit);      // the reference's own repeated addition: identical sample parameters
       } else { t_prev = t; t += a.inc; }
       have_last = false;
       continue;
@@ -135,7 +136,8 @@ __device__ __forceinline__ void rc_march(const RaycastArgs& a, const KfVolume& v
     if (sdf < 0.0f) {
       if (!have_last) {                                                    // the previous sample's tsdf was never fetched: fetch it now
         const float3 last_pos = kf_add(org, kf_scale(dir, t_prev));        // recomputed exactly as the march computed it
-        int lx = kf_f2i(kf_div(last_pos.x * rf, rS)), ly = kf_f2i(kf_div(last_pos.y * rf, rS)), lz = kf_f2i(kf_div(last_pos.z * rf, rS));
+        int lx = kf_f2i(pow2 ? (last_pos.x * rf) * inv_size : kf_div(last_pos.x * rf, rS)), ly = kf_f2i(pow2 ? (last_pos.y * rf) * inv_size : kf_div(last_pos.y * rf, rS)),
+            lz = kf_f2i(pow2 ? (last_pos.z * rf) * inv_size : kf_div(last_pos.z * rf, rS));
         lx = max(0, min(lx, R - 1)); ly = max(0, min(ly, R - 1)); lz = max(0, min(lz, R - 1));
         last_sdf = (lz >= zs0 && lz < zs1) ? v.tw[kf_vox_index(v, lx, ly, lz)].x : 0.f;
         have_last = true;
