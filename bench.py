@@ -232,8 +232,8 @@ def launch_ranks(n, argv):
 
 def collective_selftest(args):
     """No GPU needed: the ranks form a gloo group and run SlabExchange -- the very sequence of collectives SlabPipeline issues per
-    frame (async MIN all-reduce, overlap hook, pack, integer SUM all-reduce, unpack) -- on CPU tensors, with plain-torch
-    restatements of the pack / unpack kernels (tests/slab_cpu_ops.py), and check the merged maps against the first-crossing rule.
+    frame (async MIN all-reduce, overlap hook, mask, integer SUM all-reduce, unpack) -- on CPU tensors, with plain-torch
+    restatements of the mask / unpack kernels (tests/slab_cpu_ops.py), and check the merged maps against the first-crossing rule.
     Used by tests/test_slab_distributed_cpu.py to cover the launcher path end to end at world_size 2."""
     import torch
     import torch.distributed as dist
@@ -244,11 +244,11 @@ def collective_selftest(args):
     dist.init_process_group("gloo")
     rows, cols = 48, 64
     model = {}
-    ex = SlabExchange(rows, cols, torch.device("cpu"), dist, pack=ops.pack, unpack=lambda packed: model.update(zip("vn", ops.unpack(packed))))
+    ex = SlabExchange(rows, cols, torch.device("cpu"), dist, mask=ops.mask, unpack=lambda cand: model.update(zip("vn", ops.unpack(cand))))
     ok, overlapped = True, 0
     for frame in range(3):
-        t, v, n, want_v, want_n = ops.synthetic_candidates(rows, cols, rank, world, seed=100 + frame)
-        ex.t.copy_(t); ex.v.copy_(v); ex.n.copy_(n)
+        t, cand, want_v, want_n = ops.synthetic_candidates(rows, cols, rank, world, seed=100 + frame)
+        ex.t.copy_(t); ex.cand.copy_(cand)
 
         def overlap():
             nonlocal overlapped
@@ -335,7 +335,7 @@ def roofline_extra(pipe, run, first_frame, res, size, n_frames=20):
 
 def per_rank_leg(pipe, run, barrier, dist, world, rank, first, n_frames):
     """z-slab runs: what every rank did over n_frames extra frames (outside the timed region) -- voxels fused, bricks queued, and the
-    device time of its stages (HIP events) plus the merge (torch events around both all-reduces, pack, unpack; the next frame's
+    device time of its stages (HIP events) plus the merge (torch events around both all-reduces, mask, unpack; the next frame's
     preprocess is enqueued inside it while the first all-reduce is in flight).  Slabs are not equally busy: this makes it visible."""
     import torch
     pipe.stage_timers((1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 5))
@@ -359,7 +359,7 @@ def per_rank_leg(pipe, run, barrier, dist, world, rank, first, n_frames):
     rows = [{k: (int(v) if k in ("rank", "n_upd_per_frame", "bricks_queued_last_frame", "frames_lost", "z_begin", "z_end") else round(float(v), 2))
              for k, v in zip(keys, e.tolist())} for e in every]
     return dict(frames=n_frames, ranks=rows,
-                note="device time per frame and rank (HIP events; merge: torch events around MIN all-reduce + pack + integer SUM all-reduce + unpack, "
+                note="device time per frame and rank (HIP events; merge: torch events around MIN all-reduce + mask + integer SUM all-reduce + unpack, "
                      "with the next frame's preprocess enqueued behind the first all-reduce)")
 
 
@@ -643,7 +643,7 @@ def main():
                            backend=("none" if dist is None else ("rccl" if args.backend == "nccl" else "gloo (rehearsal: host-staged collectives, ranks may share a GPU)")),
                            partition="none" if not slab else
                            "z-slab x%d (boundaries: %s); %d halo layers per side RE-INTEGRATED by both neighbours (recomputed, not exchanged over xGMI); "
-                           "raycast merge = MIN all-reduce (t, 1.2 MB) + integer SUM all-reduce (vertex+normal, 7.4 MB); ICP %s"
+                           "raycast merge = MIN all-reduce (t, 1.2 MB) + integer SUM all-reduce (vertex ray parameter + normal, 4.9 MB); ICP %s"
                            % (world, "balanced from a one-frame 256^3 probe of the work per z-layer" if (world > 1 and args.slab_balance == "probe") else "equal thickness",
                               pipe.halo, args.icp_mode),
                            slab_ranges=([list(r) for r in pipe.ranges] if slab else None)),

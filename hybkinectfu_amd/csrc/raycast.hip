@@ -24,6 +24,7 @@ struct RaycastArgs {
   KfMat pose_val;
   float4* out_v; float4* out_n; uchar4* out_rgb;
   float* out_t;                  // optional: ray parameter of the first crossing this context detected (+inf: none) -- z-slab merge
+  float4* out_cand;              // optional (z-slab merge, ray form): (vertex's ray parameter, normal xyz) instead of the two maps
   float inc, near_plane, far_plane;
   int has_color;
   int neg_words;                 // words of vol.negbits to keep in LDS (0: the table does not fit -> brick flags are read from global memory)
@@ -149,6 +150,18 @@ __device__ __forceinline__ void rc_march(const RaycastArgs& a, const KfVolume& v
   }
 }
 
+// the ray of pixel (x, y) -- raycastKernel :136-150.  One function for the march and for k_slab_rays_unpack, which rebuilds a vertex from
+// its ray parameter: the same operations in the same order give the same bits.
+__device__ __forceinline__ void rc_pixel_ray(const KfCam& cam, const float* T, int x, int y, float3& org, float3& dir, float3& cam_dir) {
+  cam_dir = kf_normalize(kf_depth_to_skeleton((unsigned)x, (unsigned)y, 1.0f, cam));
+  org = kf3(T[3], T[7], T[11]);
+  const float4 wd = kf_mat_vec(T, make_float4(cam_dir.x, cam_dir.y, cam_dir.z, 0.0f));
+  dir = kf3(wd.x, wd.y, wd.z);
+  dir.x = (dir.x == 0.f) ? (float)1e-15 : dir.x;
+  dir.y = (dir.y == 0.f) ? (float)1e-15 : dir.y;
+  dir.z = (dir.z == 0.f) ? (float)1e-15 : dir.z;
+}
+
 // one 32x16 pixel tile (tile_x, tile_y) by the 512 threads of a workgroup; s_tables: the workgroup's dynamic LDS
 __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, int tile_y, unsigned* s_tables) {
   const KfVolume& v = a.vol;
@@ -191,16 +204,10 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
   const float inf = __builtin_huge_valf();
   float4 out_v = make_float4(0.f, 0.f, 0.f, 0.f), out_n = make_float4(0.f, 0.f, 0.f, 0.f);
   uchar4 out_c = make_uchar4(0, 0, 0, 0);
-  float t_cross = inf, t_cross_prev = 0.f;
+  float t_cross = inf, t_cross_prev = 0.f, out_alpha = 0.f;
   const float* T = a.pose ? a.pose : a.pose_val.m;
-  // raycastKernel :136-150
-  const float3 cam_dir = kf_normalize(kf_depth_to_skeleton((unsigned)x, (unsigned)y, 1.0f, a.cam));
-  const float3 org = kf3(T[3], T[7], T[11]);
-  const float4 wd = kf_mat_vec(T, make_float4(cam_dir.x, cam_dir.y, cam_dir.z, 0.0f));
-  float3 dir = kf3(wd.x, wd.y, wd.z);
-  dir.x = (dir.x == 0.f) ? (float)1e-15 : dir.x;
-  dir.y = (dir.y == 0.f) ? (float)1e-15 : dir.y;
-  dir.z = (dir.z == 0.f) ? (float)1e-15 : dir.z;
+  float3 org, dir, cam_dir;
+  rc_pixel_ray(a.cam, T, x, y, org, dir, cam_dir);
   const float S = v.size;
   float tmin = fmaxf(fmaxf(((dir.x > 0 ? 0.f : S) - org.x) / dir.x, ((dir.y > 0 ? 0.f : S) - org.y) / dir.y), ((dir.z > 0 ? 0.f : S) - org.z) / dir.z);
   float tmax = fminf(fminf(((dir.x > 0 ? S : 0.f) - org.x) / dir.x, ((dir.y > 0 ? S : 0.f) - org.y) / dir.y), ((dir.z > 0 ? S : 0.f) - org.z) / dir.z);
@@ -249,6 +256,7 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
         if (gradient_for_point(v, last_pos, vtx, rS, rcell, grad)) {
           out_v = make_float4(vtx.x, vtx.y, vtx.z, 1.0f);
           out_n = make_float4(grad.x, grad.y, grad.z, 0.f);
+          out_alpha = alpha;
         }
       }
     } else if (t_cross < inf) out_v = make_float4(t_cross, 0.f, 0.f, 1.f);
@@ -260,7 +268,8 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
     out_n = make_float4((float)n_samp, 0.f, 0.f, 0.f);
   }
 #endif
-  a.out_v[pix] = out_v; a.out_n[pix] = out_n;
+  if (a.out_cand) a.out_cand[pix] = make_float4(out_alpha, out_n.x, out_n.y, out_n.z);      // vertex = org + dir * alpha, rebuilt by k_slab_rays_unpack
+  else { a.out_v[pix] = out_v; a.out_n[pix] = out_n; }
   if (a.work) {
     // what the REFERENCE's march reads for this ray (raycastingVolume.cu:65-119): one voxel per sample from t_min up to the
     // crossing (or t_max); a crossing is evaluated with 2 + 6 trilinear look-ups of 8 voxels each
@@ -301,7 +310,7 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast_prefetch(RaycastArg
 }
 
 static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, const kf_raycast_params* rp, const kf_camera_params* cam,
-                          float near_plane, float far_plane, float* out_t, float4* out_v, float4* out_n) {
+                          float near_plane, float far_plane, float* out_t, float4* out_v, float4* out_n, float4* out_cand = nullptr) {
   if (!c || !rp || !cam) return KF_ERR_ARG;
   if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
   if (has_color && (!c->vol.color || !c->raycast_rgb)) return KF_ERR_STATE;
@@ -310,7 +319,7 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
   a.cam.cols = (int)cam->cols; a.cam.rows = (int)cam->rows; a.cam.cx = cam->cx; a.cam.cy = cam->cy; a.cam.fx = cam->fx; a.cam.fy = cam->fy;
   if (transform) { for (int i = 0; i < 16; ++i) a.pose_val.m[i] = transform->m[i]; a.pose = nullptr; }
   else a.pose = c->track->pose;
-  a.out_v = out_v ? out_v : c->model_v[0]; a.out_n = out_n ? out_n : c->model_n[0]; a.out_rgb = c->raycast_rgb; a.out_t = out_t;
+  a.out_v = out_v ? out_v : c->model_v[0]; a.out_n = out_n ? out_n : c->model_n[0]; a.out_rgb = c->raycast_rgb; a.out_t = out_t; a.out_cand = out_cand;
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
   { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_RAYCAST_EXP"); a.exp_mode = em; }
   a.work = c->count_work ? c->counters : nullptr;
@@ -367,18 +376,20 @@ extern "C" int kf_raycast_volume(kf_ctx* c, int has_color, const kf_mat44* trans
 // owns.  dev_t[pixel] = ray parameter of that crossing (+inf if none), dev_v / dev_n = the vertex / normal it produced
 // (zeros when the reference would have given up at that crossing).  The caller reduces over the slabs -- first crossing
 // along the ray wins, exactly the reference's sequential march -- and hands the result back with kf_set_model_maps_device.
+// The previous sample of the first owned one lies up to x = inc/cell layers outside the owned range and the trilinear +
+// gradient taps around a vertex next to it reach ceil(x) + 2 layers: a thinner halo would silently lose crossings at the
+// slab faces (those reads fail), so it is refused.  Layers clipped by the volume's own faces do not count.
+static int slab_halo_check(const kf_ctx* c, const kf_raycast_params* rp) {
+  const int need = (int)ceilf(rp->ray_increment / c->vol.cell) + 2;
+  const int lo = c->vol.own_z0 - c->vol.bz0 * KF_BRICK, hi = c->vol.bz1 * KF_BRICK - c->vol.own_z1;
+  return ((c->vol.own_z0 > 0 && lo < need) || (c->vol.own_z1 < c->vol.res && hi < need)) ? KF_ERR_ARG : 0;
+}
 extern "C" int kf_raycast_volume_slab(kf_ctx* c, int has_color, const kf_mat44* transform, const kf_raycast_params* rp,
                                       const kf_camera_params* cam, float near_plane, float far_plane,
                                       float* dev_t, float* dev_v, float* dev_n) {
   if (!c || !rp || !dev_t || !dev_v || !dev_n) return KF_ERR_ARG;
-  // The previous sample of the first owned one lies up to x = inc/cell layers outside the owned range and the trilinear +
-  // gradient taps around a vertex next to it reach ceil(x) + 2 layers: a thinner halo would silently lose crossings at the
-  // slab faces (those reads fail), so it is refused.  Layers clipped by the volume's own faces do not count.
-  {
-    const int need = (int)ceilf(rp->ray_increment / c->vol.cell) + 2;
-    const int lo = c->vol.own_z0 - c->vol.bz0 * KF_BRICK, hi = c->vol.bz1 * KF_BRICK - c->vol.own_z1;
-    if ((c->vol.own_z0 > 0 && lo < need) || (c->vol.own_z1 < c->vol.res && hi < need)) return KF_ERR_ARG;
-  }
+  const int st = slab_halo_check(c, rp);
+  if (st) return st;
   return raycast_launch(c, has_color, transform, rp, cam, near_plane, far_plane, dev_t, (float4*)dev_v, (float4*)dev_n);
 }
 
@@ -397,40 +408,57 @@ extern "C" int kf_slab_mask_candidates(kf_ctx* c, const float* dev_t, const floa
   return (int)hipGetLastError();
 }
 
-// The same merge with a smaller exchange: the winner's vertex and normal travel as six floats per pixel (the two w components
-// are constants of a valid pixel -- 1 and 0 -- and zero otherwise), so the integer SUM all-reduce moves 24 instead of 32 bytes
-// per pixel.  kf_slab_pack_candidates masks and packs in one launch; kf_set_model_maps_packed unpacks the reduced buffer
-// straight into the model maps (a unit normal is never all-zero, which is what marks a valid pixel).
-__global__ void __launch_bounds__(256) k_slab_pack(const float* __restrict__ t, const float* __restrict__ tmin, const float4* __restrict__ v,
-                                                   const float4* __restrict__ n, float* __restrict__ packed, int npx) {
+// The same merge with a smaller exchange (what SlabPipeline runs): a candidate travels in RAY FORM -- the vertex's ray parameter and the
+// normal, 16 bytes per pixel instead of two 16-byte maps.  A vertex is `org + dir * alpha` (raycastingVolume.cu:98-99) and the pixel's ray
+// is a pure function of the pose and the camera, which every rank holds bit for bit: k_slab_rays_unpack repeats those operations
+// (rc_pixel_ray) and arrives at the owner's vertex bits.  kf_raycast_volume_slab_rays writes the candidates (zeros when the reference would
+// have given up at the crossing), kf_slab_mask_rays zeroes them where another slab's crossing comes first, the caller's integer SUM
+// all-reduce returns the winner's bits and kf_set_model_maps_rays turns them into the model maps (a unit normal is never all-zero,
+// which is what marks a valid pixel).
+extern "C" int kf_raycast_volume_slab_rays(kf_ctx* c, int has_color, const kf_mat44* transform, const kf_raycast_params* rp,
+                                           const kf_camera_params* cam, float near_plane, float far_plane, float* dev_t, float* dev_cand) {
+  if (!c || !rp || !dev_t || !dev_cand) return KF_ERR_ARG;
+  const int st = slab_halo_check(c, rp);
+  if (st) return st;
+  return raycast_launch(c, has_color, transform, rp, cam, near_plane, far_plane, dev_t, nullptr, nullptr, (float4*)dev_cand);
+}
+__global__ void __launch_bounds__(256) k_slab_rays_mask(const float* __restrict__ t, const float* __restrict__ tmin, float4* __restrict__ cand, int npx) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= npx) return;
   const float ti = t[i];
-  const bool win = ti == tmin[i] && ti < __builtin_huge_valf();
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 vi = win ? v[i] : z, ni = win ? n[i] : z;
-  float* o = packed + (size_t)i * 6;
-  o[0] = vi.x; o[1] = vi.y; o[2] = vi.z; o[3] = ni.x; o[4] = ni.y; o[5] = ni.z;
+  if (!(ti == tmin[i] && ti < __builtin_huge_valf())) cand[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
-__global__ void __launch_bounds__(256) k_slab_unpack(const float* __restrict__ packed, float4* __restrict__ v, float4* __restrict__ n, int npx) {
+struct SlabUnpackArgs { const float4* cand; float4* v; float4* n; KfCam cam; const float* pose; KfMat pose_val; };
+__global__ void __launch_bounds__(256) k_slab_rays_unpack(SlabUnpackArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= npx) return;
-  const float* p = packed + (size_t)i * 6;
-  const float nx = p[3], ny = p[4], nz = p[5];
-  const bool valid = nx != 0.f || ny != 0.f || nz != 0.f;
-  v[i] = valid ? make_float4(p[0], p[1], p[2], 1.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
-  n[i] = make_float4(nx, ny, nz, 0.f);
+  if (i >= a.cam.cols * a.cam.rows) return;
+  const float4 cd = a.cand[i];
+  const bool valid = cd.y != 0.f || cd.z != 0.f || cd.w != 0.f;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) {
+    float3 org, dir, cam_dir;
+    rc_pixel_ray(a.cam, a.pose ? a.pose : a.pose_val.m, i % a.cam.cols, i / a.cam.cols, org, dir, cam_dir);
+    const float3 vtx = kf_add(org, kf_scale(dir, cd.x));
+    v = make_float4(vtx.x, vtx.y, vtx.z, 1.0f);
+  }
+  a.v[i] = v;
+  a.n[i] = make_float4(cd.y, cd.z, cd.w, 0.f);
 }
-extern "C" int kf_slab_pack_candidates(kf_ctx* c, const float* dev_t, const float* dev_tmin, const float* dev_v, const float* dev_n, float* dev_packed) {
-  if (!c || !dev_t || !dev_tmin || !dev_v || !dev_n || !dev_packed) return KF_ERR_ARG;
+extern "C" int kf_slab_mask_rays(kf_ctx* c, const float* dev_t, const float* dev_tmin, float* dev_cand) {
+  if (!c || !dev_t || !dev_tmin || !dev_cand) return KF_ERR_ARG;
   const int npx = c->cols * c->rows;
-  hipLaunchKernelGGL(k_slab_pack, dim3(kf_div_up(npx, 256)), dim3(256), 0, c->stream, dev_t, dev_tmin, (const float4*)dev_v, (const float4*)dev_n, dev_packed, npx);
+  hipLaunchKernelGGL(k_slab_rays_mask, dim3(kf_div_up(npx, 256)), dim3(256), 0, c->stream, dev_t, dev_tmin, (float4*)dev_cand, npx);
   return (int)hipGetLastError();
 }
-extern "C" int kf_set_model_maps_packed(kf_ctx* c, const float* dev_packed) {
-  if (!c || !dev_packed) return KF_ERR_ARG;
-  const int npx = c->cols * c->rows;
-  hipLaunchKernelGGL(k_slab_unpack, dim3(kf_div_up(npx, 256)), dim3(256), 0, c->stream, dev_packed, c->model_v[0], c->model_n[0], npx);
+extern "C" int kf_set_model_maps_rays(kf_ctx* c, const kf_mat44* transform, const kf_camera_params* cam, const float* dev_cand) {
+  if (!c || !cam || !dev_cand) return KF_ERR_ARG;
+  if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
+  SlabUnpackArgs a;
+  a.cand = (const float4*)dev_cand; a.v = c->model_v[0]; a.n = c->model_n[0];
+  a.cam.cols = (int)cam->cols; a.cam.rows = (int)cam->rows; a.cam.cx = cam->cx; a.cam.cy = cam->cy; a.cam.fx = cam->fx; a.cam.fy = cam->fy;
+  if (transform) { for (int k = 0; k < 16; ++k) a.pose_val.m[k] = transform->m[k]; a.pose = nullptr; }
+  else a.pose = c->track->pose;                       // the pose the raycast used: nothing moves it between the raycast and this call
+  hipLaunchKernelGGL(k_slab_rays_unpack, dim3(kf_div_up(c->cols * c->rows, 256)), dim3(256), 0, c->stream, a);
   return (int)hipGetLastError();
 }
 

@@ -157,25 +157,24 @@ class SlabExchange:
     """The collective sequence that merges one frame's per-slab raycast candidates (first crossing along each ray wins):
 
         tmin <- t;  MIN all-reduce(tmin), asynchronous  ->  [overlap(): independent work]  ->  wait
-        pack(t, tmin, v, n -> packed)          losers zeroed, winner's vertex xyz + normal xyz: 24 B per pixel
-        integer SUM all-reduce(packed bits)    exactly one rank contributes non-zero bits per pixel; integer sums keep -0.0
-        unpack(packed)                         -> model maps of every rank
+        mask(t, tmin, cand)                    losers zeroed in place
+        integer SUM all-reduce(cand bits)      exactly one rank contributes non-zero bits per pixel; integer sums keep -0.0
+        unpack(cand)                           -> model maps of every rank
 
-    `pack` / `unpack` are the device launches (kf_slab_pack_candidates / kf_set_model_maps_packed) in SlabPipeline; the
-    CPU-only tests and `bench.py --collective-selftest` pass plain-torch restatements of the two kernels and a gloo group, so
-    the SAME sequence of collectives runs at world_size 2 without a GPU.
+    A candidate is in RAY FORM: (ray parameter of the vertex, normal xyz), 16 bytes per pixel -- the vertex is rebuilt from the pixel's
+    ray, which every rank derives from the same pose bits.  `mask` / `unpack` are the device launches (kf_slab_mask_rays /
+    kf_set_model_maps_rays) in SlabPipeline; the CPU-only tests and `bench.py --collective-selftest` pass restatements of the two
+    kernels and a gloo group, so the SAME sequence of collectives runs at world_size 2 without a GPU.
     """
 
-    def __init__(self, rows, cols, device, dist, pack, unpack):
+    def __init__(self, rows, cols, device, dist, mask, unpack):
         import torch
-        self.dist, self.pack, self.unpack = dist, pack, unpack
+        self.dist, self.mask, self.unpack = dist, mask, unpack
         self.t = torch.empty((rows, cols), dtype=torch.float32, device=device)
         self.tmin = torch.empty_like(self.t)
-        self.vn = torch.empty((2, rows, cols, 4), dtype=torch.float32, device=device)       # candidates: vertex map, normal map
-        self.v, self.n = self.vn[0], self.vn[1]
-        # what actually crosses xGMI: vertex xyz + normal xyz of the winner, 24 bytes per pixel (7.4 MB at VGA)
-        self.packed = torch.empty((rows, cols, 6), dtype=torch.float32, device=device)
-        self.packed_bits = self.packed.view(torch.int32)
+        # what crosses xGMI besides the 4-byte crossing parameter: ray parameter + normal xyz of the winner, 16 bytes per pixel (4.9 MB at VGA)
+        self.cand = torch.empty((rows, cols, 4), dtype=torch.float32, device=device)
+        self.cand_bits = self.cand.view(torch.int32)
 
     def merge(self, overlap=None):
         dist = self.dist
@@ -184,9 +183,9 @@ class SlabExchange:
         if overlap is not None:
             overlap()             # runs while the collective is in flight (RCCL's own stream until wait() joins it)
         pending.wait()
-        self.pack(self.t, self.tmin, self.v, self.n, self.packed)
-        dist.all_reduce(self.packed_bits, op=dist.ReduceOp.SUM)
-        self.unpack(self.packed)
+        self.mask(self.t, self.tmin, self.cand)
+        dist.all_reduce(self.cand_bits, op=dist.ReduceOp.SUM)
+        self.unpack(self.cand)
 
 
 def slab_halo_layers(res, size, ray_increment):
@@ -234,8 +233,8 @@ class SlabPipeline:
         self.ctx.set_stream(self.stream.cuda_stream)
         c = self.ctx
         self.ex = SlabExchange(kcam.rows, kcam.cols, dev, dist,
-                               pack=lambda t, tmin, v, n, packed: c.slab_pack_candidates(t.data_ptr(), tmin.data_ptr(), v.data_ptr(), n.data_ptr(), packed.data_ptr()),
-                               unpack=lambda packed: c.set_model_maps_packed(packed.data_ptr()))
+                               mask=lambda t, tmin, cand: c.slab_mask_rays(t.data_ptr(), tmin.data_ptr(), cand.data_ptr()),
+                               unpack=lambda cand: c.set_model_maps_rays(None, cand.data_ptr()))
         self.sums = torch.zeros(32, dtype=torch.float32, device=dev)
         self._preprocessed = None           # device pointer of a frame whose preprocess was enqueued during the previous frame's merge
         self._merge_events = None           # time_merge(True): (start, end) torch event pairs around every frame's merge
@@ -263,7 +262,7 @@ class SlabPipeline:
         else:
             c.icp_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
         c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist)
-        c.raycast_slab(None, self.inc, P["depth_trunc_min"], self.trunc_max, ex.t.data_ptr(), ex.v.data_ptr(), ex.n.data_ptr())
+        c.raycast_slab_rays(None, self.inc, P["depth_trunc_min"], self.trunc_max, ex.t.data_ptr(), ex.cand.data_ptr())
 
         def overlap():
             # the MIN all-reduce runs on RCCL's own stream until wait() joins it: the next frame's preprocess -- every reader of
@@ -281,7 +280,7 @@ class SlabPipeline:
             ex.merge(overlap)
 
     def time_merge(self, on=True):
-        """Measurement legs only: time every frame's merge (both all-reduces, pack, unpack, and whatever the overlap hook enqueues)
+        """Measurement legs only: time every frame's merge (both all-reduces, mask, unpack, and whatever the overlap hook enqueues)
         with a torch event pair on the pipeline's stream."""
         self._merge_events = [] if on else None
 

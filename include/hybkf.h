@@ -175,10 +175,16 @@ int kf_raycast_volume_slab(kf_ctx* ctx, int has_color, const kf_mat44* transform
  * first crossing; an integer SUM over the slabs of the masked dev_v / dev_n then yields the winner's bits everywhere */
 int kf_slab_mask_candidates(kf_ctx* ctx, const float* dev_t, const float* dev_tmin, float* dev_v, float* dev_n);
 int kf_set_model_maps_device(kf_ctx* ctx, const float* dev_v, const float* dev_n);   /* model_{vertices,normals}_pyramid[0] <- device buffers */
-/* the same merge with 24 instead of 32 bytes per pixel on the wire: mask + pack (vertex xyz, normal xyz) into dev_packed
- * [rows x cols x 6 floats], integer-SUM all-reduce that buffer, then unpack it straight into the model maps */
-int kf_slab_pack_candidates(kf_ctx* ctx, const float* dev_t, const float* dev_tmin, const float* dev_v, const float* dev_n, float* dev_packed);
-int kf_set_model_maps_packed(kf_ctx* ctx, const float* dev_packed);
+/* the same merge in RAY FORM, 16 instead of 32 bytes per pixel on the wire (what pipeline.SlabPipeline runs): dev_cand[px] = float4
+ * (ray parameter of the vertex, normal xyz) -- a vertex is `origin + direction * parameter` and the pixel's ray is a pure function
+ * of pose and camera, which every slab context holds bit for bit.  kf_raycast_volume_slab_rays writes dev_t and dev_cand (zeros where
+ * the reference's march gives up at the crossing); kf_slab_mask_rays zeroes dev_cand where dev_t is not dev_tmin; after the caller's
+ * integer SUM all-reduce of dev_cand, kf_set_model_maps_rays (same transform / camera as the raycast) rebuilds the vertices and
+ * writes the model maps */
+int kf_raycast_volume_slab_rays(kf_ctx* ctx, int has_color, const kf_mat44* transform, const kf_raycast_params* raycast_params,
+                                const kf_camera_params* depth_camera, float near_plane, float far_plane, float* dev_t, float* dev_cand);
+int kf_slab_mask_rays(kf_ctx* ctx, const float* dev_t, const float* dev_tmin, float* dev_cand);
+int kf_set_model_maps_rays(kf_ctx* ctx, const kf_mat44* transform, const kf_camera_params* depth_camera, const float* dev_cand);
 
 /* Pixel-partitioned ICP ("partition pixels across GPUs, all-reduce the 27-float system").  `dev_sums` is a
  * caller-owned 32-float device buffer.  kf_icp_partition_begin builds the pyramids and arms the loop; for step = 0 ..

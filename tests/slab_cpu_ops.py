@@ -1,53 +1,75 @@
-"""Plain-torch restatements of the two device launches of the z-slab raycast merge (csrc/raycast.hip: k_slab_pack,
-k_slab_unpack) and a synthetic candidate generator.  Test infrastructure: the CPU-only world-2 tests run
+"""CPU restatements of the two device launches of the z-slab raycast merge (csrc/raycast.hip: k_slab_rays_mask,
+k_slab_rays_unpack) and a synthetic candidate generator.  Test infrastructure: the CPU-only world-2 tests run
 pipeline.SlabExchange -- the collective sequence SlabPipeline issues on the GPU -- with these in place of the kernels;
 tests/test_gpu_slabs.py checks on the GPU that the kernels produce the same bits as these functions."""
+import numpy as np
 import torch
 
+CAM = (64, 48, 31.5, 23.5, 52.5, 52.5)           # cols, rows, cx, cy, fx, fy of the synthetic frames
+POSE = np.array([[0.9987503, -0.0499792, 0.0, 1.25], [0.0499792, 0.9987503, 0.0, 1.5], [0.0, 0.0, 1.0, 0.125], [0.0, 0.0, 0.0, 1.0]], np.float32)
 
-def pack(t, tmin, v, n, packed):
-    """k_slab_pack: this rank's candidate survives where it IS the first crossing (t == tmin, finite); losers contribute
-    zero bits.  Vertex xyz + normal xyz, 6 floats per pixel."""
+
+def mask(t, tmin, cand):
+    """k_slab_rays_mask: this rank's candidate survives where it IS the first crossing (t == tmin, finite); losers contribute zero
+    bits.  A candidate is (ray parameter of the vertex, normal xyz), 4 floats per pixel; in place."""
     win = ((t == tmin) & torch.isfinite(t)).unsqueeze(-1).to(torch.int32)
-    packed.view(torch.int32)[..., 0:3] = v.view(torch.int32)[..., 0:3] * win
-    packed.view(torch.int32)[..., 3:6] = n.view(torch.int32)[..., 0:3] * win
+    cand.view(torch.int32).mul_(win)
 
 
-def unpack(packed):
-    """k_slab_unpack: a unit normal is never all-zero, which marks a valid pixel (vertex w = 1, else the zero vertex)."""
-    nrm = packed[..., 3:6]
-    valid = (nrm != 0).any(dim=-1, keepdim=True)
-    v = torch.zeros(packed.shape[:-1] + (4,), dtype=torch.float32)
-    n = torch.zeros_like(v)
-    v[..., 0:3] = torch.where(valid, packed[..., 0:3], torch.zeros_like(nrm))
-    v[..., 3:4] = valid.to(torch.float32)
-    n[..., 0:3] = nrm
-    return v, n
+def pixel_rays(pose, cam, rows, cols):
+    """rc_pixel_ray (raycastKernel raycastingVolume.cu:136-150) operation for operation in fp32: origin [3], direction [rows, cols, 3]."""
+    f = np.float32
+    T = np.asarray(pose, f)
+    _, _, cx, cy, fx, fy = cam
+    vx = np.broadcast_to(((np.arange(cols, dtype=f) - f(cx)) * f(1.0) / f(fx))[None, :], (rows, cols))
+    vy = np.broadcast_to(((np.arange(rows, dtype=f) - f(cy)) * f(1.0) / f(fy))[:, None], (rows, cols))
+    vz = np.ones((rows, cols), f)
+    ln = np.sqrt((vx * vx + vy * vy) + vz * vz)
+    r = (1.0 / ln.astype(np.float64)).astype(f)              # cuda_declar.h:89-94: reciprocal in double, narrowed
+    d = [vx * r, vy * r, vz * r]
+    out = np.empty((rows, cols, 3), f)
+    for k in range(3):
+        w = ((T[k, 0] * d[0] + T[k, 1] * d[1]) + T[k, 2] * d[2]) + T[k, 3] * f(0.0)
+        out[..., k] = np.where(w == 0, f(1e-15), w)
+    return T[:3, 3].copy(), out
+
+
+def unpack(cand, pose=POSE, cam=CAM):
+    """k_slab_rays_unpack: a unit normal is never all-zero, which marks a valid pixel: vertex = origin + direction * parameter, w = 1
+    (else the zero vertex); the normal's w is 0."""
+    c = cand.numpy()
+    rows, cols = c.shape[:2]
+    org, dirs = pixel_rays(pose, cam, rows, cols)
+    valid = (c[..., 1:4] != 0).any(axis=-1)
+    v = np.zeros((rows, cols, 4), np.float32)
+    n = np.zeros_like(v)
+    vt = org[None, None, :] + dirs * c[..., 0:1]
+    v[..., 0:3] = np.where(valid[..., None], vt, np.float32(0.0))
+    v[..., 3] = valid.astype(np.float32)
+    n[..., 0:3] = c[..., 1:4]
+    return torch.from_numpy(v), torch.from_numpy(n)
 
 
 def synthetic_candidates(rows, cols, rank, world, seed):
     """What `world` slabs would report for one frame, generated identically on every rank from `seed`: per pixel an owner
     slab (or none), the owner's crossing (some of them 'failed': the reference gives up there and leaves zeros -- the zeros must
-    still win), later slabs report a losing crossing further along the ray.  Returns this rank's (t, v, n) and the merged
-    maps every rank must end up with."""
+    still win), later slabs report a losing crossing further along the ray.  Returns this rank's (t, cand) and the merged model
+    maps (vertex, normal) every rank must end up with."""
     g = torch.Generator().manual_seed(seed)
     owner = torch.randint(0, world + 1, (rows, cols), generator=g)              # == world: no crossing anywhere
     t_true = torch.rand((rows, cols), generator=g) * 3 + 0.3
-    v_true = torch.randn((rows, cols, 4), generator=g)
-    n_true = torch.randn((rows, cols, 4), generator=g)
-    v_true[..., 3] = 1.0
-    n_true[..., 3] = 0.0
-    v_true[0, 0, :3] = torch.tensor([-0.0, 1.0, -0.0])                         # signed zeros must survive the integer sum
+    c_true = torch.randn((rows, cols, 4), generator=g)
+    c_true[..., 0] = t_true - 0.01 * torch.rand((rows, cols), generator=g)     # the vertex lies a little before the crossing's sample
+    c_true[0, 0, 1:] = torch.tensor([-0.0, 1.0, -0.0])                         # signed zeros must survive the integer sum
     failed = torch.rand((rows, cols), generator=g) < 0.2
-    v_true[failed] = 0
-    n_true[failed] = 0
+    c_true[failed] = 0
     mine = owner == rank
     later = (owner < rank) & (owner < world)
     inf = torch.full_like(t_true, float("inf"))
     t = torch.where(mine, t_true, torch.where(later, t_true + 0.5, inf))
-    seven = torch.full_like(v_true, 7.0)
-    zero = torch.zeros_like(v_true)
-    v = torch.where(mine.unsqueeze(-1), v_true, torch.where(later.unsqueeze(-1), seven, zero))
-    n = torch.where(mine.unsqueeze(-1), n_true, torch.where(later.unsqueeze(-1), seven, zero))
+    seven = torch.full_like(c_true, 7.0)
+    zero = torch.zeros_like(c_true)
+    cand = torch.where(mine.unsqueeze(-1), c_true, torch.where(later.unsqueeze(-1), seven, zero))
     has = (owner < world).unsqueeze(-1)
-    return t.contiguous(), v.contiguous(), n.contiguous(), torch.where(has, v_true, zero), torch.where(has, n_true, zero)
+    want_v, want_n = unpack(torch.where(has, c_true, zero).contiguous())
+    return t.contiguous(), cand.contiguous(), want_v, want_n

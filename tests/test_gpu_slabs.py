@@ -68,7 +68,22 @@ def test_slabs_equal_whole_volume(world, maxw, frames, balanced):
         assert int((wv[..., 3] != 0).sum()) > 10000
         assert np.array_equal(merged[0].cpu().numpy().view(np.uint32), wv.view(np.uint32))
         assert np.array_equal(merged[1].cpu().numpy().view(np.uint32), wn.view(np.uint32))
+        # the same merge in ray form (what SlabPipeline sends: 16 bytes per pixel): candidates (vertex's ray parameter, normal), masked by
+        # the device launch, integer-summed, vertices rebuilt from the rays -- must arrive at the same bits as the maps above
+        acc = torch.zeros((cam[1], cam[0], 4), dtype=torch.int32, device=dev)
+        for c, (t, _, _) in zip(slabs, bufs):
+            cand = torch.empty((cam[1], cam[0], 4), dtype=torch.float32, device=dev)
+            c.raycast_slab_rays(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], t.data_ptr(), cand.data_ptr())
+            c.slab_mask_rays(t.data_ptr(), tmin.data_ptr(), cand.data_ptr())
+            c.sync()
+            acc += cand.view(torch.int32)
+        rays = acc.view(torch.float32).contiguous()
         for c in slabs:
+            c.set_model_maps_rays(None, rays.data_ptr())
+            c.sync()
+            assert np.array_equal(c.download_map(K.MAP_MODEL_VERTICES).view(np.uint32), wv.view(np.uint32))
+            assert np.array_equal(c.download_map(K.MAP_MODEL_NORMALS).view(np.uint32), wn.view(np.uint32))
+        for c in slabs[:1]:                                        # (and the map form's hand-over still works)
             c.set_model_maps_device(merged[0].data_ptr(), merged[1].data_ptr())
             c.sync()
     # volumes: owned layers of every slab equal the whole volume; update counts add up over the owned layers
@@ -203,34 +218,34 @@ def test_slab_pipeline_over_rccl_matches_single_gpu_pipeline():
         dist.destroy_process_group()
 
 
-def test_pack_unpack_kernels_equal_torch_restatement():
-    """k_slab_pack / k_slab_unpack (what SlabPipeline launches between its two all-reduces) == tests/slab_cpu_ops.py, the
-    restatement the CPU-only world-2 tests run in their place -- bit for bit, for every rank's view of a synthetic frame."""
+def test_mask_unpack_kernels_equal_cpu_restatement():
+    """k_slab_rays_mask / k_slab_rays_unpack (what SlabPipeline launches between its two all-reduces) == tests/slab_cpu_ops.py, the
+    restatement the CPU-only world-2 tests run in their place -- bit for bit, for every rank's view of a synthetic frame; the vertex
+    rebuilt from its ray parameter included (rc_pixel_ray operation for operation in numpy fp32)."""
     import slab_cpu_ops as ops
-    cam = (64, 48, 31.5, 23.5, 52.5, 52.5)
-    ctx = K.Context(K.camera(*cam), 32, 3.0, levels=3)
+    ctx = K.Context(K.camera(*ops.CAM), 32, 3.0, levels=3)
     world = 3
-    total = torch.zeros((48, 64, 6), dtype=torch.int32)
+    total = torch.zeros((48, 64, 4), dtype=torch.int32)
     for rank in range(world):
-        t, v, n, want_v, want_n = ops.synthetic_candidates(48, 64, rank, world, seed=11)
+        t, cand, want_v, want_n = ops.synthetic_candidates(48, 64, rank, world, seed=11)
         ts = torch.stack([ops.synthetic_candidates(48, 64, r, world, seed=11)[0] for r in range(world)])
         tmin = ts.min(dim=0).values
-        want = torch.empty((48, 64, 6), dtype=torch.float32)
-        ops.pack(t, tmin, v, n, want)
-        td, tmd, vd, nd = t.cuda(), tmin.cuda(), v.cuda(), n.cuda()
-        pd = torch.full((48, 64, 6), 9.0, dtype=torch.float32, device="cuda")
-        ctx.slab_pack_candidates(td.data_ptr(), tmd.data_ptr(), vd.data_ptr(), nd.data_ptr(), pd.data_ptr())
+        want = cand.clone()
+        ops.mask(t, tmin, want)
+        td, tmd, cd = t.cuda(), tmin.cuda(), cand.cuda()
+        ctx.slab_mask_rays(td.data_ptr(), tmd.data_ptr(), cd.data_ptr())
         ctx.sync()
-        assert torch.equal(pd.cpu().view(torch.int32), want.view(torch.int32))
+        assert torch.equal(cd.cpu().view(torch.int32), want.view(torch.int32))
         total += want.view(torch.int32)
     merged = total.view(torch.float32).contiguous()
     md = merged.cuda()
-    ctx.set_model_maps_packed(md.data_ptr())
+    ctx.set_model_maps_rays(ops.POSE, md.data_ptr())
     ctx.sync()
     uv, un = ops.unpack(merged)
     assert np.array_equal(ctx.download_map(K.MAP_MODEL_VERTICES).view(np.uint32), uv.numpy().view(np.uint32))
     assert np.array_equal(ctx.download_map(K.MAP_MODEL_NORMALS).view(np.uint32), un.numpy().view(np.uint32))
     assert torch.equal(uv.view(torch.int32), want_v.view(torch.int32)) and torch.equal(un.view(torch.int32), want_n.view(torch.int32))
+    assert int((uv[..., 3] == 1).sum()) > 1000
     ctx.close()
 
 

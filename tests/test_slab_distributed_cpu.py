@@ -70,18 +70,19 @@ def _exchange_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rows, cols = 30, 44
     model = {}
-    ex = PL.SlabExchange(rows, cols, torch.device("cpu"), dist, pack=ops.pack,
-                         unpack=lambda packed: model.update(zip("vn", ops.unpack(packed))))
+    ex = PL.SlabExchange(rows, cols, torch.device("cpu"), dist, mask=ops.mask,
+                         unpack=lambda cand: model.update(zip("vn", ops.unpack(cand))))
     ok = True
     for frame in range(4):
-        t, v, n, want_v, want_n = ops.synthetic_candidates(rows, cols, rank, world, seed=7 + frame)
-        ex.t.copy_(t); ex.v.copy_(v); ex.n.copy_(n)
+        t, cand, want_v, want_n = ops.synthetic_candidates(rows, cols, rank, world, seed=7 + frame)
+        ex.t.copy_(t); ex.cand.copy_(cand)
         calls = []
         ex.merge(lambda: calls.append(1))
         ok = ok and calls == [1]
         ok = ok and torch.equal(model["v"].view(torch.int32), want_v.view(torch.int32))
         ok = ok and torch.equal(model["n"].view(torch.int32), want_n.view(torch.int32))
         # the same rule through the unpacked reference merge
+        v, n = ops.unpack(cand)                                  # this rank's own candidates as maps
         mv, mn = PL.merge_candidates(t, v, n, lambda x: dist.all_reduce(x, op=dist.ReduceOp.MIN), lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM))
         ok = ok and torch.equal(mv.view(torch.int32), want_v.view(torch.int32)) and torch.equal(mn.view(torch.int32), want_n.view(torch.int32))
     open(os.path.join(out_dir, "rank%d.txt" % rank), "w").write("ok" if ok else "mismatch")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Pretty-print the interesting parts of a bench.py JSON line.  usage: show_bench_line.py <file>"""
+"""Pretty-print the interesting parts of a bench.py JSON line.  usage: show_bench_line.py <file> (or the line on stdin)"""
 import json, sys
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+d = json.loads((open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin).read().strip().splitlines()[-1])
 r = d.get("roofline", {})
 print("value %.2f %s  ms/step %.4f  n_gpus %d  regime %s  env %s" % (d["value"], d["unit"], d["ms_per_step"], d["n_gpus"], d.get("regime", {}).get("name"), d["config"].get("env")))
 print("roofline: kernel_ms %s frac %s achieved %s stage %s" % (r.get("kernel_ms"), r.get("frac"), r.get("achieved"), (r.get("stage") or {}).get("ms")))
