@@ -110,7 +110,7 @@ extern "C" int kf_destroy(kf_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->own_stream) hipStreamSynchronize(c->own_stream);
   void* ptrs[] = {c->up_dev[0], c->up_dev[1], c->raw_depth, c->trunced_depth, c->filtered_depth, c->raw_rgb, c->raycast_rgb, c->icp_partials, c->icp_loop_slots,
-                  c->track, c->counters, c->grid_barrier, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macro, c->vol.negbits, c->active_bricks,
+                  c->track, c->counters, c->grid_barrier, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macrobits, c->vol.negbits, c->active_bricks,
                   c->tile_max_depth, c->triangles, c->mc_block_counts, c->mc_list, c->mc_nbr_bits, c->mc_partials, c->mc_codes, c->mc_surv, c->mc_block_bits, c->mc_recs, c->mc_d1_list};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->up_stream) { hipStreamSynchronize(c->up_stream); hipStreamDestroy(c->up_stream); }
@@ -201,7 +201,9 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
   if (cfg->has_color) TRY(dev_alloc(&v.color, c->n_stored_vox));
   TRY(dev_alloc(&v.flags, c->n_stored_bricks + 4));      // updated with 32-bit atomics: keep the last word whole
   v.nm = (v.res + KF_MACRO - 1) / KF_MACRO;
-  TRY(dev_alloc(&v.macro, (size_t)v.nm * v.nm * v.nm + 4));   // read as 32-bit words by the raycast's LDS copy
+  v.ns = (v.nm + (1 << KF_SUPER_SHIFT) - 1) >> KF_SUPER_SHIFT;
+  v.macro_words = kf_bit_words((size_t)v.nm * v.nm * v.nm); v.super_words = kf_bit_words((size_t)v.ns * v.ns * v.ns);
+  TRY(dev_alloc(&v.macrobits, (size_t)(v.macro_words + v.super_words)));
   TRY(dev_alloc(&v.negbits, kf_negbit_words(c->n_stored_bricks)));
   TRY(dev_alloc(&c->active_bricks, c->n_stored_bricks + 8));       // + 16 aligned spare bytes behind the queue (integrate.hip: queue_pad; +8 words keeps them aligned for any count)
   {                                                          // tile maxima over 8- and 16-pixel tiles, see integrate.hip
@@ -232,7 +234,7 @@ extern "C" int kf_reset_volume(kf_ctx* c) {
   KF_CHECK(hipMemsetAsync(c->vol.tw, 0, c->n_stored_vox * sizeof(float2), c->stream));
   if (c->vol.color) KF_CHECK(hipMemsetAsync(c->vol.color, 0, c->n_stored_vox * sizeof(uchar4), c->stream));
   KF_CHECK(hipMemsetAsync(c->vol.flags, 0, c->n_stored_bricks, c->stream));
-  KF_CHECK(hipMemsetAsync(c->vol.macro, 0, (size_t)c->vol.nm * c->vol.nm * c->vol.nm, c->stream));
+  KF_CHECK(hipMemsetAsync(c->vol.macrobits, 0, (size_t)(c->vol.macro_words + c->vol.super_words) * sizeof(unsigned), c->stream));
   KF_CHECK(hipMemsetAsync(c->vol.negbits, 0, kf_negbit_words(c->n_stored_bricks) * sizeof(unsigned), c->stream));
   KF_CHECK(hipMemsetAsync(c->counters, 0, sizeof(KfCounters), c->stream));
   ++c->vol_flags_serial; c->fuse_calls = 0;
@@ -439,10 +441,7 @@ __global__ void __launch_bounds__(256) k_rebuild_flags(KfVolume v, size_t n_bric
     if (threadIdx.x == 0) {
       v.flags[b] = (uint8_t)s_flag;
       if (s_flag & KF_FLAG_HASNEG) atomicOr(&v.negbits[b >> 5], 1u << (b & 31)); else atomicAnd(&v.negbits[b >> 5], ~(1u << (b & 31)));
-      if (s_flag & KF_FLAG_HASNEG) {
-        const int bx = (int)(b % v.nb), by = (int)((b / v.nb) % v.nb), bz = (int)(b / ((size_t)v.nb * v.nb)) + v.bz0;
-        v.macro[((size_t)(bz >> 2) * v.nm + (by >> 2)) * v.nm + (bx >> 2)] = 1;
-      }
+      if (s_flag & KF_FLAG_HASNEG) kf_mark_macro(v, (int)(b % v.nb), (int)((b / v.nb) % v.nb), (int)(b / ((size_t)v.nb * v.nb)) + v.bz0);
     }
     __syncthreads();
   }
@@ -470,6 +469,7 @@ static int volume_xfer(kf_ctx* c, uint32_t z0, uint32_t z1, float* tsdf, float* 
       if (e == hipSuccess) {
         hipLaunchKernelGGL(k_volume_import, dim3(grid), dim3(256), 0, c->stream, c->vol, (int)z0, (int)z1, dt, dw, dc);
         int fg = (int)(c->n_stored_bricks > 4096 ? 4096 : c->n_stored_bricks);
+        hipMemsetAsync(c->vol.macrobits, 0, (size_t)(c->vol.macro_words + c->vol.super_words) * sizeof(unsigned), c->stream);   // rebuilt with the flags
         hipLaunchKernelGGL(k_rebuild_flags, dim3(fg), dim3(256), 0, c->stream, c->vol, c->n_stored_bricks);
       }
     }

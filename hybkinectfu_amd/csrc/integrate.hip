@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
       if (wflags && (threadIdx.x & 63) == 0) {
         atomicOr(reinterpret_cast<unsigned*>(v.flags) + (slot[b] >> 2), wflags << (8u * (slot[b] & 3u)));
         if (wflags & KF_FLAG_HASNEG) {
-          v.macro[((size_t)(bz[b] >> 2) * v.nm + (by[b] >> 2)) * v.nm + (bx[b] >> 2)] = 1;   // 4 bricks per macro edge
+          kf_mark_macro(v, bx[b], by[b], bz[b]);
           atomicOr(&v.negbits[slot[b] >> 5], 1u << (slot[b] & 31u));
         }
       }
@@ -661,7 +661,7 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
       if (wflags && (threadIdx.x & 63) == 0) {
         atomicOr(reinterpret_cast<unsigned*>(v.flags) + (slot[b] >> 2), wflags << (8u * (slot[b] & 3u)));
         if (wflags & KF_FLAG_HASNEG) {
-          v.macro[((size_t)(bz[b] >> 2) * v.nm + (by[b] >> 2)) * v.nm + (bx[b] >> 2)] = 1;
+          kf_mark_macro(v, bx[b], by[b], bz[b]);
           atomicOr(&v.negbits[slot[b] >> 5], 1u << (slot[b] & 31u));
         }
       }
@@ -860,6 +860,24 @@ __global__ void __launch_bounds__(256) k_selftest_div(unsigned n, unsigned seed,
     return;
   }
   const float u = (float)(s >> 8) * (1.0f / 16777216.0f), w = (float)(t >> 8) * (1.0f / 16777216.0f);
+  if (mode == 12) {
+    // the closed-form walk of the ray parameter against the chain of additions it replaces: starts anywhere in [2^-4, 2^4) (and right below
+    // powers of two), increments with full mantissas, with few mantissa bits (ties with the grid of t) and tiny ones, walks of 1 .. ~400 steps
+    unsigned q = t * 22695477u + 1u; q ^= q << 13; q ^= q >> 17; q ^= q << 5;
+    float t0 = exp2f(-4.f + 8.f * u);
+    if ((i & 7u) == 3u) t0 = __uint_as_float((__float_as_uint(t0) | 0x007FFF00u) - (q & 0xFFu));          // a few ulps below the next binade
+    float inc = 1e-3f + 0.08f * w;
+    if ((i & 3u) == 1u) inc = __uint_as_float(__float_as_uint(inc) & 0xFFFFF000u);                       // short mantissa
+    if ((i & 15u) == 2u) inc = __uint_as_float((__float_as_uint(t0) & 0x7F800000u) - (24u << 23)) * (float)(3 + 2 * (q & 1023u));   // odd multiple of ulp(t)/2: every step a tie
+    if ((i & 63u) == 5u) inc = t0 * 1e-8f;                                                                 // below half an ulp: t never moves -> bounded below
+    const float steps = (float)((q >> 10) % 400u) + 0.5f * (float)((q >> 20) & 3u);
+    const float t_exit = (i & 63u) == 5u ? t0 : t0 + inc * steps;
+    float ta = t0, pa = -1.f, tb2 = t0, pb = -1.f;
+    kf_ray_advance(ta, pa, inc, t_exit);
+    kf_ray_advance_plain(tb2, pb, inc, t_exit);
+    if (__float_as_uint(ta) != __float_as_uint(tb2) || __float_as_uint(pa) != __float_as_uint(pb)) atomicAdd(mismatches, 1u);
+    return;
+  }
   float a, b;
   if (mode == 0) { a = (u * 2.f - 1.f) * 8000.f; b = 1e-4f + w * 20.f; }            // pf.x*fx / pf.z
   else if (mode == 1) { a = (u * 2.f - 1.f) * 3.f; b = 0.005f + w * 0.5f; }          // sdf / trunc

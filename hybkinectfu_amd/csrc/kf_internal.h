@@ -16,6 +16,9 @@
 #define KF_FLAG_SAT0 16u           // bits 4..7: z-layer pair q (voxels of layers 2q, 2q+1) holds nothing but (tsdf 1, weight max_weight):
                                   // free space that further free-space observations cannot change (integrate.hip)
 #define KF_MACRO 32                // voxels per macro-cell edge (raycast empty-space skipping)
+#ifndef KF_SUPER_SHIFT
+#define KF_SUPER_SHIFT 2           // a super cell is (1 << KF_SUPER_SHIFT)^3 macro cells: 128^3 voxels, the raycast's coarsest skip level
+#endif
 #define KF_MAX_LEVELS 3
 #define KF_ICP_MAX_WG 2048             // workgroups of one ICP / SDF step launch (1536 pixels each: up to 3.1 M pixels)
 #define KF_ICP_LOOP_MAX_WG 512         // workgroups of the persistent ICP loop (bounded by the CU count anyway)
@@ -44,9 +47,12 @@ struct KfVolume {
   float2* tw;            // (tsdf, weight) per voxel
   uchar4* color;         // (c0, c1, c2, unused) per voxel; null when the context has no colour
   uint8_t* flags;        // per brick KF_FLAG_*
-  uint8_t* macro;        // per 32^3-voxel macro cell of the WHOLE volume: 1 = some voxel in it has (had) tsdf < 0
+  unsigned* macrobits;   // two packed bit tables over the WHOLE volume, [macro_words | super_words]: bit = some voxel of the 32^3-voxel macro cell /
+                         // of the 128^3-voxel super cell has (had) tsdf < 0; set with atomicOr by whoever finds a brick's first negative voxel
   unsigned* negbits;     // one bit per STORED brick slot: the brick's KF_FLAG_HASNEG, packed so the raycast can keep the table in LDS
   int nm;                // macro cells per axis = ceil(res / 32)
+  int ns;                // super cells per axis = ceil(nm / 4)
+  int macro_words, super_words;   // words of the two tables (each padded to whole 16-byte vectors)
   int res;               // voxels per axis
   int nb;                // bricks per axis
   int bz0, bz1;          // stored brick layers
@@ -190,6 +196,8 @@ void kf_evt_attached_done(kf_ctx* c, int stage);
 #define KF_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 static inline int kf_div_up(int a, int b) { return (a + b - 1) / b; }
+// words of a packed table of n bits, padded to whole 16-byte vectors
+static inline int kf_bit_words(size_t n_bits) { return (int)((((n_bits + 31) >> 5) + 3) & ~(size_t)3); }
 // words of KfVolume::negbits, padded to whole 16-byte vectors (the raycast copies the table with uint4 loads)
 static inline size_t kf_negbit_words(size_t n_bricks) { return ((n_bricks + 127) / 128) * 4; }
 
@@ -303,6 +311,50 @@ __device__ __forceinline__ int2 kf_project(float3 v, const KfCam& c) {
 // (24-bit multiplies: v_mad_u32_u24 is a full-rate instruction, a 32- or 64-bit integer multiply is not, and the gather-bound kernels form
 // dozens of these per pixel.  Exact while bricks per axis <= 1024 -- kf_create refuses more --: every factor is below 2^24 and every
 // product below 2^32.  A layer below the stored range gives a meaningless slot, as the 64-bit form did: callers test kf_z_stored first.)
+// The ray parameter's walk `do { t_prev = t; t += inc; } while (t < t_exit)` (raycastingVolume.cu:116 repeats `ray_current += fRayIncrement`;
+// every sample parameter is the result of that chain of fp32 additions) without running the chain: inside one binade [2^e, 2^(e+1)) every t is
+// a multiple of u = ulp(t), so RN(t + inc) = t + s with s = inc rounded to the u-grid -- the SAME s at every step unless inc lies exactly half-way
+// between two grid points (a tie, resolved by the parity of t: detected, then the plain chain runs).  k steps therefore land on t + k*s exactly,
+// which is representable (a multiple of u below 2^(e+1)), so one fused multiply-add produces it without error.  The jump stops short of
+// min(t_exit, 2^(e+1)); the step across either is a plain addition again (RN on the coarser grid above 2^(e+1) is whatever the hardware says).
+// Exact (kf_selftest_div mode 12: 2^23 random walks incl. binade crossings and ties) and NOT used by default: a ray of 3 m takes ~85 additions
+// at the stock increment, but spread over ~10 walks of three instructions per step -- the chain is cheaper than the 35 instructions of this form
+// (raycast 75.9 vs 79.4 us at C2, 110.9 vs 115.3 us at C4, one box).  It pays when the increment is small against the cells (-DKF_RAY_ADVANCE_CLOSED).
+__device__ __forceinline__ void kf_ray_advance_plain(float& t, float& t_prev, float inc, float t_exit) {
+  do { t_prev = t; t += inc; } while (t < t_exit);
+}
+__device__ __forceinline__ void kf_ray_advance(float& t, float& t_prev, float inc, float t_exit) {
+  t_prev = t; t += inc;
+  if (t < t_exit) { t_prev = t; t += inc; }                      // short walks (a brick is two or three steps) never reach the closed form
+  while (t < t_exit) {
+    const float t1 = t + inc;
+    if (!(t1 < t_exit)) { t_prev = t; t = t1; break; }
+    const unsigned tb = __float_as_uint(t), eb = tb & 0x7F800000u;
+    const float hi = __uint_as_float(eb + 0x00800000u);          // 2^(e+1)
+    const float u = __uint_as_float(eb - (23u << 23));           // ulp(t)
+    const float s = t1 - t;                                      // exact while t1 stays in the binade (Sterbenz)
+    const float r = inc - s;                                     // exact: what the rounding dropped, |r| <= u/2
+    const float lim = fminf(t_exit, hi);
+    const bool closed = (tb - 0x0C800000u) < 0x72000000u         // t positive, normal, ulp normal, below 2^126
+                        && t1 < hi && s > 0.f && fabsf(r) * 2.f != u;
+    if (!closed) { t_prev = t; t = t1; continue; }               // one plain step: binade crossing, tie, degenerate increment
+    // the largest m >= 1 with t + m*s < lim (t1 = t + s < lim already): estimate, then settle it with exact tests
+    float m = fmaxf(floorf((lim - t) * __builtin_amdgcn_rcpf(s)), 1.f);
+    while (__builtin_fmaf(m, s, t) >= lim) m -= 1.f;
+    while (__builtin_fmaf(m + 1.f, s, t) < lim) m += 1.f;
+    t_prev = __builtin_fmaf(m - 1.f, s, t);
+    t = __builtin_fmaf(m, s, t);                                 // < lim <= t_exit: the loop goes on with a plain step
+  }
+}
+
+// brick (bx, by, bz) of the whole volume has found its first negative voxel: its macro cell and super cell are no longer empty
+__device__ __forceinline__ void kf_mark_macro(const KfVolume& v, int bx, int by, int bz) {
+  const int mx = bx >> 2, my = by >> 2, mz = bz >> 2;                                         // 4 bricks per macro edge
+  const unsigned mi = (unsigned)((mz * v.nm + my) * v.nm + mx);
+  atomicOr(&v.macrobits[mi >> 5], 1u << (mi & 31u));
+  const unsigned si = (unsigned)((((mz >> KF_SUPER_SHIFT) * v.ns) + (my >> KF_SUPER_SHIFT)) * v.ns + (mx >> KF_SUPER_SHIFT));
+  atomicOr(&v.macrobits[v.macro_words + (si >> 5)], 1u << (si & 31u));
+}
 __device__ __forceinline__ unsigned kf_brick_slot(const KfVolume& v, int bx, int by, int bz) {
   return __umul24(__umul24((unsigned)(bz - v.bz0), (unsigned)v.nb) + (unsigned)by, (unsigned)v.nb) + (unsigned)bx;
 }

@@ -59,6 +59,13 @@ __device__ __forceinline__ bool gradient_for_point(const KfVolume& v, float3 sam
   return true;
 }
 
+// the walk of the ray parameter: the chain of additions itself.  Its closed form (kf_ray_advance: exact, self-tested) is 3-4 % SLOWER here --
+// a walk is 1-12 additions at the stock increment (4.5 voxels) and the chain costs three instructions per step (-DKF_RAY_ADVANCE_CLOSED for the A/B)
+#ifdef KF_RAY_ADVANCE_CLOSED
+#define RC_ADVANCE kf_ray_advance
+#else
+#define RC_ADVANCE kf_ray_advance_plain
+#endif
 #define RAYCAST_THREADS 512
 #define RAYCAST_LDS_BYTES 49152   // budget for the two bit tables: 3 workgroups x 8 waves stay resident per CU (160 KiB LDS)
 
@@ -71,14 +78,14 @@ __device__ __forceinline__ bool rc_bit(const unsigned* words, unsigned i) { retu
 // sample's tsdf is fetched on demand), so a ray's range may be marched in pieces by different lanes: the first crossing of the ray
 // is the first piece's that has one.
 struct RcRay { float3 org, dir, inv_dir; };
-__device__ __forceinline__ void rc_march(const RaycastArgs& a, const KfVolume& v, const unsigned* s_macro, const unsigned* s_neg, bool neg_in_lds, const RcRay& ray,
+__device__ __forceinline__ void rc_march(const RaycastArgs& a, const KfVolume& v, const unsigned* s_macro, const unsigned* s_super, const unsigned* s_neg, bool neg_in_lds, const RcRay& ray,
                                          const KfRecip& rS, float t_end, float& t, float& t_prev, bool& have_last, float& last_sdf,
-                                         float& t_cross, float& t_cross_prev, int& n_iter, int& n_samp) {
+                                         float& t_cross, float& t_cross_prev, int& n_iter, int& n_samp, int& n_macro) {
   const float3 org = ray.org, dir = ray.dir;
   const int R = v.res;
   const float rf = (float)R;
   const int zs0 = v.bz0 * KF_BRICK, zs1 = v.bz1 * KF_BRICK;
-  const int nm = v.nm;
+  const int nm = v.nm, ns = v.ns;
   // the empty-space walk measures in VOXEL units along each axis: with q the sample's (unrounded) voxel coordinate and `base` the first voxel
   // of its cell (32 voxels wide for a macro cell, 8 for a brick), the cell's far face lies E - (q - base) voxels ahead for a ray going up
   // the axis and q - base voxels for one going down: one fused multiply-add per axis with the ray's constants sgn / up, times cell / |dir|
@@ -107,6 +114,8 @@ __device__ __forceinline__ void rc_march(const RaycastArgs& a, const KfVolume& v
     // a wave sit in different states, and a wave executes the union of the paths its lanes take on every trip.
     const int mx = gx >> 5, my = gy >> 5, mz = gz >> 5;
     const bool macro_empty = !rc_bit(s_macro, __umul24(__umul24((unsigned)mz, (unsigned)nm) + (unsigned)my, (unsigned)nm) + (unsigned)mx);
+    // level 0: the 128^3-voxel super cell (4 x 4 x 4 macro cells) the same way -- two thirds of a ray's trips were macro cells of open space
+    const bool super_empty = !rc_bit(s_super, __umul24(__umul24((unsigned)(mz >> KF_SUPER_SHIFT), (unsigned)ns) + (unsigned)(my >> KF_SUPER_SHIFT), (unsigned)ns) + (unsigned)(mx >> KF_SUPER_SHIFT));
     const bool owned = gz >= v.own_z0 && gz < v.own_z1;
     size_t slot = 0; bool has_neg = false;
     if (!macro_empty && owned) {
@@ -114,20 +123,23 @@ __device__ __forceinline__ void rc_march(const RaycastArgs& a, const KfVolume& v
       has_neg = neg_in_lds ? rc_bit(s_neg, (unsigned)slot) : (v.flags[slot] & KF_FLAG_HASNEG) != 0;
     }
     if (!has_neg) {
+      n_macro += macro_empty ? (super_empty ? 0x10000 : 1) : 0;
       // macro cell: walk to its far side; owned brick with the table an LDS read away: brick by brick is cheaper than sample by
       // sample (the cell is the VOXEL's brick: if rounding put pos a hair outside it, the walk is merely shorter, never past the
       // far face); otherwise one sample
       const bool walk = macro_empty || (owned && neg_in_lds);
       if (walk) {
-        const int mask = macro_empty ? ~31 : ~7;
-        const float edge = macro_empty ? 32.f : 8.f, eps = macro_empty ? 3.2e-3f : 8e-3f;       // eps: 1e-4 / 1e-3 of the cell edge, in voxels
+        const int sup = (KF_MACRO << KF_SUPER_SHIFT);
+        const int mask = super_empty ? ~(sup - 1) : macro_empty ? ~31 : ~7;
+        const float edge = super_empty ? (float)sup : macro_empty ? 32.f : 8.f;
+        const float eps = super_empty ? 1e-4f * (float)sup : macro_empty ? 3.2e-3f : 8e-3f;       // eps: 1e-4 / 1e-4 / 1e-3 of the cell edge, in voxels
         // the exit parameter only has to be conservative (eps and the 1e-6 t margin absorb a few ulps)
         const float dx = __builtin_fmaf(qx - (float)(gx & mask), sgn.x, up.x * edge) - eps;
         const float dy = __builtin_fmaf(qy - (float)(gy & mask), sgn.y, up.y * edge) - eps;
         const float dz = __builtin_fmaf(qz - (float)(gz & mask), sgn.z, up.z * edge) - eps;
         const float dt = fminf(fminf(dx * per_vox.x, dy * per_vox.y), dz * per_vox.z);
         const float t_exit = fminf(t + dt - 1e-6f * t, t_end);
-        do { t_prev = t; t += a.inc; } while (t < t_exit);      // the reference's own repeated addition: identical sample parameters
+        RC_ADVANCE(t, t_prev, a.inc, t_exit);                   // the reference's own repeated addition: identical sample parameters
       } else { t_prev = t; t += a.inc; }
       have_last = false;
       continue;
@@ -165,31 +177,23 @@ __device__ __forceinline__ void rc_pixel_ray(const KfCam& cam, const float* T, i
 // one 32x16 pixel tile (tile_x, tile_y) by the 512 threads of a workgroup; s_tables: the workgroup's dynamic LDS
 __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, int tile_y, unsigned* s_tables) {
   const KfVolume& v = a.vol;
-  // Two packed tables live in LDS so that the empty-space walk costs LDS reads instead of dependent L2 round trips (the
-  // march is latency-bound: halving the rays does not shorten it): one bit per 32^3 macro cell of the whole volume
-  // (packed here from the byte table), and -- when it fits -- one bit per stored 8^3 brick (KfVolume::negbits).
+  // Packed bit tables live in LDS so that the empty-space walk costs LDS reads instead of dependent L2 round trips: one bit
+  // per 32^3-voxel macro cell and per 128^3-voxel super cell of the whole volume (KfVolume::macrobits, kept current by the
+  // fusion pass with atomicOr: copied as they are), and -- when it fits -- one bit per stored 8^3 brick (KfVolume::negbits).
 #ifdef KF_EXPERIMENTS
   const unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #endif
-  const int nm3 = v.nm * v.nm * v.nm;
-  const int macro_words = (((nm3 + 31) >> 5) + 3) & ~3;        // multiple of 4: the brick table behind it is moved as uint4
-  unsigned* s_macro = s_tables;
-  const unsigned* s_neg = s_tables + macro_words;
+  const int skip_words = v.macro_words + v.super_words;          // multiples of 4: everything is moved as uint4
+  const unsigned* s_macro = s_tables;
+  const unsigned* s_super = s_tables + v.macro_words;
+  const unsigned* s_neg = s_tables + skip_words;
   {
-    const unsigned* src = reinterpret_cast<const unsigned*>(v.macro);            // 4 cells per word, bytes are 0 / 1
-    const int src_words = (nm3 + 3) >> 2;
-    for (int i = threadIdx.x; i < macro_words; i += RAYCAST_THREADS) {
-      unsigned bits = 0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned w = (i * 8 + j < src_words) ? src[i * 8 + j] : 0u;
-        bits |= ((w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u)) << (4 * j);
-      }
-      s_macro[i] = bits;
-    }
+    const uint4* msrc = reinterpret_cast<const uint4*>(v.macrobits);
+    uint4* mdst = reinterpret_cast<uint4*>(s_tables);
+    for (int i = threadIdx.x; i < skip_words / 4; i += RAYCAST_THREADS) mdst[i] = msrc[i];
     if (a.neg_words) {
       const uint4* nsrc = reinterpret_cast<const uint4*>(v.negbits);
-      uint4* ndst = reinterpret_cast<uint4*>(s_tables + macro_words);
+      uint4* ndst = reinterpret_cast<uint4*>(s_tables + skip_words);
       for (int i = threadIdx.x; i < a.neg_words / 4; i += RAYCAST_THREADS) ndst[i] = nsrc[i];
     }
     __syncthreads();
@@ -217,7 +221,7 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
 #ifdef KF_EXPERIMENTS
   unsigned long long st1 = __builtin_amdgcn_s_memtime(), st2 = st1;
 #endif
-  int n_iter = 0, n_samp = 0;
+  int n_iter = 0, n_samp = 0, n_macro = 0;
   if (tmin < tmax) {
     // raySample :65-119
     const int R = v.res;
@@ -236,8 +240,8 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
       t_end = fminf(tmax, t_out);
       t_first = fmaxf(tmin, fminf(t_in - 1e-6f * fabsf(t_in), t_end));
     }
-    if (t < t_first) { do { t_prev = t; t += a.inc; } while (t < t_first); have_last = false; }
-    rc_march(a, v, s_macro, s_neg, neg_in_lds, ray, rS, t_end, t, t_prev, have_last, last_sdf, t_cross, t_cross_prev, n_iter, n_samp);
+    if (t < t_first) { RC_ADVANCE(t, t_prev, a.inc, t_first); have_last = false; }
+    rc_march(a, v, s_macro, s_super, s_neg, neg_in_lds, ray, rS, t_end, t, t_prev, have_last, last_sdf, t_cross, t_cross_prev, n_iter, n_samp, n_macro);
 #ifdef KF_EXPERIMENTS
     st2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -265,7 +269,7 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
   if (KF_EXP_MODE(a) == 3) {                                                // diagnostics: shader-clock ticks of the three phases, loop trips
     const unsigned long long st3 = __builtin_amdgcn_s_memtime();
     out_v = make_float4((float)(st1 - st0), (float)(st2 - st1), (float)(st3 - st2), (float)n_iter);
-    out_n = make_float4((float)n_samp, 0.f, 0.f, 0.f);
+    out_n = make_float4((float)n_samp, (float)(n_macro & 0xFFFF), (float)(n_macro >> 16), 0.f);
   }
 #endif
   if (a.out_cand) a.out_cand[pix] = make_float4(out_alpha, out_n.x, out_n.y, out_n.z);      // vertex = org + dir * alpha, rebuilt by k_slab_rays_unpack
@@ -323,7 +327,7 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
   { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_RAYCAST_EXP"); a.exp_mode = em; }
   a.work = c->count_work ? c->counters : nullptr;
-  const size_t macro_bytes = (((((size_t)c->vol.nm * c->vol.nm * c->vol.nm + 31) / 32) + 3) & ~(size_t)3) * 4, neg_bytes = kf_negbit_words(c->n_stored_bricks) * 4;
+  const size_t macro_bytes = (size_t)(c->vol.macro_words + c->vol.super_words) * 4, neg_bytes = kf_negbit_words(c->n_stored_bricks) * 4;
   a.neg_words = (macro_bytes + neg_bytes <= RAYCAST_LDS_BYTES) ? (int)(neg_bytes / 4) : 0;
   if (macro_bytes > RAYCAST_LDS_BYTES) return KF_ERR_STATE;
   kf_evt_begin(c, KF_STAGE_RAYCAST);

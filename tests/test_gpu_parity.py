@@ -314,6 +314,10 @@ def test_exact_division_helper():
     # spelled-out definition -- the reference's CUDA conversion rule (cvt.rzi.s32): special values + 2^24 random bit patterns each
     for mode in (10, 11):
         assert ctx.selftest_div(1 << 24, 777 + mode, mode) == 0, mode
+    # the ray parameter's walk in closed form (kf_ray_advance) against the chain of fp32 additions it stands for (the reference's
+    # `ray_current += fRayIncrement`, raycastingVolume.cu:116): 2^22 random (start, increment, exit) triples incl. binade crossings and ties
+    for seed in (1, 2):
+        assert ctx.selftest_div(1 << 22, 4242 + seed, 12) == 0, seed
     ctx.close()
 
 
