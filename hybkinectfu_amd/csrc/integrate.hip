@@ -781,8 +781,20 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
     if (a.sat_cull) hipLaunchKernelGGL(k_integrate_cull<true>, dim3((n_macro + CULL_WAVES - 1) / CULL_WAVES), dim3(CULL_WAVES * 64), 0, c->stream, a);
     else hipLaunchKernelGGL(k_integrate_cull<false>, dim3((n_macro + CULL_WAVES - 1) / CULL_WAVES), dim3(CULL_WAVES * 64), 0, c->stream, a);
   }
-  static unsigned grid_cap = 0;                          // workgroups walking the queue: tuning knob
-  if (!grid_cap) { const char* e = getenv("KF_INTEGRATE_GRID"); grid_cap = e ? (unsigned)atoi(e) : 8192u; if (grid_cap < 64u || grid_cap > 65536u) grid_cap = 8192u; }
+  // Workgroups walking the queue.  Large volumes (>= 2^20 stored bricks: the queue holds >~100k bricks): 8192 workgroups with four bricks in
+  // flight each.  Smaller ones: ONE brick in flight and exactly as many workgroups as the chip holds at once (8 per CU) -- at 512^3 the queue
+  // is ~9 k bricks, i.e. 2.2 rounds of 4.5 k two-brick workgroups of which the last is a fifth full; 2048 resident workgroups that each walk
+  // 4-5 bricks with the look-ahead end together: 20.0 -> 18.5 us at 512^3, 11.8 -> 9.6 us at 256^3, one box (at 1024^3 the same form loses: 324 vs
+  // 304 us).  KF_INTEGRATE_GRID / KF_INTEGRATE_BR override.
+  static unsigned grid_env = 0, resident = 0;
+  if (!grid_env) { const char* e = getenv("KF_INTEGRATE_GRID"); grid_env = e ? (unsigned)atoi(e) : 1u; if (grid_env != 1u && (grid_env < 64u || grid_env > 65536u)) grid_env = 1u; }
+  if (!resident) {
+    int per_cu = 0; hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_integrate_pairs<1, false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+    resident = (hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0) ? (unsigned)(prop.multiProcessorCount * per_cu) : 2048u;
+  }
+  const bool big = c->n_stored_bricks >= ((size_t)1 << 20);
+  const unsigned grid_cap = grid_env != 1u ? grid_env : (big || has_color ? 8192u : resident);
   unsigned grid = (unsigned)(c->n_stored_bricks < grid_cap ? c->n_stored_bricks : grid_cap);
   // the roofline kernel's live timer: the event pair rides on the dispatch itself (kf_evt_attach), so what is measured is the kernel, as rocprofv3 sees it
   hipEvent_t ke0 = nullptr, ke1 = nullptr;
@@ -800,11 +812,10 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   }
   else if (has_color) FUSE_LAUNCH((k_integrate_bricks<true, 1>));
   else {
-    // bricks in flight per workgroup: 2, or 4 when the stored volume is large enough for the queue to hold >~100k bricks
-    // (measured: 512^3 24 us with 2 vs 25 us with 4; 1024^3 378 us with 2 vs 358 us with 4).  KF_INTEGRATE_BR overrides.
+    // bricks in flight per workgroup (see the grid above): 1, or 4 for large volumes.  KF_INTEGRATE_BR overrides.
     static int br_env = -1;
     if (br_env < 0) { const char* e = getenv("KF_INTEGRATE_BR"); br_env = e ? atoi(e) : 0; if (br_env != 1 && br_env != 2 && br_env != 4) br_env = 0; }
-    const int br = br_env ? br_env : (c->n_stored_bricks >= ((size_t)1 << 20) ? 4 : 2);
+    const int br = br_env ? br_env : (big ? 4 : 1);
     static int pairs = -1;                               // 1 (default): the packed-pair kernel; 0: the scalar one (A/B and colour path)
     if (pairs < 0) { const char* e = getenv("KF_INTEGRATE_PAIRS"); pairs = e ? atoi(e) : 1; }
 #ifdef KF_EXPERIMENTS
