@@ -160,6 +160,34 @@ def test_triangle_cap():
     ctx.close(); ctx2.close()
 
 
+def test_raycast_after_volume_upload_uses_rebuilt_skip_tables():
+    """kf_upload_volume rebuilds the brick flags and the packed macro / super-cell tables the raycast's empty-space walk reads (ctx.hip
+    k_rebuild_flags): a volume uploaded into a fresh context, and into a context that held OTHER content before, must raycast to the
+    oracle's maps bit for bit; an empty volume uploaded over a used one leaves no stale cell behind (no hit anywhere)."""
+    res, size = 128, 3.0
+    ctx, ovol, pose, ocam = _fuse_sequence(res, size, small_cam(), 3, 5 * size / res, 2.5)
+    inc = 0.8 * 5 * size / res
+    ov, on, _ = O.raycast(ovol, False, pose, inc, ocam, 0.3, 4.0)
+    assert int((ov[..., 3] != 0).sum()) > 500
+    t, w = ctx.download_volume()
+    fresh = K.Context(K.camera(*small_cam()), res, size, P["volume_max_weight"], levels=3)
+    used = K.Context(K.camera(*small_cam()), res, size, P["volume_max_weight"], levels=3)
+    rng = np.random.default_rng(5)
+    junk_t = np.where(rng.random(t.shape) < 0.02, -0.5, 1.0).astype(np.float32)          # negative voxels scattered over every macro cell
+    used.upload_volume(junk_t, np.ones_like(w))
+    used.raycast(pose, inc, 0.3, 4.0)
+    for c in (fresh, used):
+        c.upload_volume(t, w)
+        c.raycast(pose, inc, 0.3, 4.0)
+        assert np.array_equal(bits(c.download_map(K.MAP_MODEL_VERTICES)), bits(ov))
+        assert np.array_equal(bits(c.download_map(K.MAP_MODEL_NORMALS)), bits(on))
+    used.upload_volume(np.zeros_like(t), np.zeros_like(w))
+    used.raycast(pose, inc, 0.3, 4.0)
+    assert not used.download_map(K.MAP_MODEL_VERTICES).any()
+    for c in (ctx, fresh, used):
+        c.close()
+
+
 def test_integrate_color_bit_exact():
     ctx, ovol, pose, ocam = _fuse_sequence(32, 3.0, small_cam(), 3, 0.2, 2.5, color=True)
     t, w, c = ctx.download_volume(color=True)
