@@ -362,12 +362,16 @@ def test_prefetched_preprocess_is_bit_identical():
     dev = torch.from_numpy(frames.astype(np.int16)).cuda()
     fb = cam[0] * cam[1] * 2
     outs = []
-    for mode in ("plain", "prefetch", "wrong-prefetch"):
+    forms = {}
+    for mode in ("plain", "prefetch", "wrong-prefetch", "prefetch-per-step"):
+        # the request is honoured in two places: as riders of the persistent tracking launch (+ the tile tables in the raycast launch), or,
+        # when the tracker takes one launch per step (here: a second live context), entirely in the raycast launch
+        other_ctx = K.Context(K.camera(*small_cam()), 32, 3.0, levels=3) if mode == "prefetch-per-step" else None
         pipe = SingleGpuPipeline(K.camera(*cam), res, size, wl)
         poses = []
         for k in range(n):
             nxt = None
-            if mode == "prefetch" and k + 1 < n:
+            if mode.startswith("prefetch") and k + 1 < n:
                 nxt = dev.data_ptr() + (k + 1) * fb
             if mode == "wrong-prefetch":
                 nxt = dev.data_ptr() + ((k + 3) % n) * fb
@@ -375,12 +379,16 @@ def test_prefetched_preprocess_is_bit_identical():
             ok, pose, status, iters = pipe.track_result()
             assert ok
             poses.append(pose.copy())
+            forms.setdefault(mode, set()).add(pipe.ctx.last_form)
         pipe.sync()
+        if other_ctx is not None:
+            other_ctx.close()
         maps = [pipe.ctx.download_map(m) for m in (K.MAP_RAW_DEPTH, K.MAP_TRUNCED_DEPTH, K.MAP_FILTERED_DEPTH, K.MAP_NEW_VERTICES,
                                                    K.MAP_NEW_NORMALS, K.MAP_MODEL_VERTICES, K.MAP_MODEL_NORMALS)]
         vol = pipe.ctx.download_volume()
         outs.append((poses, maps, vol))
         pipe.close()
+    assert 1 in forms["prefetch"] and 2 in forms["prefetch-per-step"] and 1 not in forms["prefetch-per-step"]     # persistent loop / one launch per step
     for other in outs[1:]:
         for a, b in zip(outs[0][0], other[0]):
             assert np.array_equal(a, b)
