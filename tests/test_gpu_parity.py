@@ -364,8 +364,8 @@ def test_prefetched_preprocess_is_bit_identical():
     outs = []
     forms = {}
     for mode in ("plain", "prefetch", "wrong-prefetch", "prefetch-per-step"):
-        # the request is honoured in two places: as riders of the persistent tracking launch (+ the tile tables in the raycast launch), or,
-        # when the tracker takes one launch per step (here: a second live context), entirely in the raycast launch
+        # the request is honoured by the raycast launch whichever form the tracker took before it: the persistent loop, or -- here forced by a
+        # second live context -- one launch per Gauss-Newton step
         other_ctx = K.Context(K.camera(*small_cam()), 32, 3.0, levels=3) if mode == "prefetch-per-step" else None
         pipe = SingleGpuPipeline(K.camera(*cam), res, size, wl)
         poses = []
