@@ -43,6 +43,32 @@ struct KfBilateralArgs {
   float tmin, tmax, ss_inv, sd_inv, sigma_depth;
   KfTileAccum acc;
 };
+// The TSDF integration's tile maxima (and, once saturated free space can exist, minima) of one 64-pixel image row held by a wave: `value` is
+// the lane's gated depth (0: invalid or outside the image).  Shared by the filter below and by kf_tiles_from_gated.
+__device__ __forceinline__ void kf_tile_accumulate(const KfTileAccum& acc, float value, bool inside, int x, int y, int lx, int cols, int rows) {
+  if (acc.tile) {                                          // uniform; every lane of the wave takes part in the DPP steps
+    float d = (value < acc.max_dist) ? value : 0.f;
+    d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0xB1, 0xf, 0xf, true)));    // quad_perm:[1,0,3,2]
+    d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x4E, 0xf, 0xf, true)));    // quad_perm:[2,3,0,1]
+    d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x141, 0xf, 0xf, true)));   // row_half_mirror: 8-pixel groups
+    const float d16 = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x140, 0xf, 0xf, true)));   // row_mirror: 16-pixel groups
+    // a group whose leader lies outside the image holds no pixel at all (d == 0): the indices below stay inside the tables
+    if ((lx & 7) == 0 && d > 0.f) atomicMax(acc.tile + acc.off0 + (y >> 3) * acc.w0 + (x >> 3), __float_as_int(d));
+    if ((lx & 15) == 0 && d16 > 0.f) atomicMax(acc.tile + acc.off1 + (y >> 4) * acc.w1 + (x >> 4), __float_as_int(d16));
+    // the tile MINIMA (second half of the buffer, cleared to +inf): 0 as soon as one pixel of the tile cannot integrate (invalid or
+    // beyond max_dist), else the smallest depth -- what lets the cull prove "every voxel of this brick sees free space" (integrate.hip)
+    if (acc.n) {                                             // uniform
+    float m = inside ? ((value != 0.f && value < acc.max_dist) ? value : 0.f) : __builtin_huge_valf();
+    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0xB1, 0xf, 0xf, false)));
+    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0x4E, 0xf, 0xf, false)));
+    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0x141, 0xf, 0xf, false)));
+    const float m16 = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0x140, 0xf, 0xf, false)));
+    if ((lx & 7) == 0 && x < cols && y < rows) atomicMin(acc.tile + acc.n + acc.off0 + (y >> 3) * acc.w0 + (x >> 3), __float_as_int(m));
+    if ((lx & 15) == 0 && x < cols && y < rows) atomicMin(acc.tile + acc.n + acc.off1 + (y >> 4) * acc.w1 + (x >> 4), __float_as_int(m16));
+    }
+  }
+}
+
 // tile (bx, by) by 256 threads (tid 0..255) with `tile` their (BIL_TX + 2R) x (BIL_TY + 2R) floats of LDS; every thread of the calling
 // workgroup must come through here (one workgroup barrier inside), whether or not its tile lies in the image
 template <int R, bool FAST>
@@ -71,27 +97,7 @@ __device__ __forceinline__ void kf_bilateral_tile(const KfBilateralArgs& b, int 
   const bool inside = x < cols && y < rows;
   float value = inside ? tile[(ly + R) * TW + lx + R] : 0.f;
   if (FAST && value > BIL_SENTINEL_CUT) value = 0.f;       // (the centre pixel itself is invalid)
-  if (acc.tile) {                                          // uniform; every lane of the wave takes part in the DPP steps
-    float d = (value < acc.max_dist) ? value : 0.f;
-    d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0xB1, 0xf, 0xf, true)));    // quad_perm:[1,0,3,2]
-    d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x4E, 0xf, 0xf, true)));    // quad_perm:[2,3,0,1]
-    d = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x141, 0xf, 0xf, true)));   // row_half_mirror: 8-pixel groups
-    const float d16 = fmaxf(d, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x140, 0xf, 0xf, true)));   // row_mirror: 16-pixel groups
-    // a group whose leader lies outside the image holds no pixel at all (d == 0): the indices below stay inside the tables
-    if ((lx & 7) == 0 && d > 0.f) atomicMax(acc.tile + acc.off0 + (y >> 3) * acc.w0 + (x >> 3), __float_as_int(d));
-    if ((lx & 15) == 0 && d16 > 0.f) atomicMax(acc.tile + acc.off1 + (y >> 4) * acc.w1 + (x >> 4), __float_as_int(d16));
-    // the tile MINIMA (second half of the buffer, cleared to +inf): 0 as soon as one pixel of the tile cannot integrate (invalid or
-    // beyond max_dist), else the smallest depth -- what lets the cull prove "every voxel of this brick sees free space" (integrate.hip)
-    if (acc.n) {                                             // uniform
-    float m = inside ? ((value != 0.f && value < acc.max_dist) ? value : 0.f) : __builtin_huge_valf();
-    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0xB1, 0xf, 0xf, false)));
-    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0x4E, 0xf, 0xf, false)));
-    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0x141, 0xf, 0xf, false)));
-    const float m16 = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(0x7F800000, __float_as_int(m), 0x140, 0xf, 0xf, false)));
-    if ((lx & 7) == 0 && x < cols && y < rows) atomicMin(acc.tile + acc.n + acc.off0 + (y >> 3) * acc.w0 + (x >> 3), __float_as_int(m));
-    if ((lx & 15) == 0 && x < cols && y < rows) atomicMin(acc.tile + acc.n + acc.off1 + (y >> 4) * acc.w1 + (x >> 4), __float_as_int(m16));
-    }
-  }
+  kf_tile_accumulate(acc, value, inside, x, y, lx, cols, rows);
   if (!inside) return;
   float result = value;
   if (value != 0.f) {
@@ -146,6 +152,40 @@ __device__ __forceinline__ void kf_bilateral_tile(const KfBilateralArgs& b, int 
     }
   }
   filtered[y * cols + x] = result;
+}
+
+
+// The tile tables alone, from a depth map that has been gated already (b.trunced): what is left for the raycast launch to do when the
+// filter itself rode in the tracking launch (track.hip: k_icp_loop) -- the tables may only be written once the fusion pass has cleared them.
+__device__ __forceinline__ void kf_tiles_from_gated(const KfBilateralArgs& b, int bx, int by, int tid) {
+  const int lx = tid & 63, ly = tid >> 6;
+  const int x = bx * BIL_TX + lx, y = by * BIL_TY + ly;
+  const bool inside = x < b.cols && y < b.rows;
+  const float value = inside ? b.trunced[y * b.cols + x] : 0.f;
+  kf_tile_accumulate(b.acc, value, inside, x, y, lx, b.cols, b.rows);
+}
+
+// Vertex and normal of pixel (x, y) from the filtered depth map (VerticesNormalsCalculater.cu:15-33 and :35-64 in one pass): the body of
+// k_vertices_normals (preprocess.hip), also run by rider workgroups of the raycast launch (raycast.hip) for the NEXT frame.
+__device__ __forceinline__ void kf_vertex_normal_pixel(const float* __restrict__ depth, float4* __restrict__ out_v, float4* __restrict__ out_n, const KfCam& cam, int x, int y) {
+  const int i = y * cam.cols + x;
+  // DepthCamera.h:19-29 `depth*(x - cx)/fx`: ten quotients by the two focal lengths per pixel -> their reciprocals are refined once
+  const KfRecip rfx = kf_recip(cam.fx), rfy = kf_recip(cam.fy);
+  auto skeleton = [&](int px, int py, float d) { return kf3(kf_div(d * ((float)(unsigned)px - cam.cx), rfx), kf_div(d * ((float)(unsigned)py - cam.cy), rfy), d); };
+  const float d0 = depth[i];
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f), n = v;
+  float3 v0 = kf3(0.f, 0.f, 0.f);
+  if (d0 != 0.f) { v0 = skeleton(x, y, d0); v = make_float4(v0.x, v0.y, v0.z, 1.0f); }
+  if (d0 != 0.f && !(x == cam.cols - 1 || y == cam.rows - 1 || x == 0 || y == 0)) {
+    const float dr = depth[i + 1], du = depth[i + cam.cols], dl = depth[i - 1], dd = depth[i - cam.cols];
+    if (dr != 0.f && du != 0.f && dl != 0.f && dd != 0.f) {                       // a vertex's z is its depth: z == 0 <=> depth == 0
+      const float3 vr = skeleton(x + 1, y, dr), vu = skeleton(x, y + 1, du);
+      const float3 vl = skeleton(x - 1, y, dl), vd = skeleton(x, y - 1, dd);
+      const float3 c = kf_normalize(kf_cross(kf_sub(vu, vd), kf_sub(vr, vl)));
+      n = make_float4(c.x, c.y, c.z, 0.f);
+    }
+  }
+  out_v[i] = v; out_n[i] = n;
 }
 
 

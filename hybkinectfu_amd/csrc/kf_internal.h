@@ -137,6 +137,7 @@ struct kf_ctx {
   // fused form of the prefetch (default): kf_prefetch_frame only records the request; the next kf_raycast_volume launches the raycast with the
   // next frame's gate + bilateral filter riding along (k_raycast_prefetch) and the vertices / normals launch behind it, on the context's own stream
   int fp_pending;                     // a request waits for the next raycast
+  int fp_filtered;                    // ... and its gate + bilateral filter has already run as riders of the tracking launch (track.hip)
   const uint16_t* fp_src; float fp_params[4]; kf_camera_params fp_cam;
   int fp_done;                        // the prefetched set was produced on the context's stream (no event to wait for)
   int fp_tiles; float fp_tiles_dist; int fp_tiles_min;   // the integrate tile tables were built for the prefetched depth map (distance; minima too)

@@ -70,24 +70,7 @@ __global__ void __launch_bounds__(256) k_gate_bilateral(KfBilateralArgs b) {
 __global__ void __launch_bounds__(256) k_vertices_normals(const float* __restrict__ depth, float4* __restrict__ out_v, float4* __restrict__ out_n, KfCam cam) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= cam.cols || y >= cam.rows) return;
-  const int i = y * cam.cols + x;
-  // DepthCamera.h:19-29 `depth*(x - cx)/fx`: ten quotients by the two focal lengths per pixel -> their reciprocals are refined once
-  const KfRecip rfx = kf_recip(cam.fx), rfy = kf_recip(cam.fy);
-  auto skeleton = [&](int px, int py, float d) { return kf3(kf_div(d * ((float)(unsigned)px - cam.cx), rfx), kf_div(d * ((float)(unsigned)py - cam.cy), rfy), d); };
-  const float d0 = depth[i];
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f), n = v;
-  float3 v0 = kf3(0.f, 0.f, 0.f);
-  if (d0 != 0.f) { v0 = skeleton(x, y, d0); v = make_float4(v0.x, v0.y, v0.z, 1.0f); }
-  if (d0 != 0.f && !(x == cam.cols - 1 || y == cam.rows - 1 || x == 0 || y == 0)) {
-    const float dr = depth[i + 1], du = depth[i + cam.cols], dl = depth[i - 1], dd = depth[i - cam.cols];
-    if (dr != 0.f && du != 0.f && dl != 0.f && dd != 0.f) {                       // a vertex's z is its depth: z == 0 <=> depth == 0
-      const float3 vr = skeleton(x + 1, y, dr), vu = skeleton(x, y + 1, du);
-      const float3 vl = skeleton(x - 1, y, dl), vd = skeleton(x, y - 1, dd);
-      const float3 c = kf_normalize(kf_cross(kf_sub(vu, vd), kf_sub(vr, vl)));
-      n = make_float4(c.x, c.y, c.z, 0.f);
-    }
-  }
-  out_v[i] = v; out_n[i] = n;
+  kf_vertex_normal_pixel(depth, out_v, out_n, cam, x, y);                      // bilateral_tile.h
 }
 
 // VerticesNormalsCalculater.cu:15-33
@@ -273,7 +256,7 @@ extern "C" int kf_preprocess(kf_ctx* c, float tmin, float tmax, float sigma_pixe
   kf_evt_begin(c, KF_STAGE_PREPROCESS);
   const int radius = (int)ceil(2.0 * (double)sigma_pixel);
   const float want[4] = {tmin, tmax, sigma_pixel, sigma_depth};
-  c->fp_pending = 0;                                        // a recorded request no raycast has picked up is void now
+  c->fp_pending = 0; c->fp_filtered = 0;                    // a recorded request no raycast has picked up is void now
   if (c->prefetch_valid && c->pending_mm && c->pending_mm == c->prefetch_src && memcmp(want, c->prefetch_params, sizeof(want)) == 0) {
     // this very frame was preprocessed ahead of time on the side stream (kf_prefetch_frame): adopt its buffers
     float* t;
@@ -329,7 +312,7 @@ extern "C" int kf_preprocess(kf_ctx* c, float tmin, float tmax, float sigma_pixe
 extern "C" int kf_prefetch_frame(kf_ctx* c, const uint16_t* dev_mm, uint32_t cols, uint32_t rows, float tmin, float tmax,
                                  float sigma_pixel, float sigma_depth, const kf_camera_params* cam) {
   if (!c || !dev_mm || !cam || (int)cols != c->cols || (int)rows != c->rows || (int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
-  c->prefetch_valid = 0; c->fp_pending = 0; c->fp_done = 0;
+  c->prefetch_valid = 0; c->fp_pending = 0; c->fp_done = 0; c->fp_filtered = 0;
   if ((int)ceil(2.0 * (double)sigma_pixel) != 4) return 0;
   KF_CHECK(hipSetDevice(c->cfg.device));
   const size_t npx = (size_t)c->cols * c->rows;

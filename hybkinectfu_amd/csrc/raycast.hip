@@ -299,17 +299,25 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
 // lasts as long as its slowest waves while the average SIMD is busy for less than half of that; the filter of the frame that comes next
 // depends on nothing this frame computes.  Workgroups [0, n_rc) are the raycast's tiles (dispatched first, higher wave priority), the rest
 // filter two 64x4 tiles each (bilateral_tile.h) and fill the chip as the raycast drains -- no second stream, no events.
+// behind == 1: the filter itself has run already (riders of the tracking launch, track.hip); what is left are the integrate tile tables, which
+// may only be written now that the fusion pass has cleared them (one gated-depth read per pixel; b.acc.tile null: not wanted), and the frame's
+// vertices + normals (out_v non-null), which then need no launch of their own.
+struct KfFrontTail { int behind; float4* out_v; float4* out_n; KfCam cam; };
 template <bool FAST>
-__global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast_prefetch(RaycastArgs a, KfBilateralArgs b, int rc_gx, int n_rc, int bil_gx, int bil_tiles) {
+__global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast_prefetch(RaycastArgs a, KfBilateralArgs b, KfFrontTail ft, int rc_gx, int n_rc, int bil_gx, int bil_tiles) {
   extern __shared__ unsigned s_dyn[];
   if ((int)blockIdx.x < n_rc) {
     __builtin_amdgcn_s_setprio(2);
     raycast_tile(a, (int)blockIdx.x % rc_gx, (int)blockIdx.x / rc_gx, s_dyn);
   } else {
-    const int half = (int)(threadIdx.x >> 8), t = ((int)blockIdx.x - n_rc) * 2 + half;
+    const int half = (int)(threadIdx.x >> 8), t = ((int)blockIdx.x - n_rc) * 2 + half, tid = (int)(threadIdx.x & 255);
     // a tile index past the last one names a row below the image: its threads touch nothing but still meet the barrier
     const int tt = t < bil_tiles ? t : bil_tiles;
-    kf_bilateral_tile<4, FAST>(b, tt % bil_gx, tt / bil_gx, (int)(threadIdx.x & 255), reinterpret_cast<float*>(s_dyn) + half * ((BIL_TX + 8) * (BIL_TY + 8)));
+    if (ft.behind) {
+      kf_tiles_from_gated(b, tt % bil_gx, tt / bil_gx, tid);
+      const int x = (tt % bil_gx) * BIL_TX + (tid & 63), y = (tt / bil_gx) * BIL_TY + (tid >> 6);
+      if (ft.out_v && x < ft.cam.cols && y < ft.cam.rows) kf_vertex_normal_pixel(b.filtered, ft.out_v, ft.out_n, ft.cam, x, y);
+    } else kf_bilateral_tile<4, FAST>(b, tt % bil_gx, tt / bil_gx, tid, reinterpret_cast<float*>(s_dyn) + half * ((BIL_TX + 8) * (BIL_TY + 8)));
   }
 }
 
@@ -340,24 +348,33 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
       // kf_prefetch_frame left a note: the next frame's u16 -> f32 + gate + bilateral rides in this launch (k_raycast_prefetch), its vertices /
       // normals follow; the set lands in the alternate buffers and kf_preprocess adopts it when it is asked for exactly that frame
       c->fp_pending = 0;
+      const int behind = c->fp_filtered; c->fp_filtered = 0;                 // the filter rode in the tracking launch: the tile tables and the vertices / normals are left
       KfBilateralArgs b; bool fast;
       const bool build_tiles = c->tiles_clear && c->fuse_max_dist > 0.f;      // the fusion pass of this frame has cleared the tables: they can be built for the next depth map
       kf_bilateral_args(c, c->fp_src, nullptr, c->alt_raw, c->alt_trunced, c->alt_filtered, c->fp_params[0], c->fp_params[1], c->fp_params[2], c->fp_params[3],
                         build_tiles, &b, &fast);
+      KfFrontTail ft; memset(&ft, 0, sizeof(ft));
+      ft.behind = behind;
+      if (behind) {
+        ft.out_v = c->alt_v0; ft.out_n = c->alt_n0;
+        ft.cam.cols = (int)c->fp_cam.cols; ft.cam.rows = (int)c->fp_cam.rows; ft.cam.cx = c->fp_cam.cx; ft.cam.cy = c->fp_cam.cy; ft.cam.fx = c->fp_cam.fx; ft.cam.fy = c->fp_cam.fy;
+      }
       const int bil_gx = kf_div_up(c->cols, BIL_TX), bil_tiles = bil_gx * kf_div_up(c->rows, BIL_TY);
       const int n_rc = (int)(grid.x * grid.y), n_bil = (bil_tiles + 1) / 2;
       const size_t lds2 = lds > 2 * (BIL_TX + 8) * (BIL_TY + 8) * sizeof(float) ? lds : 2 * (BIL_TX + 8) * (BIL_TY + 8) * sizeof(float);
       const dim3 g2((unsigned)(n_rc + n_bil));
       if (fast) {
-        if (timed) hipExtLaunchKernelGGL(k_raycast_prefetch<true>, g2, dim3(RAYCAST_THREADS), (unsigned)lds2, c->stream, ke0, ke1, 0, a, b, (int)grid.x, n_rc, bil_gx, bil_tiles);
-        else hipLaunchKernelGGL(k_raycast_prefetch<true>, g2, dim3(RAYCAST_THREADS), lds2, c->stream, a, b, (int)grid.x, n_rc, bil_gx, bil_tiles);
+        if (timed) hipExtLaunchKernelGGL(k_raycast_prefetch<true>, g2, dim3(RAYCAST_THREADS), (unsigned)lds2, c->stream, ke0, ke1, 0, a, b, ft, (int)grid.x, n_rc, bil_gx, bil_tiles);
+        else hipLaunchKernelGGL(k_raycast_prefetch<true>, g2, dim3(RAYCAST_THREADS), lds2, c->stream, a, b, ft, (int)grid.x, n_rc, bil_gx, bil_tiles);
       } else {
-        if (timed) hipExtLaunchKernelGGL(k_raycast_prefetch<false>, g2, dim3(RAYCAST_THREADS), (unsigned)lds2, c->stream, ke0, ke1, 0, a, b, (int)grid.x, n_rc, bil_gx, bil_tiles);
-        else hipLaunchKernelGGL(k_raycast_prefetch<false>, g2, dim3(RAYCAST_THREADS), lds2, c->stream, a, b, (int)grid.x, n_rc, bil_gx, bil_tiles);
+        if (timed) hipExtLaunchKernelGGL(k_raycast_prefetch<false>, g2, dim3(RAYCAST_THREADS), (unsigned)lds2, c->stream, ke0, ke1, 0, a, b, ft, (int)grid.x, n_rc, bil_gx, bil_tiles);
+        else hipLaunchKernelGGL(k_raycast_prefetch<false>, g2, dim3(RAYCAST_THREADS), lds2, c->stream, a, b, ft, (int)grid.x, n_rc, bil_gx, bil_tiles);
       }
       if (timed) kf_evt_attached_done(c, KF_STAGE_RAYCAST_KERNEL);
-      const int st = kf_launch_vertices_normals(c, c->stream, c->alt_filtered, c->alt_v0, c->alt_n0, &c->fp_cam);
-      if (st) return st;
+      if (!behind) {
+        const int st = kf_launch_vertices_normals(c, c->stream, c->alt_filtered, c->alt_v0, c->alt_n0, &c->fp_cam);
+        if (st) return st;
+      }
       c->prefetch_src = c->fp_src; memcpy(c->prefetch_params, c->fp_params, sizeof(c->prefetch_params));
       c->prefetch_valid = 1; c->fp_done = 1;
       c->fp_tiles = build_tiles ? 1 : 0; c->fp_tiles_dist = c->fuse_max_dist; c->fp_tiles_min = (build_tiles && b.acc.n) ? 1 : 0;

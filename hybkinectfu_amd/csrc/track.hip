@@ -21,6 +21,7 @@
 // Sums are fp32 in a fixed (reproducible) association that differs from the reference's tree, so parity for this stage is
 // by tolerance (pose within 1e-4 m / 1e-4 rad), as SURVEY.md section 8a row a6 states.
 #include "kf_internal.h"
+#include "bilateral_tile.h"
 #include <string.h>
 #include <stdlib.h>
 
@@ -607,6 +608,12 @@ struct IcpLoopArgs {
   KfTrackState* track;
   unsigned* stall_word;                          // pinned host word: set when the loop gives up waiting, polled by the next kf_icp_track
   int exp_mode;                                  // diagnostics only (KF_ICP_EXP): 1 = skip the solve (timing), 7 = shader-clock stamps per phase
+  // Riders: workgroups [n_loop, gridDim.x) do not take part in the loop -- they carry the NEXT frame's u16 -> f32 + gate + bilateral filter
+  // (kf_prefetch_frame, requested before kf_icp_track).  The loop keeps one workgroup on each of ~200 CUs busy for ~0.14 ms at two waves per
+  // SIMD and leaves the other CUs idle; the riders are dispatched behind the loop's workgroups (they cannot displace them), wait for
+  // nobody, and are long done when the loop ends.  gridDim.x == n_loop: none.
+  int n_loop;
+  KfBilateralArgs bil; int bil_gx, bil_tiles, bil_fast;
 };
 
 #define ICP_SPIN_LIMIT 8192u            // polls (~1-1.5 us each: about 10 ms) before a workgroup gives up: a legitimate wait is tens of microseconds
@@ -683,6 +690,15 @@ __device__ __forceinline__ void fold_partials_tagged(const unsigned long long* s
 }
 
 __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
+  if ((int)blockIdx.x >= L.n_loop) {                                           // a rider: two 64x4 filter tiles (bilateral_tile.h), then done
+    __shared__ float s_bil[2 * (BIL_TX + 8) * (BIL_TY + 8)];
+    const int half = (int)(threadIdx.x >> 8), t = ((int)blockIdx.x - L.n_loop) * 2 + half;
+    const int tt = t < L.bil_tiles ? t : L.bil_tiles;                          // past the last tile: a row below the image, nothing is touched
+    float* tile = s_bil + half * ((BIL_TX + 8) * (BIL_TY + 8));
+    if (L.bil_fast) kf_bilateral_tile<4, true>(L.bil, tt % L.bil_gx, tt / L.bil_gx, (int)(threadIdx.x & 255), tile);
+    else kf_bilateral_tile<4, false>(L.bil, tt % L.bil_gx, tt / L.bil_gx, (int)(threadIdx.x & 255), tile);
+    return;
+  }
   __shared__ float s_cur[16], s_linv[16];
   __shared__ float s_wave[27 * (ICP_THREADS / 16)], s_tot[(ICP_THREADS / 32) * 32];
   __shared__ int s_code, s_abort;
@@ -710,7 +726,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     const float4* __restrict__ model_v = L.model_v[l]; const float4* __restrict__ model_n = L.model_n[l];
     const int npx = a.cam.cols * a.cam.rows;
     int px_l, grid_l;
-    icp_level_geometry(npx, (int)gridDim.x, l, px_l, grid_l);
+    icp_level_geometry(npx, L.n_loop, l, px_l, grid_l);
     const bool has_px = (int)blockIdx.x < grid_l;
     // this lane's own vertices / normals depend neither on the running transform nor on the iteration: they are loaded once
     // per pyramid level and stay in registers for all of its iterations (the reference re-reads them 4 / 5 / 10 times)
@@ -1028,6 +1044,22 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
     L.slots = c->icp_loop_slots; L.tag_base = c->icp_loop_seq; L.track = c->track;
     L.stall_word = stall_word;
     { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_ICP_EXP"); L.exp_mode = em; }
+    L.n_loop = grid0;
+    // a pending kf_prefetch_frame: the next frame's filter rides in this launch (see IcpLoopArgs) and leaves the gated + filtered image in
+    // the alternate buffers; the raycast launch that follows carries its tile tables (the fusion pass in between clears them) and its
+    // vertices / normals.  Not under a cooperative launch, whose whole grid would have to be resident.
+    static int ride_env = -1;
+    if (ride_env < 0) { const char* e = getenv("KF_PREFETCH_IN_TRACK"); ride_env = e ? atoi(e) : 1; }
+    unsigned n_riders = 0;
+    if (ride_env && !coop_env && c->fp_pending && c->alt_raw && !c->fp_filtered) {
+      bool fast;
+      kf_bilateral_args(c, c->fp_src, nullptr, c->alt_raw, c->alt_trunced, c->alt_filtered, c->fp_params[0], c->fp_params[1], c->fp_params[2], c->fp_params[3],
+                        false, &L.bil, &fast);
+      L.bil_fast = fast ? 1 : 0;
+      L.bil_gx = kf_div_up(c->cols, BIL_TX); L.bil_tiles = L.bil_gx * kf_div_up(c->rows, BIL_TY);
+      n_riders = (unsigned)((L.bil_tiles + 1) / 2);
+      c->fp_filtered = 1;
+    }
     if (coop_env) {
       // a cooperative launch: the runtime itself checks that the whole grid can be resident and refuses otherwise
       void* params[] = {(void*)&L};
@@ -1036,7 +1068,7 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
       (void)hipGetLastError();                               // refused: this device / configuration cannot hold the loop -- per-step from now on
       c->loop_refused = 1;
     } else {
-      hipLaunchKernelGGL(k_icp_loop, dim3(grid0), dim3(ICP_THREADS), 0, c->stream, L);
+      hipLaunchKernelGGL(k_icp_loop, dim3((unsigned)grid0 + n_riders), dim3(ICP_THREADS), 0, c->stream, L);
       c->last_track_form = 1;
       kf_evt_end(c, KF_STAGE_TRACK);
       return (int)hipGetLastError();

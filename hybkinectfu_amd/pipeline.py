@@ -23,17 +23,18 @@ class SingleGpuPipeline:
         self.inc = P["raycast_increment_factor"] * P["integrate_sdf_trunc"]     # AppParamsProducer.cpp:113-117
 
     def process_frame_device(self, dev_mm_ptr, frame_id, next_mm_ptr=None):
-        """next_mm_ptr: where the NEXT frame already lies in HBM (streaming input): its preprocess is enqueued on the context's
-        side stream right behind the tracking loop and overlaps with it."""
+        """next_mm_ptr: where the NEXT frame already lies in HBM (streaming input): its depth conversion + gate + bilateral filter ride in this
+        frame's tracking launch and its vertices / normals in this frame's raycast launch (or, when the tracker takes another launch form, the
+        filter rides in the raycast launch and the vertices / normals follow it)."""
         c = self.ctx
         c.set_depth_mm_device(dev_mm_ptr)                                                                    # copyFrameToGPU
         c.preprocess(P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])  # :106-110
+        if next_mm_ptr is not None:           # before the tracker: the next frame's filter rides on the CUs the ICP loop leaves idle (else: in the raycast launch)
+            c.prefetch_frame(next_mm_ptr, P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
         if self.tracker == "sdf":
             c.sdf_track(frame_id, P["sdf_max_iter_nums"], P["camera_shake_dist"], P["camera_shake_angle"])                  # :116 with CameraPoseFinderSDF
         else:
             c.icp_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])  # :116
-        if next_mm_ptr is not None:
-            c.prefetch_frame(next_mm_ptr, P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
         c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist, has_color=self.color, angle_weight=self.color)      # :125-140
         c.raycast(None, self.inc, P["depth_trunc_min"], self.trunc_max, has_color=self.color)                           # :149-154
 

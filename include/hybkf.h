@@ -118,8 +118,10 @@ int kf_preprocess(kf_ctx* ctx, float trunc_min, float trunc_max, float sigma_pix
                   const kf_camera_params* depth_camera);
 /* No reference counterpart (the reference synchronises after every launch): have kf_preprocess's work for the NEXT frame -- a device
  * u16 millimetre image, as for kf_set_depth_mm_device -- done ahead of time into a second buffer set.  Default form: the call only
- * leaves a note, and the next kf_raycast_volume(_slab) launch carries the next frame's conversion + gate + bilateral filter along as
- * extra workgroups of the same launch (the vertices / normals launch follows it) -- same stream, no events.  KF_PREFETCH_FUSED=0 selects
+ * leaves a note.  Called BEFORE kf_icp_track, the next frame's conversion + gate + bilateral filter ride in the tracking launch as extra
+ * workgroups on the CUs the persistent loop leaves idle, and its integrate tile tables and vertices / normals as extra workgroups of the
+ * next kf_raycast_volume(_slab) launch; when the tracker took another launch form (or the call came after it) the whole filter rides in
+ * the raycast launch and the vertices / normals launch follows it -- same stream, no events either way.  KF_PREFETCH_FUSED=0 selects
  * the older form: the two preprocess launches on a side stream, concurrent with whatever is enqueued next.  Either way the next
  * kf_set_depth_mm_device(same pointer) + kf_preprocess(same parameters) adopts the result; any other sequence ignores it.
  * Results are bit-identical to the unprefetched path. */
