@@ -167,7 +167,8 @@ __device__ __forceinline__ void kf_tiles_from_gated(const KfBilateralArgs& b, in
 
 // Vertex and normal of pixel (x, y) from the filtered depth map (VerticesNormalsCalculater.cu:15-33 and :35-64 in one pass): the body of
 // k_vertices_normals (preprocess.hip), also run by rider workgroups of the raycast launch (raycast.hip) for the NEXT frame.
-__device__ __forceinline__ void kf_vertex_normal_pixel(const float* __restrict__ depth, float4* __restrict__ out_v, float4* __restrict__ out_n, const KfCam& cam, int x, int y) {
+__device__ __forceinline__ void kf_vertex_normal_pixel(const float* __restrict__ depth, float4* __restrict__ out_v, float4* __restrict__ out_n, const KfCam& cam, int x, int y,
+                                                       float4* keep_v = nullptr, float4* keep_n = nullptr) {
   const int i = y * cam.cols + x;
   // DepthCamera.h:19-29 `depth*(x - cx)/fx`: ten quotients by the two focal lengths per pixel -> their reciprocals are refined once
   const KfRecip rfx = kf_recip(cam.fx), rfy = kf_recip(cam.fy);
@@ -186,7 +187,55 @@ __device__ __forceinline__ void kf_vertex_normal_pixel(const float* __restrict__
     }
   }
   out_v[i] = v; out_n[i] = n;
+  if (keep_v) { *keep_v = v; *keep_n = n; }
 }
+
+// sample.cu:37-61 (vertices) and :16-36 (normals), intended semantics: each output pixel exactly once.
+__device__ __forceinline__ float4 pyr_vertex(float4 p00, float4 p01, float4 p10, float4 p11) {
+  if (p00.z == 0.f || p01.z == 0.f || p10.z == 0.f || p11.z == 0.f) return make_float4(0.f, 0.f, 0.f, 0.f);
+  const float q = 0.25f;                                  // `*0.25`: double literal narrowed by operator*(float4, const float&)
+  return make_float4((p00.x + p01.x + p10.x + p11.x) * q, (p00.y + p01.y + p10.y + p11.y) * q,
+                     (p00.z + p01.z + p10.z + p11.z) * q, (p00.w + p01.w + p10.w + p11.w) * q);
+}
+__device__ __forceinline__ float4 pyr_normal(float4 p00, float4 p01, float4 p10, float4 p11) {
+  if (kf_is_zero4(p01) || kf_is_zero4(p10) || kf_is_zero4(p00) || kf_is_zero4(p11)) return make_float4(0.f, 0.f, 0.f, 0.f);
+  const float q = 0.25f;
+  float3 n = kf_normalize(kf3((p00.x + p01.x + p10.x + p11.x) * q, (p00.y + p01.y + p10.y + p11.y) * q, (p00.z + p01.z + p10.z + p11.z) * q));
+  return make_float4(n.x, n.y, n.z, 0.f);
+}
+
+// Levels 1 and 2 of a vertex / normal map pair for one TW x TH tile of level 0 (TW, TH multiples of 4, tile origin (x0, y0) a multiple of them):
+// every 2x2 and 4x4 block lies inside the tile, so the pyramid needs nothing from other workgroups.  s_v / s_n hold the tile's level-0
+// texels (row-major, TW wide; zeros outside the image), s1_v / s1_n take its (TW/2) x (TH/2) level-1 texels.  All `nthreads` threads
+// (ids 0 .. nthreads-1) of the calling group come through here together, between them two barriers of `sync` (a callable: __syncthreads).
+// Same functions, same operand order as k_pyramid (preprocess.hip): the same bits.
+struct KfPyrOut { float4* v1; float4* n1; float4* v2; float4* n2; int c1, r1, c2, r2; };       // v1 null: no pyramid wanted
+template <int TW, int TH, typename Sync>
+__device__ __forceinline__ void kf_tile_pyramid(const KfPyrOut& o, int x0, int y0, int tid, const float4* s_v, const float4* s_n, float4* s1_v, float4* s1_n, Sync sync) {
+  constexpr int W1 = TW / 2, H1 = TH / 2, W2 = TW / 4, H2 = TH / 4;
+  sync();
+  if (tid < W1 * H1) {
+    const int lx = tid % W1, ly = tid / W1, x1 = x0 / 2 + lx, y1 = y0 / 2 + ly;
+    float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), qn = qv;
+    if (x1 < o.c1 && y1 < o.r1) {
+      const int k = (2 * ly) * TW + 2 * lx;
+      qv = pyr_vertex(s_v[k], s_v[k + 1], s_v[k + TW], s_v[k + TW + 1]);
+      qn = pyr_normal(s_n[k], s_n[k + 1], s_n[k + TW], s_n[k + TW + 1]);
+      o.v1[(size_t)y1 * o.c1 + x1] = qv; o.n1[(size_t)y1 * o.c1 + x1] = qn;
+    }
+    s1_v[tid] = qv; s1_n[tid] = qn;
+  }
+  sync();
+  if (o.v2 && tid < W2 * H2) {
+    const int lx = tid % W2, ly = tid / W2, x2 = x0 / 4 + lx, y2 = y0 / 4 + ly;
+    if (x2 < o.c2 && y2 < o.r2) {
+      const int k = (2 * ly) * W1 + 2 * lx;
+      o.v2[(size_t)y2 * o.c2 + x2] = pyr_vertex(s1_v[k], s1_v[k + 1], s1_v[k + W1], s1_v[k + W1 + 1]);
+      o.n2[(size_t)y2 * o.c2 + x2] = pyr_normal(s1_n[k], s1_n[k + 1], s1_n[k + W1], s1_n[k + W1 + 1]);
+    }
+  }
+}
+
 
 
 // host side (preprocess.hip): the launch arguments for a buffer set, and the vertices + normals launch that follows the filter

@@ -119,7 +119,7 @@ extern "C" int kf_destroy(kf_ctx* c) {
     if (c->up_copied[i]) hipEventDestroy(c->up_copied[i]);
     if (c->up_consumed[i]) hipEventDestroy(c->up_consumed[i]);
   }
-  void* alts[] = {c->alt_raw, c->alt_trunced, c->alt_filtered, c->alt_v0, c->alt_n0, c->rgb_staging};
+  void* alts[] = {c->alt_raw, c->alt_trunced, c->alt_filtered, c->alt_v0, c->alt_n0, c->rgb_staging, c->alt_v12[0], c->alt_v12[1], c->alt_n12[0], c->alt_n12[1]};
   for (void* p : alts) if (p) hipFree(p);
   if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
   if (c->ev_track) hipEventDestroy(c->ev_track);
@@ -397,6 +397,8 @@ extern "C" int kf_upload_map(kf_ctx* c, int id, uint32_t level, const void* src,
     if (id != KF_MAP_RAW_RGB) return KF_ERR_ARG;
     return kf_upload_rgb(c, (const uint8_t*)src, c->cfg.rgb_camera.cols, c->cfg.rgb_camera.rows);
   }
+  if (id == KF_MAP_NEW_VERTICES || id == KF_MAP_NEW_NORMALS) c->new_pyr_ok = 0;          // the tracker rebuilds the pyramids from level 0, as it always did
+  if (id == KF_MAP_MODEL_VERTICES || id == KF_MAP_MODEL_NORMALS) c->model_pyr_ok = 0;
   KF_CHECK(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, c->stream));
   KF_CHECK(hipStreamSynchronize(c->stream));
   return 0;

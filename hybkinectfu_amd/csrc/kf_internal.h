@@ -132,6 +132,10 @@ struct kf_ctx {
   // current frame is tracked (the persistent ICP loop leaves ~100 CUs idle); kf_preprocess swaps the sets when it is asked for
   // exactly that frame with exactly those parameters.  Allocated on first use.
   float* alt_raw; float* alt_trunced; float* alt_filtered; float4* alt_v0; float4* alt_n0;
+  float4* alt_v12[2]; float4* alt_n12[2];   // levels 1 and 2 of the alternate set's vertex / normal pyramids (written by the raycast launch's riders)
+  // levels 1.. of the new / model map pyramids describe their level 0 (whoever writes a level 0 without its pyramid clears the flag; the
+  // tracker's pyramid launch builds what is missing).  alt_pyr_ok: the same for the alternate (prefetched) set, adopted with it.
+  int new_pyr_ok, model_pyr_ok, alt_pyr_ok;
   hipStream_t side_stream; hipEvent_t ev_preprocessed, ev_prefetched;
   const uint16_t* prefetch_src; float prefetch_params[4]; int prefetch_valid, prefetch_in_use;
   // fused form of the prefetch (default): kf_prefetch_frame only records the request; the next kf_raycast_volume launches the raycast with the

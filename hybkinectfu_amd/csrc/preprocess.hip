@@ -99,20 +99,6 @@ __global__ void __launch_bounds__(256) k_vertices_to_normals(const float4* __res
   out[y * cols + x] = r;
 }
 
-// sample.cu:37-61 (vertices) and :16-36 (normals), intended semantics: each output pixel exactly once.
-__device__ __forceinline__ float4 pyr_vertex(float4 p00, float4 p01, float4 p10, float4 p11) {
-  if (p00.z == 0.f || p01.z == 0.f || p10.z == 0.f || p11.z == 0.f) return make_float4(0.f, 0.f, 0.f, 0.f);
-  const float q = 0.25f;                                  // `*0.25`: double literal narrowed by operator*(float4, const float&)
-  return make_float4((p00.x + p01.x + p10.x + p11.x) * q, (p00.y + p01.y + p10.y + p11.y) * q,
-                     (p00.z + p01.z + p10.z + p11.z) * q, (p00.w + p01.w + p10.w + p11.w) * q);
-}
-__device__ __forceinline__ float4 pyr_normal(float4 p00, float4 p01, float4 p10, float4 p11) {
-  if (kf_is_zero4(p01) || kf_is_zero4(p10) || kf_is_zero4(p00) || kf_is_zero4(p11)) return make_float4(0.f, 0.f, 0.f, 0.f);
-  const float q = 0.25f;
-  float3 n = kf_normalize(kf3((p00.x + p01.x + p10.x + p11.x) * q, (p00.y + p01.y + p10.y + p11.y) * q, (p00.z + p01.z + p10.z + p11.z) * q));
-  return make_float4(n.x, n.y, n.z, 0.f);
-}
-
 // One thread per 2x2 block of level-1 pixels (= one level-2 pixel): reads 16 level-0 texels, writes 4 level-1 and 1 level-2.
 // blockIdx.z: 0 = vertices, 1 = normals.
 // slots 0/1 = new vertices/normals, 2/3 = model vertices/normals (odd slot = normal averaging rule)
@@ -169,13 +155,18 @@ int kf_launch_pyramids(kf_ctx* c, bool model, bool vertices, bool normals) {
                      (KfTrackState*)nullptr, (KfGridBarrier*)nullptr, -1);
   return (int)hipGetLastError();
 }
-// all four pyramids (ICP.cpp:57-60) plus the start-of-tracking bookkeeping in ONE launch
+// the pyramids (ICP.cpp:57-60) that do not describe their level 0 yet -- the raycast launch leaves the model maps' behind, its riders the
+// prefetched frame's (raycast.hip) -- plus the start-of-tracking bookkeeping in ONE launch
 int kf_launch_pyramids_and_begin(kf_ctx* c, int begin_mode) {
   PyrMaps m; pyr_maps(c, m);
   int c1 = c->cols >> 1, r1 = c->rows >> 1;
-  dim3 grid(c->levels < 2 ? 1 : kf_div_up(kf_div_up(c1, 2), 32), c->levels < 2 ? 1 : kf_div_up(kf_div_up(r1, 2), 8), c->levels < 2 ? 1 : 4);
-  hipLaunchKernelGGL(k_pyramid, grid, dim3(256), 0, c->stream, m, c->levels < 2 ? 0 : c->cols, c->levels < 2 ? 0 : c->rows, c->levels, 0,
+  const bool need_new = !c->new_pyr_ok, need_model = !c->model_pyr_ok;
+  const bool none = c->levels < 2 || (!need_new && !need_model);
+  const int kinds = none ? 1 : (need_new && need_model ? 4 : 2), kind_base = (!none && !need_new) ? 2 : 0;
+  dim3 grid(none ? 1 : kf_div_up(kf_div_up(c1, 2), 32), none ? 1 : kf_div_up(kf_div_up(r1, 2), 8), kinds);
+  hipLaunchKernelGGL(k_pyramid, grid, dim3(256), 0, c->stream, m, none ? 0 : c->cols, none ? 0 : c->rows, c->levels, kind_base,
                      c->track, c->grid_barrier, begin_mode);
+  c->new_pyr_ok = 1; c->model_pyr_ok = 1;
   return (int)hipGetLastError();
 }
 
@@ -206,6 +197,7 @@ extern "C" int kf_bilateral_filter_depth(kf_ctx* c, float sigma_pixel, float sig
 extern "C" int kf_calculate_new_vertices(kf_ctx* c, const kf_camera_params* cam) {
   if (!c || !cam || (int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
   dim3 grid(kf_div_up(c->cols, 64), kf_div_up(c->rows, 4));
+  c->new_pyr_ok = 0;
   hipLaunchKernelGGL(k_depth_to_vertices, grid, dim3(256), 0, c->stream, c->filtered_depth, c->new_v[0], to_cam(cam));
   return (int)hipGetLastError();
 }
@@ -213,6 +205,7 @@ extern "C" int kf_calculate_new_vertices(kf_ctx* c, const kf_camera_params* cam)
 extern "C" int kf_calculate_new_normals(kf_ctx* c) {
   if (!c) return KF_ERR_ARG;
   dim3 grid(kf_div_up(c->cols, 64), kf_div_up(c->rows, 4));
+  c->new_pyr_ok = 0;
   hipLaunchKernelGGL(k_vertices_to_normals, grid, dim3(256), 0, c->stream, c->new_v[0], c->new_n[0], c->cols, c->rows);
   return (int)hipGetLastError();
 }
@@ -266,6 +259,15 @@ extern "C" int kf_preprocess(kf_ctx* c, float tmin, float tmax, float sigma_pixe
     float4* q;
     q = c->new_v[0]; c->new_v[0] = c->alt_v0; c->alt_v0 = q;
     q = c->new_n[0]; c->new_n[0] = c->alt_n0; c->alt_n0 = q;
+    c->new_pyr_ok = 0;
+    if (c->alt_pyr_ok && c->levels == 3 && c->alt_v12[0]) {     // the set came with its pyramids (riders of the raycast launch): they are adopted too
+      for (int l = 0; l < 2; ++l) {
+        q = c->new_v[l + 1]; c->new_v[l + 1] = c->alt_v12[l]; c->alt_v12[l] = q;
+        q = c->new_n[l + 1]; c->new_n[l + 1] = c->alt_n12[l]; c->alt_n12[l] = q;
+      }
+      c->new_pyr_ok = 1;
+    }
+    c->alt_pyr_ok = 0;
     if (c->fp_done) {
       // produced by the previous frame's raycast launch on this very stream: nothing to wait for.  If that launch also built the integrate
       // tile tables for this depth map (and no integrate has cleared them since), they become current now.
@@ -282,6 +284,7 @@ extern "C" int kf_preprocess(kf_ctx* c, float tmin, float tmax, float sigma_pixe
     c->prefetch_valid = 0;
     // the tile tables can ride along when they are clear (the last fusion pass cleared them) and an integration distance is known
     const bool build_tiles = c->tiles_clear && c->fuse_max_dist > 0.f;
+    c->new_pyr_ok = 0;
     st = launch_fused_preprocess(c, c->stream, c->pending_mm, c->raw_depth, c->raw_depth, c->trunced_depth, c->filtered_depth, c->new_v[0], c->new_n[0],
                                  tmin, tmax, sigma_pixel, sigma_depth, cam, build_tiles);
     c->trunc_serial++;
@@ -319,7 +322,13 @@ extern "C" int kf_prefetch_frame(kf_ctx* c, const uint16_t* dev_mm, uint32_t col
   if (!c->alt_raw) {
     KF_CHECK(hipMalloc((void**)&c->alt_raw, npx * 4)); KF_CHECK(hipMalloc((void**)&c->alt_trunced, npx * 4)); KF_CHECK(hipMalloc((void**)&c->alt_filtered, npx * 4));
     KF_CHECK(hipMalloc((void**)&c->alt_v0, npx * sizeof(float4))); KF_CHECK(hipMalloc((void**)&c->alt_n0, npx * sizeof(float4)));
+    if (c->levels == 3)
+      for (int l = 0; l < 2; ++l) {
+        const size_t n = (size_t)(c->cols >> (l + 1)) * (c->rows >> (l + 1)) * sizeof(float4);
+        KF_CHECK(hipMalloc((void**)&c->alt_v12[l], n ? n : 16)); KF_CHECK(hipMalloc((void**)&c->alt_n12[l], n ? n : 16));
+      }
   }
+  c->alt_pyr_ok = 0;
   static int fused = -1;                                   // KF_PREFETCH_FUSED=0: the side-stream form (events between two streams)
   if (fused < 0) { const char* e = getenv("KF_PREFETCH_FUSED"); fused = e ? atoi(e) : 1; }
   if (fused) {

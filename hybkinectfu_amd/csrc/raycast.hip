@@ -302,7 +302,10 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
 // behind == 1: the filter itself has run already (riders of the tracking launch, track.hip); what is left are the integrate tile tables, which
 // may only be written now that the fusion pass has cleared them (one gated-depth read per pixel; b.acc.tile null: not wanted), and the frame's
 // vertices + normals (out_v non-null), which then need no launch of their own.
-struct KfFrontTail { int behind; float4* out_v; float4* out_n; KfCam cam; };
+// ... and with them levels 1 and 2 of their pyramids (pyr.v1 non-null): a 64x4 tile holds whole 2x2 and 4x4 blocks, so the riders need nothing
+// from each other and the tracker's pyramid launch finds the new maps' pyramids done.
+struct KfFrontTail { int behind; float4* out_v; float4* out_n; KfCam cam; KfPyrOut pyr; };
+#define RIDER_LDS_BYTES (2 * (BIL_TX * BIL_TY + BIL_TX * BIL_TY / 4) * 2 * (int)sizeof(float4))      // per half: the tile's vertices + normals and their level 1
 template <bool FAST>
 __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast_prefetch(RaycastArgs a, KfBilateralArgs b, KfFrontTail ft, int rc_gx, int n_rc, int bil_gx, int bil_tiles) {
   extern __shared__ unsigned s_dyn[];
@@ -315,8 +318,15 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast_prefetch(RaycastArg
     const int tt = t < bil_tiles ? t : bil_tiles;
     if (ft.behind) {
       kf_tiles_from_gated(b, tt % bil_gx, tt / bil_gx, tid);
-      const int x = (tt % bil_gx) * BIL_TX + (tid & 63), y = (tt / bil_gx) * BIL_TY + (tid >> 6);
-      if (ft.out_v && x < ft.cam.cols && y < ft.cam.rows) kf_vertex_normal_pixel(b.filtered, ft.out_v, ft.out_n, ft.cam, x, y);
+      const int x0 = (tt % bil_gx) * BIL_TX, y0 = (tt / bil_gx) * BIL_TY, x = x0 + (tid & 63), y = y0 + (tid >> 6);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f), n = v;
+      if (ft.out_v && x < ft.cam.cols && y < ft.cam.rows) kf_vertex_normal_pixel(b.filtered, ft.out_v, ft.out_n, ft.cam, x, y, &v, &n);
+      if (ft.pyr.v1) {                                                       // uniform
+        float4* s_v = reinterpret_cast<float4*>(s_dyn) + half * (RIDER_LDS_BYTES / 2 / (int)sizeof(float4));
+        float4* s_n = s_v + BIL_TX * BIL_TY, *s1_v = s_n + BIL_TX * BIL_TY, *s1_n = s1_v + BIL_TX * BIL_TY / 4;
+        s_v[tid] = v; s_n[tid] = n;
+        kf_tile_pyramid<BIL_TX, BIL_TY>(ft.pyr, x0, y0, tid, s_v, s_n, s1_v, s1_n, [] { __syncthreads(); });
+      }
     } else kf_bilateral_tile<4, FAST>(b, tt % bil_gx, tt / bil_gx, tid, reinterpret_cast<float*>(s_dyn) + half * ((BIL_TX + 8) * (BIL_TY + 8)));
   }
 }
@@ -331,6 +341,7 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
   a.cam.cols = (int)cam->cols; a.cam.rows = (int)cam->rows; a.cam.cx = cam->cx; a.cam.cy = cam->cy; a.cam.fx = cam->fx; a.cam.fy = cam->fy;
   if (transform) { for (int i = 0; i < 16; ++i) a.pose_val.m[i] = transform->m[i]; a.pose = nullptr; }
   else a.pose = c->track->pose;
+  if (!out_cand && (!out_v || !out_n)) c->model_pyr_ok = 0;             // the model maps' level 0 is rewritten
   a.out_v = out_v ? out_v : c->model_v[0]; a.out_n = out_n ? out_n : c->model_n[0]; a.out_rgb = c->raycast_rgb; a.out_t = out_t; a.out_cand = out_cand;
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
   { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_RAYCAST_EXP"); a.exp_mode = em; }
@@ -357,11 +368,16 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
       ft.behind = behind;
       if (behind) {
         ft.out_v = c->alt_v0; ft.out_n = c->alt_n0;
+        if (c->levels == 3 && c->alt_v12[0]) {
+          ft.pyr.v1 = c->alt_v12[0]; ft.pyr.n1 = c->alt_n12[0]; ft.pyr.v2 = c->alt_v12[1]; ft.pyr.n2 = c->alt_n12[1];
+          ft.pyr.c1 = c->cols >> 1; ft.pyr.r1 = c->rows >> 1; ft.pyr.c2 = ft.pyr.c1 >> 1; ft.pyr.r2 = ft.pyr.r1 >> 1;
+        }
         ft.cam.cols = (int)c->fp_cam.cols; ft.cam.rows = (int)c->fp_cam.rows; ft.cam.cx = c->fp_cam.cx; ft.cam.cy = c->fp_cam.cy; ft.cam.fx = c->fp_cam.fx; ft.cam.fy = c->fp_cam.fy;
       }
       const int bil_gx = kf_div_up(c->cols, BIL_TX), bil_tiles = bil_gx * kf_div_up(c->rows, BIL_TY);
       const int n_rc = (int)(grid.x * grid.y), n_bil = (bil_tiles + 1) / 2;
-      const size_t lds2 = lds > 2 * (BIL_TX + 8) * (BIL_TY + 8) * sizeof(float) ? lds : 2 * (BIL_TX + 8) * (BIL_TY + 8) * sizeof(float);
+      const size_t rider_lds = behind ? (size_t)RIDER_LDS_BYTES : 2 * (BIL_TX + 8) * (BIL_TY + 8) * sizeof(float);
+      const size_t lds2 = lds > rider_lds ? lds : rider_lds;
       const dim3 g2((unsigned)(n_rc + n_bil));
       if (fast) {
         if (timed) hipExtLaunchKernelGGL(k_raycast_prefetch<true>, g2, dim3(RAYCAST_THREADS), (unsigned)lds2, c->stream, ke0, ke1, 0, a, b, ft, (int)grid.x, n_rc, bil_gx, bil_tiles);
@@ -375,6 +391,7 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
         const int st = kf_launch_vertices_normals(c, c->stream, c->alt_filtered, c->alt_v0, c->alt_n0, &c->fp_cam);
         if (st) return st;
       }
+      c->alt_pyr_ok = (behind && ft.pyr.v1) ? 1 : 0;
       c->prefetch_src = c->fp_src; memcpy(c->prefetch_params, c->fp_params, sizeof(c->prefetch_params));
       c->prefetch_valid = 1; c->fp_done = 1;
       c->fp_tiles = build_tiles ? 1 : 0; c->fp_tiles_dist = c->fuse_max_dist; c->fp_tiles_min = (build_tiles && b.acc.n) ? 1 : 0;
@@ -475,6 +492,7 @@ extern "C" int kf_set_model_maps_rays(kf_ctx* c, const kf_mat44* transform, cons
   if (!c || !cam || !dev_cand) return KF_ERR_ARG;
   if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
   SlabUnpackArgs a;
+  c->model_pyr_ok = 0;
   a.cand = (const float4*)dev_cand; a.v = c->model_v[0]; a.n = c->model_n[0];
   a.cam.cols = (int)cam->cols; a.cam.rows = (int)cam->rows; a.cam.cx = cam->cx; a.cam.cy = cam->cy; a.cam.fx = cam->fx; a.cam.fy = cam->fy;
   if (transform) { for (int k = 0; k < 16; ++k) a.pose_val.m[k] = transform->m[k]; a.pose = nullptr; }
@@ -486,6 +504,7 @@ extern "C" int kf_set_model_maps_rays(kf_ctx* c, const kf_mat44* transform, cons
 extern "C" int kf_set_model_maps_device(kf_ctx* c, const float* dev_v, const float* dev_n) {
   if (!c || !dev_v || !dev_n) return KF_ERR_ARG;
   const size_t bytes = (size_t)c->cols * c->rows * sizeof(float4);
+  c->model_pyr_ok = 0;
   KF_CHECK(hipMemcpyAsync(c->model_v[0], dev_v, bytes, hipMemcpyDeviceToDevice, c->stream));
   KF_CHECK(hipMemcpyAsync(c->model_n[0], dev_n, bytes, hipMemcpyDeviceToDevice, c->stream));
   return 0;
