@@ -25,6 +25,7 @@ struct RaycastArgs {
   float4* out_v; float4* out_n; uchar4* out_rgb;
   float* out_t;                  // optional: ray parameter of the first crossing this context detected (+inf: none) -- z-slab merge
   float4* out_cand;              // optional (z-slab merge, ray form): (vertex's ray parameter, normal xyz) instead of the two maps
+  KfPyrOut pyr;                  // v1 non-null: the workgroups also leave levels 1 and 2 of the two maps' pyramids (bilateral_tile.h: kf_tile_pyramid)
   float inc, near_plane, far_plane;
   int has_color;
   int neg_words;                 // words of vol.negbits to keep in LDS (0: the table does not fit -> brick flags are read from global memory)
@@ -202,11 +203,12 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // a workgroup is a 32x16 pixel tile, a wave an 8x8 patch of it
   const int x = tile_x * 32 + (wave & 3) * 8 + (lane & 7), y = tile_y * 16 + (wave >> 2) * 8 + (lane >> 3);
-  if (x >= a.cam.cols || y >= a.cam.rows) return;
-  if (KF_EXP_MODE(a) == 2 && ((tile_x + tile_y) & 1)) return;      // timing experiment: half the rays (latency- or throughput-bound?)
+  // (pixels outside the image and the timing experiment "half the rays" -- latency- or throughput-bound? -- march nothing but stay for the epilogue)
+  const bool live = x < a.cam.cols && y < a.cam.rows && !(KF_EXP_MODE(a) == 2 && ((tile_x + tile_y) & 1));
+  float4 out_v = make_float4(0.f, 0.f, 0.f, 0.f), out_n = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto march_pixel = [&]() {
   const int pix = y * a.cam.cols + x;
   const float inf = __builtin_huge_valf();
-  float4 out_v = make_float4(0.f, 0.f, 0.f, 0.f), out_n = make_float4(0.f, 0.f, 0.f, 0.f);
   uchar4 out_c = make_uchar4(0, 0, 0, 0);
   float t_cross = inf, t_cross_prev = 0.f, out_alpha = 0.f;
   const float* T = a.pose ? a.pose : a.pose_val.m;
@@ -288,6 +290,19 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
   }
   if (a.out_t) a.out_t[pix] = t_cross;
   if (a.has_color) a.out_rgb[pix] = out_c;
+  };
+  if (live) march_pixel();
+  // Levels 1 and 2 of the model maps' pyramids, which the NEXT frame's tracker reads first (ICP.cpp:57-60): a 32x16 tile holds whole 2x2 and
+  // 4x4 blocks, so the workgroup that produced the texels averages them itself -- through the LDS the bit tables occupied until its last wave
+  // left the march -- and the tracker's pyramid launch (a pass over four maps, ~8 us) has nothing left to do.
+  if (a.pyr.v1) {                                                            // uniform
+    __syncthreads();                                                         // every wave is done with the tables
+    float4* s_v = reinterpret_cast<float4*>(s_tables);
+    float4* s_n = s_v + 32 * 16, *s1_v = s_n + 32 * 16, *s1_n = s1_v + 16 * 8;
+    const int li = ((wave >> 2) * 8 + (lane >> 3)) * 32 + (wave & 3) * 8 + (lane & 7);
+    s_v[li] = out_v; s_n[li] = out_n;
+    kf_tile_pyramid<32, 16>(a.pyr, tile_x * 32, tile_y * 16, (int)threadIdx.x, s_v, s_n, s1_v, s1_n, [] { __syncthreads(); });
+  }
 }
 
 __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
@@ -306,6 +321,8 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast(RaycastArgs a) {
 // from each other and the tracker's pyramid launch finds the new maps' pyramids done.
 struct KfFrontTail { int behind; float4* out_v; float4* out_n; KfCam cam; KfPyrOut pyr; };
 #define RIDER_LDS_BYTES (2 * (BIL_TX * BIL_TY + BIL_TX * BIL_TY / 4) * 2 * (int)sizeof(float4))      // per half: the tile's vertices + normals and their level 1
+// (six waves per SIMD = three 8-wave workgroups per CU: all 600 ray tiles of a VGA frame resident at once, as in k_raycast -- the filter code would
+// otherwise take 90 registers and push the last 88 tiles into a second round)
 template <bool FAST>
 __global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast_prefetch(RaycastArgs a, KfBilateralArgs b, KfFrontTail ft, int rc_gx, int n_rc, int bil_gx, int bil_tiles) {
   extern __shared__ unsigned s_dyn[];
@@ -342,6 +359,14 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
   if (transform) { for (int i = 0; i < 16; ++i) a.pose_val.m[i] = transform->m[i]; a.pose = nullptr; }
   else a.pose = c->track->pose;
   if (!out_cand && (!out_v || !out_n)) c->model_pyr_ok = 0;             // the model maps' level 0 is rewritten
+  memset(&a.pyr, 0, sizeof(a.pyr));
+  static int pyr_env = -1;
+  if (pyr_env < 0) { const char* e = getenv("KF_RAYCAST_PYRAMID"); pyr_env = e ? atoi(e) : 1; }
+  const bool model_pyr = pyr_env && !out_cand && !out_v && !out_n && c->levels == 3;      // the model maps themselves, stock pyramid depth
+  if (model_pyr) {
+    a.pyr.v1 = c->model_v[1]; a.pyr.n1 = c->model_n[1]; a.pyr.v2 = c->model_v[2]; a.pyr.n2 = c->model_n[2];
+    a.pyr.c1 = c->cols >> 1; a.pyr.r1 = c->rows >> 1; a.pyr.c2 = a.pyr.c1 >> 1; a.pyr.r2 = a.pyr.r1 >> 1;
+  }
   a.out_v = out_v ? out_v : c->model_v[0]; a.out_n = out_n ? out_n : c->model_n[0]; a.out_rgb = c->raycast_rgb; a.out_t = out_t; a.out_cand = out_cand;
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
   { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_RAYCAST_EXP"); a.exp_mode = em; }
@@ -353,7 +378,8 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
   {
     hipEvent_t ke0 = nullptr, ke1 = nullptr;               // the kernel's own timer rides on its dispatch (kf_evt_attach): the kernel as rocprofv3 sees it
     const dim3 grid(kf_div_up(c->cols, 32), kf_div_up(c->rows, 16));
-    const size_t lds = macro_bytes + (size_t)a.neg_words * 4;
+    const size_t pyr_lds = model_pyr ? (size_t)(32 * 16 + 16 * 8) * 2 * sizeof(float4) : 0;      // the tile's two maps and their level 1
+    const size_t lds = macro_bytes + (size_t)a.neg_words * 4 > pyr_lds ? macro_bytes + (size_t)a.neg_words * 4 : pyr_lds;
     const bool timed = kf_evt_attach(c, KF_STAGE_RAYCAST_KERNEL, &ke0, &ke1);
     if (c->fp_pending && c->alt_raw) {
       // kf_prefetch_frame left a note: the next frame's u16 -> f32 + gate + bilateral rides in this launch (k_raycast_prefetch), its vertices /
@@ -402,6 +428,7 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
     } else hipLaunchKernelGGL(k_raycast, grid, dim3(RAYCAST_THREADS), lds, c->stream, a);
   }
   kf_evt_end(c, KF_STAGE_RAYCAST);
+  if (model_pyr) c->model_pyr_ok = 1;
   return (int)hipGetLastError();
 }
 

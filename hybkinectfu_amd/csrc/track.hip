@@ -800,7 +800,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   if (s_code != STEP_APPLIED) { if (threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; } return; }
   if (threadIdx.x < 16) st->pose[threadIdx.x] = s_cur[threadIdx.x];
   if (threadIdx.x == 64) kf_mat44_inverse(s_cur, st->pose_inv);               // a lane of another wave: the integrate pass reads it (integrateVolume.cu:84)
-  if (threadIdx.x == 0) { st->tracked = 1; st->iterations = applied + 1; }
+  if (threadIdx.x == 0) { st->status = KF_TRACK_OK; st->tracked = 1; st->iterations = applied + 1; }    // (status: this launch may have run without k_track_begin's reset)
 }
 
 // ---- SDF tracker ------------------------------------------------------------------------------------------------------
@@ -1004,7 +1004,6 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   if (c->levels == 1) iters[0] = 3; else if (c->levels == 2) { iters[0] = 10; iters[1] = 5; } else { iters[0] = 10; iters[1] = 5; iters[2] = 4; }
   int st;
   kf_evt_begin(c, KF_STAGE_TRACK);
-  if ((st = kf_launch_pyramids_and_begin(c, 1))) return st;             // ICP.cpp:57-63: four pyramids + loop set-up, one launch
   kf_camera_params cams[KF_MAX_LEVELS]; cams[0] = *cam0;
   for (int l = 1; l < c->levels; ++l) {                      // ICP.cpp:36-48
     cams[l].cols = cams[l - 1].cols / 2; cams[l].rows = cams[l - 1].rows / 2;
@@ -1030,6 +1029,11 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   }
   if (use_loop && (c->loop_occupancy < 1 || (long long)grid0 > (long long)c->loop_occupancy * c->num_cus)) use_loop = false;     // e.g. 1280x960: 800 workgroups
   if (use_loop && c->persistent_backoff > 0) { --c->persistent_backoff; use_loop = false; }
+  // ICP.cpp:57-63: the four pyramids + the loop's set-up, one launch -- unless every pyramid describes its level 0 already (the raycast launch
+  // left the model maps' behind, its riders the prefetched frame's: raycast.hip) AND the persistent loop runs, which reads nothing of that
+  // set-up but the committed pose and writes its whole verdict itself: the steady-state frame then has no pyramid launch at all
+  const bool pyramids_done = c->levels == 3 && c->new_pyr_ok && c->model_pyr_ok;
+  if (!(use_loop && !coop_env && pyramids_done) && (st = kf_launch_pyramids_and_begin(c, 1))) return st;
   if (use_loop) {
     IcpLoopArgs L; memset(&L, 0, sizeof(L));
     for (int l = 0; l < c->levels; ++l) {
