@@ -324,7 +324,7 @@ struct KfFrontTail { int behind; float4* out_v; float4* out_n; KfCam cam; KfPyrO
 // (six waves per SIMD = three 8-wave workgroups per CU: all 600 ray tiles of a VGA frame resident at once, as in k_raycast -- the filter code would
 // otherwise take 90 registers and push the last 88 tiles into a second round)
 template <bool FAST>
-__global__ void __launch_bounds__(RAYCAST_THREADS) k_raycast_prefetch(RaycastArgs a, KfBilateralArgs b, KfFrontTail ft, int rc_gx, int n_rc, int bil_gx, int bil_tiles) {
+__global__ void __launch_bounds__(RAYCAST_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) k_raycast_prefetch(RaycastArgs a, KfBilateralArgs b, KfFrontTail ft, int rc_gx, int n_rc, int bil_gx, int bil_tiles) {
   extern __shared__ unsigned s_dyn[];
   if ((int)blockIdx.x < n_rc) {
     __builtin_amdgcn_s_setprio(2);
