@@ -397,6 +397,41 @@ def test_prefetched_preprocess_is_bit_identical():
         assert np.array_equal(outs[0][2][0], other[2][0]) and np.array_equal(outs[0][2][1], other[2][1])
 
 
+def test_lost_frame_in_the_prefetched_stream_equals_the_plain_sequence():
+    """The steady-state frame has no pyramid / set-up launch of its own (the pyramids ride in the previous raycast launch, the persistent loop
+    writes its whole verdict itself): a frame the tracker LOSES in the middle of a prefetched stream, and the frames after it, must leave the
+    same verdicts, pose bits, counters and voxel bits as the plain call sequence, which runs the set-up launch before every loop."""
+    import torch
+    from hybkinectfu_amd.pipeline import SingleGpuPipeline
+    res, size, cam = 256, 3.0, S.vga_camera()
+    wl = dict(trunc_max=P["depth_trunc_max"], integ_dist=P["integrate_depth_trunc"])
+    n, bad = 8, 4
+    frames = np.stack([S.render_depth_mm(S.trajectory_pose(k, size), cam, size) for k in range(n)])
+    frames[bad] = 0                                                        # a sensor drop-out: no valid pixel, no system to solve (ICP.cpp:138)
+    dev = torch.from_numpy(frames.astype(np.int16)).cuda()
+    fb = cam[0] * cam[1] * 2
+    outs = []
+    for mode in ("plain", "prefetch"):
+        pipe = SingleGpuPipeline(K.camera(*cam), res, size, wl)
+        log = []
+        for k in range(n):
+            nxt = dev.data_ptr() + (k + 1) * fb if (mode == "prefetch" and k + 1 < n) else None
+            pipe.process_frame_device(dev.data_ptr() + k * fb, k, nxt)
+            ok, pose, status, iters = pipe.track_result()
+            log.append((bool(ok), int(status), int(iters), pose.copy()))
+        pipe.sync()
+        st = pipe.stats()
+        outs.append((log, pipe.ctx.download_volume(), st["frames_fused"], st["frames_lost"], pipe.ctx.download_map(K.MAP_MODEL_VERTICES)))
+        pipe.close()
+    (la, va, fa, xa, ma), (lb, vb, fb_, xb, mb) = outs
+    assert not la[bad][0] and la[bad][1] != 0 and all(r[0] for i, r in enumerate(la) if i != bad)       # exactly the empty frame is lost
+    assert fa == n - 1 and xa == 1 and (fa, xa) == (fb_, xb)
+    for ra, rb in zip(la, lb):
+        assert ra[:3] == rb[:3] and np.array_equal(ra[3].view(np.uint32), rb[3].view(np.uint32))
+    assert np.array_equal(va[0].view(np.uint32), vb[0].view(np.uint32)) and np.array_equal(va[1], vb[1])
+    assert np.array_equal(ma.view(np.uint32), mb.view(np.uint32))
+
+
 def test_maximum_configuration_2048_cubed():
     """BASELINE.json's largest configuration on ONE GPU: 2048^3 @ 8 m (68.7 GB of voxels), 1280x960 depth.  Exercises the 64-bit
     voxel addressing, a brick queue of > 1 M entries, the one-launch-per-step ICP (1.2 M pixels exceed the persistent loop's
