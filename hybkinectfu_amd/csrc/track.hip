@@ -56,6 +56,7 @@ struct TrackArgs {
   int slab_pixels;                               // 1: sum only pixels whose own voxel (pworld0) lies in the layers this context OWNS (z-slab partition)
 #ifdef KF_EXPERIMENTS
   unsigned long long* dbg;                       // KF_ICP_EXP=11: where workgroup 0 accumulates the solve's sub-phase times (10 ns ticks)
+  int exp_nodet;                                 // KF_ICP_EXP=12: skip the determinant (timing only)
 #endif
 };
 
@@ -319,8 +320,7 @@ __device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_to
   if (!a.sdf) {
     // ICP: the determinant test (ICP.cpp:138) and the solve + increment (:143, :71-82) do not depend on each other, so two
     // lanes of DIFFERENT waves run them side by side and lane 0 keeps the solve's result only if the determinant passed.
-    // LDS scratch behind the 27 totals (s_tot + 32): [0..15] candidate transform, [16] solve verdict, [17] det verdict,
-    // [20..25] the increment x, [26..28] cosines and [29..31] sines of its three angles.
+    // LDS scratch behind the 27 totals (s_tot + 32): [0..15] candidate transform, [16] solve verdict, [17] det verdict.
     float* scratch = const_cast<float*>(s_tot) + 32;
     const unsigned det_lane = blockDim.x > 64u ? 64u : 1u;
 #ifdef KF_EXPERIMENTS
@@ -332,48 +332,50 @@ __device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_to
     if (threadIdx.x == det_lane) {
       float A[36], b[6];
       unpack27(s_tot, A, b);
+#ifdef KF_EXPERIMENTS
+      if (a.exp_nodet) scratch[17] = 0.f; else            // timing experiment (KF_ICP_EXP=12): what does the determinant lane cost the step?
+#endif
       scratch[17] = ((double)det6(A) < 1E-10) ? 1.f : 0.f;
       KF_SOLVE_STAMP(6);                                                     // determinant lane: entry -> done
     }
-    // wave 0 runs the solve, the trigonometry and the increment as ONE chain: its lanes hand values to each other through LDS
-    // in program order (a wave's LDS operations complete in order), so no workgroup barrier is needed until the determinant
-    // wave is joined at the end -- the determinant (the longer of the two 6x6 factorizations) hides behind the whole chain.
+    // wave 0 runs the solve, the trigonometry and the increment as ONE chain without touching LDS in between: lane 0 solves; the increment
+    // goes to the whole wave as scalars (v_readfirstlane: lane 0 is the wave's first lane); lanes 0-2 take the sine / cosine of one angle
+    // each and hand them back the same way (v_readlane); then EVERY lane forms the rotation and the shake verdict from those scalars -- the
+    // same expressions, hence the same bits, in all of them -- and twelve lanes compute one element each of T * cur (ICP.cpp:81) instead of
+    // lane 0 computing all twelve.  (A third of the instructions of the LDS hand-off form it replaces and no wavefront fences -- and the same
+    // 1.2 us per Gauss-Newton step: the phase is the solve's dependent chain plus two workgroup barriers, not instruction issue.)  The
+    // determinant (the longer of the two 6x6 factorizations, 1.1 us) runs on a lane of another wave and is joined at the workgroup barrier
+    // below; it holds the step back by 0.15 us (KF_ICP_EXP=12 on the experiments build skips it: 145.5 -> 142.7 us per frame).
     if (threadIdx.x < 64) {
-      float* vs = scratch;                                                  // (plain accesses: the wavefront-scope fences below order them)
+      float* vs = scratch;
+      float x[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (threadIdx.x == 0) {
-        float A[36], b[6], x[6];
+        float A[36], b[6];
         unpack27(s_tot, A, b);
         llt_solve6(A, b, x);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) vs[20 + i] = x[i];
         KF_SOLVE_STAMP(0);                                                   // unpack + Cholesky solve
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (threadIdx.x < 3) {                                               // the three Euler angles: one lane each, one pass of the trig code
-        const float ang = vs[20 + threadIdx.x];
-        float sn, cs; kf_sincos_small(ang, &sn, &cs);
-        vs[26 + threadIdx.x] = cs; vs[29 + threadIdx.x] = sn;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) x[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x[i])));
+      const float ang = threadIdx.x == 0 ? x[0] : (threadIdx.x == 1 ? x[1] : x[2]);
+      float sn, cs; kf_sincos_small(ang, &sn, &cs);
+      const int sni = __float_as_int(sn), csi = __float_as_int(cs);
+      const float c0 = __int_as_float(__builtin_amdgcn_readlane(csi, 0)), s0 = __int_as_float(__builtin_amdgcn_readlane(sni, 0));
+      const float c1 = __int_as_float(__builtin_amdgcn_readlane(csi, 1)), s1 = __int_as_float(__builtin_amdgcn_readlane(sni, 1));
+      const float c2 = __int_as_float(__builtin_amdgcn_readlane(csi, 2)), s2 = __int_as_float(__builtin_amdgcn_readlane(sni, 2));
+      if (threadIdx.x == 0) KF_SOLVE_STAMP(1);                               // increment broadcast + sin/cos + hand-back
+      float T[16];
+      const bool still = transform_from_sincos(x, c0, s0, c1, s1, c2, s2, a.dist_shake2, a.cos_shake, T);
+      if (threadIdx.x == 0) vs[16] = still ? 0.f : 1.f;
+      if (still && threadIdx.x < 16) {
+        // ICP.cpp:81 cur = T * cur; T's last row is (0, 0, 0, 1): that row of the product is cur's own last row, bit for bit
+        const int i = (int)threadIdx.x >> 2, j = (int)threadIdx.x & 3;
+        const float t0 = i == 0 ? T[0] : (i == 1 ? T[4] : T[8]), t1 = i == 0 ? T[1] : (i == 1 ? T[5] : T[9]);
+        const float t2 = i == 0 ? T[2] : (i == 1 ? T[6] : T[10]), t3 = i == 0 ? T[3] : (i == 1 ? T[7] : T[11]);
+        const float prod = t0 * s_cur[j] + t1 * s_cur[4 + j] + t2 * s_cur[8 + j] + t3 * s_cur[12 + j];
+        vs[threadIdx.x] = i < 3 ? prod : s_cur[12 + j];
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (threadIdx.x == 0) KF_SOLVE_STAMP(1);                               // hand-off + sin/cos + hand-off
-      if (threadIdx.x == 0) {
-        float x[6], T[16], ncur[16];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) x[i] = vs[20 + i];
-        const bool still = transform_from_sincos(x, vs[26], vs[29], vs[27], vs[30], vs[28], vs[31], a.dist_shake2, a.cos_shake, T);
-        vs[16] = still ? 0.f : 1.f;
-        if (still) {
-          // ICP.cpp:81 cur = T * cur; T's last row is (0, 0, 0, 1): that row of the product is cur's own last row, bit for bit
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ncur[i * 4 + j] = T[i * 4] * s_cur[j] + T[i * 4 + 1] * s_cur[4 + j] + T[i * 4 + 2] * s_cur[8 + j] + T[i * 4 + 3] * s_cur[12 + j];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) ncur[12 + j] = s_cur[12 + j];
-          for (int i = 0; i < 16; ++i) vs[i] = ncur[i];
-        }
-        KF_SOLVE_STAMP(2);                                                   // rotation, shake test, T * cur
-      }
+      if (threadIdx.x == 0) KF_SOLVE_STAMP(2);                               // rotation, shake test, T * cur
     }
     __syncthreads();
     if (threadIdx.x == 0) KF_SOLVE_STAMP(3);                                 // workgroup barrier (waits for the determinant lane)
@@ -713,6 +715,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   a.dist_thres2 = L.dist_thres2; a.sin_thres2 = L.sin_thres2; a.sdf = 0;
 #ifdef KF_EXPERIMENTS
   a.dbg = (KF_EXP_MODE(L) == 11 && blockIdx.x == 0) ? L.slots + (size_t)26 * KF_ICP_LOOP_MAX_WG * 32 : nullptr;
+  a.exp_nodet = KF_EXP_MODE(L) == 12;
 #endif
   int step = 0, n_prev = 0, applied = 0;
   // diagnostic build path (KF_ICP_EXP=7): workgroup 0 accumulates shader-clock ticks per segment into track->reduced
