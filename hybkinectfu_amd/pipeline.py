@@ -237,7 +237,6 @@ class SlabPipeline:
                                mask=lambda t, tmin, cand: c.slab_mask_rays(t.data_ptr(), tmin.data_ptr(), cand.data_ptr()),
                                unpack=lambda cand: c.set_model_maps_rays(None, cand.data_ptr()))
         self.sums = torch.zeros(32, dtype=torch.float32, device=dev)
-        self._preprocessed = None           # device pointer of a frame whose preprocess was enqueued during the previous frame's merge
         self._merge_events = None           # time_merge(True): (start, end) torch event pairs around every frame's merge
 
     def process_frame_device(self, dev_mm_ptr, frame_id, next_mm_ptr=None):
@@ -251,9 +250,11 @@ class SlabPipeline:
 
     def _process_frame_device(self, dev_mm_ptr, frame_id, next_mm_ptr):
         c, dist, ex = self.ctx, self.dist, self.ex
-        if self._preprocessed != dev_mm_ptr:                              # not done ahead of time by the previous call (see below)
-            self._preprocess(dev_mm_ptr)
-        self._preprocessed = None
+        self._preprocess(dev_mm_ptr)                                      # (adopts the set the previous frame's launches prepared, if they did)
+        if next_mm_ptr is not None:
+            # the next frame's front end rides in this frame's launches (kf_prefetch_frame): gate + bilateral in the tracking launch when the persistent
+            # loop runs, tile tables + vertices / normals + their pyramids in the raycast launch -- the replicated part of a rank's frame shrinks
+            c.prefetch_frame(next_mm_ptr, P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
         if self.tracker == "sdf":
             c.sdf_partition_track(frame_id, P["sdf_max_iter_nums"], P["camera_shake_dist"], P["camera_shake_angle"], self.sums.data_ptr(),
                                   lambda: dist.all_reduce(self.sums, op=dist.ReduceOp.SUM))
@@ -265,23 +266,17 @@ class SlabPipeline:
         c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist)
         c.raycast_slab_rays(None, self.inc, P["depth_trunc_min"], self.trunc_max, ex.t.data_ptr(), ex.cand.data_ptr())
 
-        def overlap():
-            # the MIN all-reduce runs on RCCL's own stream until wait() joins it: the next frame's preprocess -- every reader of
-            # this frame's maps is already behind us in the stream -- fills that time instead of the start of the next frame
-            if next_mm_ptr is not None:
-                self._preprocess(next_mm_ptr)
-                self._preprocessed = next_mm_ptr
         if self._merge_events is not None:
             e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
             e0.record(self.stream)
-            ex.merge(overlap)
+            ex.merge()
             e1.record(self.stream)
             self._merge_events.append((e0, e1))
         else:
-            ex.merge(overlap)
+            ex.merge()
 
     def time_merge(self, on=True):
-        """Measurement legs only: time every frame's merge (both all-reduces, mask, unpack, and whatever the overlap hook enqueues)
+        """Measurement legs only: time every frame's merge (both all-reduces, mask, unpack)
         with a torch event pair on the pipeline's stream."""
         self._merge_events = [] if on else None
 
