@@ -493,21 +493,30 @@ __global__ void __launch_bounds__(256) k_slab_rays_mask(const float* __restrict_
   const float ti = t[i];
   if (!(ti == tmin[i] && ti < __builtin_huge_valf())) cand[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
-struct SlabUnpackArgs { const float4* cand; float4* v; float4* n; KfCam cam; const float* pose; KfMat pose_val; };
+struct SlabUnpackArgs { const float4* cand; float4* v; float4* n; KfCam cam; const float* pose; KfMat pose_val; KfPyrOut pyr; };
+// one 32x8 pixel tile per workgroup: the tile's whole 2x2 and 4x4 blocks also give levels 1 and 2 of the model maps' pyramids (kf_tile_pyramid),
+// so the tracker that follows finds them done, as after a single-GPU raycast
 __global__ void __launch_bounds__(256) k_slab_rays_unpack(SlabUnpackArgs a) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.cam.cols * a.cam.rows) return;
-  const float4 cd = a.cand[i];
-  const bool valid = cd.y != 0.f || cd.z != 0.f || cd.w != 0.f;
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid) {
-    float3 org, dir, cam_dir;
-    rc_pixel_ray(a.cam, a.pose ? a.pose : a.pose_val.m, i % a.cam.cols, i / a.cam.cols, org, dir, cam_dir);
-    const float3 vtx = kf_add(org, kf_scale(dir, cd.x));
-    v = make_float4(vtx.x, vtx.y, vtx.z, 1.0f);
+  __shared__ float4 s_v[32 * 8], s_n[32 * 8], s1_v[16 * 4], s1_n[16 * 4];
+  const int x = (int)blockIdx.x * 32 + (int)(threadIdx.x & 31), y = (int)blockIdx.y * 8 + (int)(threadIdx.x >> 5);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f), n = v;
+  if (x < a.cam.cols && y < a.cam.rows) {
+    const int i = y * a.cam.cols + x;
+    const float4 cd = a.cand[i];
+    const bool valid = cd.y != 0.f || cd.z != 0.f || cd.w != 0.f;
+    if (valid) {
+      float3 org, dir, cam_dir;
+      rc_pixel_ray(a.cam, a.pose ? a.pose : a.pose_val.m, x, y, org, dir, cam_dir);
+      const float3 vtx = kf_add(org, kf_scale(dir, cd.x));
+      v = make_float4(vtx.x, vtx.y, vtx.z, 1.0f);
+    }
+    n = make_float4(cd.y, cd.z, cd.w, 0.f);
+    a.v[i] = v; a.n[i] = n;
   }
-  a.v[i] = v;
-  a.n[i] = make_float4(cd.y, cd.z, cd.w, 0.f);
+  if (a.pyr.v1) {                                                            // uniform
+    s_v[threadIdx.x] = v; s_n[threadIdx.x] = n;
+    kf_tile_pyramid<32, 8>(a.pyr, (int)blockIdx.x * 32, (int)blockIdx.y * 8, (int)threadIdx.x, s_v, s_n, s1_v, s1_n, [] { __syncthreads(); });
+  }
 }
 extern "C" int kf_slab_mask_rays(kf_ctx* c, const float* dev_t, const float* dev_tmin, float* dev_cand) {
   if (!c || !dev_t || !dev_tmin || !dev_cand) return KF_ERR_ARG;
@@ -520,11 +529,17 @@ extern "C" int kf_set_model_maps_rays(kf_ctx* c, const kf_mat44* transform, cons
   if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
   SlabUnpackArgs a;
   c->model_pyr_ok = 0;
+  memset(&a.pyr, 0, sizeof(a.pyr));
+  if (c->levels == 3) {
+    a.pyr.v1 = c->model_v[1]; a.pyr.n1 = c->model_n[1]; a.pyr.v2 = c->model_v[2]; a.pyr.n2 = c->model_n[2];
+    a.pyr.c1 = c->cols >> 1; a.pyr.r1 = c->rows >> 1; a.pyr.c2 = a.pyr.c1 >> 1; a.pyr.r2 = a.pyr.r1 >> 1;
+  }
   a.cand = (const float4*)dev_cand; a.v = c->model_v[0]; a.n = c->model_n[0];
   a.cam.cols = (int)cam->cols; a.cam.rows = (int)cam->rows; a.cam.cx = cam->cx; a.cam.cy = cam->cy; a.cam.fx = cam->fx; a.cam.fy = cam->fy;
   if (transform) { for (int k = 0; k < 16; ++k) a.pose_val.m[k] = transform->m[k]; a.pose = nullptr; }
   else a.pose = c->track->pose;                       // the pose the raycast used: nothing moves it between the raycast and this call
-  hipLaunchKernelGGL(k_slab_rays_unpack, dim3(kf_div_up(c->cols * c->rows, 256)), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_slab_rays_unpack, dim3(kf_div_up(c->cols, 32), kf_div_up(c->rows, 8)), dim3(256), 0, c->stream, a);
+  if (a.pyr.v1) c->model_pyr_ok = 1;
   return (int)hipGetLastError();
 }
 

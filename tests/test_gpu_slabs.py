@@ -246,6 +246,14 @@ def test_mask_unpack_kernels_equal_cpu_restatement():
     assert np.array_equal(ctx.download_map(K.MAP_MODEL_NORMALS).view(np.uint32), un.numpy().view(np.uint32))
     assert torch.equal(uv.view(torch.int32), want_v.view(torch.int32)) and torch.equal(un.view(torch.int32), want_n.view(torch.int32))
     assert int((uv[..., 3] == 1).sum()) > 1000
+    # the unpack launch also leaves levels 1 and 2 of the model maps' pyramids (32x8 tiles, tile-local): the same bits as the pyramid kernel's
+    mine = [ctx.download_map(m, level) for level in (1, 2) for m in (K.MAP_MODEL_VERTICES, K.MAP_MODEL_NORMALS)]
+    ctx.downsample(True)                                         # k_pyramid over the same level 0
+    ctx.sync()
+    ref = [ctx.download_map(m, level) for level in (1, 2) for m in (K.MAP_MODEL_VERTICES, K.MAP_MODEL_NORMALS)]
+    for a, b in zip(mine, ref):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert mine[0].any() and mine[1].any()                       # (a quarter of the synthetic pixels is empty: level 2 has no complete 4x4 block)
     ctx.close()
 
 
