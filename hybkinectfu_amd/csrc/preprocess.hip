@@ -320,13 +320,19 @@ extern "C" int kf_prefetch_frame(kf_ctx* c, const uint16_t* dev_mm, uint32_t col
   KF_CHECK(hipSetDevice(c->cfg.device));
   const size_t npx = (size_t)c->cols * c->rows;
   if (!c->alt_raw) {
-    KF_CHECK(hipMalloc((void**)&c->alt_raw, npx * 4)); KF_CHECK(hipMalloc((void**)&c->alt_trunced, npx * 4)); KF_CHECK(hipMalloc((void**)&c->alt_filtered, npx * 4));
-    KF_CHECK(hipMalloc((void**)&c->alt_v0, npx * sizeof(float4))); KF_CHECK(hipMalloc((void**)&c->alt_n0, npx * sizeof(float4)));
+    // the alternate buffer set, all or nothing: a context whose set is incomplete must look like one without a set
+    void* p[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t bytes[9] = {npx * 4, npx * 4, npx * 4, npx * sizeof(float4), npx * sizeof(float4), 0, 0, 0, 0};
     if (c->levels == 3)
       for (int l = 0; l < 2; ++l) {
         const size_t n = (size_t)(c->cols >> (l + 1)) * (c->rows >> (l + 1)) * sizeof(float4);
-        KF_CHECK(hipMalloc((void**)&c->alt_v12[l], n ? n : 16)); KF_CHECK(hipMalloc((void**)&c->alt_n12[l], n ? n : 16));
+        bytes[5 + 2 * l] = bytes[6 + 2 * l] = n ? n : 16;
       }
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 9 && e == hipSuccess; ++i) if (bytes[i]) e = hipMalloc(&p[i], bytes[i]);
+    if (e != hipSuccess) { for (int i = 0; i < 9; ++i) if (p[i]) hipFree(p[i]); return (int)e; }
+    c->alt_raw = (float*)p[0]; c->alt_trunced = (float*)p[1]; c->alt_filtered = (float*)p[2]; c->alt_v0 = (float4*)p[3]; c->alt_n0 = (float4*)p[4];
+    c->alt_v12[0] = (float4*)p[5]; c->alt_n12[0] = (float4*)p[6]; c->alt_v12[1] = (float4*)p[7]; c->alt_n12[1] = (float4*)p[8];
   }
   c->alt_pyr_ok = 0;
   static int fused = -1;                                   // KF_PREFETCH_FUSED=0: the side-stream form (events between two streams)
