@@ -24,6 +24,7 @@ struct RaycastArgs {
   KfMat pose_val;
   float4* out_v; float4* out_n; uchar4* out_rgb;
   float* out_t;                  // optional: ray parameter of the first crossing this context detected (+inf: none) -- z-slab merge
+  float* out_t2;                 // optional second copy of out_t (the buffer the caller's MIN all-reduce works in place on)
   float4* out_cand;              // optional (z-slab merge, ray form): (vertex's ray parameter, normal xyz) instead of the two maps
   KfPyrOut pyr;                  // v1 non-null: the workgroups also leave levels 1 and 2 of the two maps' pyramids (bilateral_tile.h: kf_tile_pyramid)
   float inc, near_plane, far_plane;
@@ -289,6 +290,7 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
     }
   }
   if (a.out_t) a.out_t[pix] = t_cross;
+  if (a.out_t2) a.out_t2[pix] = t_cross;
   if (a.has_color) a.out_rgb[pix] = out_c;
   };
   if (live) march_pixel();
@@ -349,7 +351,7 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) __attribute__((amdgpu_waves_p
 }
 
 static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, const kf_raycast_params* rp, const kf_camera_params* cam,
-                          float near_plane, float far_plane, float* out_t, float4* out_v, float4* out_n, float4* out_cand = nullptr) {
+                          float near_plane, float far_plane, float* out_t, float4* out_v, float4* out_n, float4* out_cand = nullptr, float* out_t2 = nullptr) {
   if (!c || !rp || !cam) return KF_ERR_ARG;
   if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
   if (has_color && (!c->vol.color || !c->raycast_rgb)) return KF_ERR_STATE;
@@ -367,7 +369,7 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
     a.pyr.v1 = c->model_v[1]; a.pyr.n1 = c->model_n[1]; a.pyr.v2 = c->model_v[2]; a.pyr.n2 = c->model_n[2];
     a.pyr.c1 = c->cols >> 1; a.pyr.r1 = c->rows >> 1; a.pyr.c2 = a.pyr.c1 >> 1; a.pyr.r2 = a.pyr.r1 >> 1;
   }
-  a.out_v = out_v ? out_v : c->model_v[0]; a.out_n = out_n ? out_n : c->model_n[0]; a.out_rgb = c->raycast_rgb; a.out_t = out_t; a.out_cand = out_cand;
+  a.out_v = out_v ? out_v : c->model_v[0]; a.out_n = out_n ? out_n : c->model_n[0]; a.out_rgb = c->raycast_rgb; a.out_t = out_t; a.out_t2 = out_t2; a.out_cand = out_cand;
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
   { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_RAYCAST_EXP"); a.exp_mode = em; }
   a.work = c->count_work ? c->counters : nullptr;
@@ -481,11 +483,11 @@ extern "C" int kf_slab_mask_candidates(kf_ctx* c, const float* dev_t, const floa
 // all-reduce returns the winner's bits and kf_set_model_maps_rays turns them into the model maps (a unit normal is never all-zero,
 // which is what marks a valid pixel).
 extern "C" int kf_raycast_volume_slab_rays(kf_ctx* c, int has_color, const kf_mat44* transform, const kf_raycast_params* rp,
-                                           const kf_camera_params* cam, float near_plane, float far_plane, float* dev_t, float* dev_cand) {
+                                           const kf_camera_params* cam, float near_plane, float far_plane, float* dev_t, float* dev_t_copy, float* dev_cand) {
   if (!c || !rp || !dev_t || !dev_cand) return KF_ERR_ARG;
   const int st = slab_halo_check(c, rp);
   if (st) return st;
-  return raycast_launch(c, has_color, transform, rp, cam, near_plane, far_plane, dev_t, nullptr, nullptr, (float4*)dev_cand);
+  return raycast_launch(c, has_color, transform, rp, cam, near_plane, far_plane, dev_t, nullptr, nullptr, (float4*)dev_cand, dev_t_copy);
 }
 __global__ void __launch_bounds__(256) k_slab_rays_mask(const float* __restrict__ t, const float* __restrict__ tmin, float4* __restrict__ cand, int npx) {
   const int i = blockIdx.x * 256 + threadIdx.x;

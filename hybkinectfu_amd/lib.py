@@ -322,11 +322,11 @@ class Context:
         _chk(self.lib.kf_slab_mask_candidates(self.h, C.c_void_p(dev_t), C.c_void_p(dev_tmin), C.c_void_p(dev_v), C.c_void_p(dev_n)),
              "kf_slab_mask_candidates")
 
-    def raycast_slab_rays(self, pose, inc, near, far, dev_t, dev_cand):
+    def raycast_slab_rays(self, pose, inc, near, far, dev_t, dev_cand, dev_t_copy=None):
         rp = RaycastParams(inc)
         tp = C.byref(Mat44.of(pose)) if pose is not None else None
         _chk(self.lib.kf_raycast_volume_slab_rays(self.h, 0, tp, C.byref(rp), C.byref(self.cam), C.c_float(near), C.c_float(far),
-                                                  C.c_void_p(dev_t), C.c_void_p(dev_cand)), "kf_raycast_volume_slab_rays")
+                                                  C.c_void_p(dev_t), C.c_void_p(dev_t_copy), C.c_void_p(dev_cand)), "kf_raycast_volume_slab_rays")
 
     def slab_mask_rays(self, dev_t, dev_tmin, dev_cand):
         _chk(self.lib.kf_slab_mask_rays(self.h, C.c_void_p(dev_t), C.c_void_p(dev_tmin), C.c_void_p(dev_cand)), "kf_slab_mask_rays")

@@ -177,9 +177,11 @@ class SlabExchange:
         self.cand = torch.empty((rows, cols, 4), dtype=torch.float32, device=device)
         self.cand_bits = self.cand.view(torch.int32)
 
-    def merge(self, overlap=None):
+    def merge(self, overlap=None, tmin_ready=False):
+        """tmin_ready: the caller has filled self.tmin with a copy of self.t already (the raycast launch writes both)."""
         dist = self.dist
-        self.tmin.copy_(self.t)
+        if not tmin_ready:
+            self.tmin.copy_(self.t)
         pending = dist.all_reduce(self.tmin, op=dist.ReduceOp.MIN, async_op=True)
         if overlap is not None:
             overlap()             # runs while the collective is in flight (RCCL's own stream until wait() joins it)
@@ -264,16 +266,16 @@ class SlabPipeline:
         else:
             c.icp_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
         c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist)
-        c.raycast_slab_rays(None, self.inc, P["depth_trunc_min"], self.trunc_max, ex.t.data_ptr(), ex.cand.data_ptr())
+        c.raycast_slab_rays(None, self.inc, P["depth_trunc_min"], self.trunc_max, ex.t.data_ptr(), ex.cand.data_ptr(), ex.tmin.data_ptr())
 
         if self._merge_events is not None:
             e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
             e0.record(self.stream)
-            ex.merge()
+            ex.merge(tmin_ready=True)
             e1.record(self.stream)
             self._merge_events.append((e0, e1))
         else:
-            ex.merge()
+            ex.merge(tmin_ready=True)
 
     def time_merge(self, on=True):
         """Measurement legs only: time every frame's merge (both all-reduces, mask, unpack)

@@ -184,7 +184,8 @@ int kf_set_model_maps_device(kf_ctx* ctx, const float* dev_v, const float* dev_n
  * integer SUM all-reduce of dev_cand, kf_set_model_maps_rays (same transform / camera as the raycast) rebuilds the vertices and
  * writes the model maps */
 int kf_raycast_volume_slab_rays(kf_ctx* ctx, int has_color, const kf_mat44* transform, const kf_raycast_params* raycast_params,
-                                const kf_camera_params* depth_camera, float near_plane, float far_plane, float* dev_t, float* dev_cand);
+                                const kf_camera_params* depth_camera, float near_plane, float far_plane, float* dev_t, float* dev_t_copy,
+                                float* dev_cand);       /* dev_t_copy (may be null): a second copy of dev_t, for the in-place MIN all-reduce */
 int kf_slab_mask_rays(kf_ctx* ctx, const float* dev_t, const float* dev_tmin, float* dev_cand);
 int kf_set_model_maps_rays(kf_ctx* ctx, const kf_mat44* transform, const kf_camera_params* depth_camera, const float* dev_cand);
 
