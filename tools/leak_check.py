@@ -32,6 +32,7 @@ def full(c):
         c.raycast(None, 0.04, P["depth_trunc_min"], P["depth_trunc_max"])
     c.track_result()
 print("+ three full frames: %.2f MB per cycle" % cycle(20, full))
+print("+ three full frames (again: one-time allocations of the runtime are behind us): %.2f MB per cycle" % cycle(40, full))
 def col(n):
     torch.cuda.synchronize(); f0, _ = torch.cuda.mem_get_info()
     for i in range(n):
