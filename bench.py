@@ -539,9 +539,10 @@ def main():
     barrier()
     s0 = pipe.stats()
     # Time the fusion kernel (bit 5) and the whole integrate stage (bit 3) inside the timed region with HIP events on the context's
-    # own stream.  Every `period`-th frame is sampled so that a short run still yields >= 10 timed launches (the event records
-    # cost ~3 us per pair: every frame timed takes ~5 % off `value`, every 2nd 2 %, every 8th nothing measurable).
-    timer_period = max(1, min(8, args.steps // 10))
+    # own stream.  Every `period`-th frame is sampled so that a short run still yields >= 5 timed launches (a timed launch costs
+    # ~6 us of stream time -- its dispatch carries two event packets: every 2nd frame timed takes 1.4 % off `value` at C2, every 4th
+    # 0.7 %, every 8th nothing measurable; the kernel's duration varies by < 2 % from launch to launch).
+    timer_period = max(1, min(8, args.steps // 5))
     # (every event pair costs ~3 us of stream time: at --steps 20 the kernel's pair alone is 0.9 % of the timed region, the stage's pair
     # another 1.4 % -- so when the per-stage times are measured anyway on the 50 frames AFTER the timed region (N=1 extras), the
     # integrate STAGE is taken from there and only the roofline kernel is timed inside the region)
@@ -582,7 +583,7 @@ def main():
         n_upd, kern_ms, launches, stage_ms = (int(every[roof_rank][0].item()), float(every[roof_rank][1].item()),
                                               int(every[roof_rank][2].item()), float(every[roof_rank][3].item()))
     alg_bytes = (n_upd / max(args.steps, 1)) * 16.0 + cam[0] * cam[1] * 4.0       # N_upd x 2 x 8 B + depth map
-    if launches >= 10 and kern_ms > 0:
+    if launches >= 5 and kern_ms > 0:
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "integrate_traffic.json")
@@ -605,7 +606,7 @@ def main():
             roofline["traffic"], roofline["traffic_source"] = None, None
     else:
         roofline = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None, kernel="k_integrate_pairs",
-                        launches_timed=int(launches), refused="fewer than 10 timed launches of the kernel: run with --steps >= 10")
+                        launches_timed=int(launches), refused="fewer than 5 timed launches of the kernel: run with --steps >= 5")
 
     mesh = None
     if wl.get("extract_mesh"):
