@@ -316,7 +316,10 @@ enum { STEP_APPLIED = 0, STEP_LOST_DET = 1, STEP_LOST_SHAKE = 2, STEP_CONVERGED 
 // identical inputs -> identical outputs.  Returns STEP_* through *s_code (LDS).
 //   ICP: minimizePointToPlaneErrFunc (ICP.cpp:117-143) + loop body of estimateCameraPose (:71-82)
 //   SDF: loop body of CameraPoseFinderSDF::estimateCameraPose (SDF.cpp:62-101)
-__device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_tot, float* s_cur, int* s_code) {
+// s_next (ICP only, may be null): write the new transform THERE instead of over s_cur and return after ONE workgroup barrier -- the caller flips
+// between two buffers (the persistent loop: the copy back and its second barrier were 0.33 us of every Gauss-Newton step); the returned code
+// is the one *s_code would carry.
+__device__ __forceinline__ int apply_step(const TrackArgs& a, const float* s_tot, float* s_cur, int* s_code, float* s_next = nullptr) {
   if (!a.sdf) {
     // ICP: the determinant test (ICP.cpp:138) and the solve + increment (:143, :71-82) do not depend on each other, so two
     // lanes of DIFFERENT waves run them side by side and lane 0 keeps the solve's result only if the determinant passed.
@@ -373,7 +376,7 @@ __device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_to
         const float t0 = i == 0 ? T[0] : (i == 1 ? T[4] : T[8]), t1 = i == 0 ? T[1] : (i == 1 ? T[5] : T[9]);
         const float t2 = i == 0 ? T[2] : (i == 1 ? T[6] : T[10]), t3 = i == 0 ? T[3] : (i == 1 ? T[7] : T[11]);
         const float prod = t0 * s_cur[j] + t1 * s_cur[4 + j] + t2 * s_cur[8 + j] + t3 * s_cur[12 + j];
-        vs[threadIdx.x] = i < 3 ? prod : s_cur[12 + j];
+        (s_next ? s_next : vs)[threadIdx.x] = i < 3 ? prod : s_cur[12 + j];
       }
       if (threadIdx.x == 0) KF_SOLVE_STAMP(2);                               // rotation, shake test, T * cur
     }
@@ -383,12 +386,13 @@ __device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_to
       int code = STEP_APPLIED;                                             // every lane reads the two verdicts (LDS broadcast); sixteen lanes copy
       if (scratch[17] != 0.f) code = STEP_LOST_DET;
       else if (scratch[16] != 0.f) code = STEP_LOST_SHAKE;
+      if (s_next) return code;                                             // ping-pong form: every lane holds the verdict, the transform lies in s_next
       if (code == STEP_APPLIED && threadIdx.x < 16) s_cur[threadIdx.x] = scratch[threadIdx.x];
       if (threadIdx.x == 0) *s_code = code;
     }
     __syncthreads();
     if (threadIdx.x == 0) KF_SOLVE_STAMP(4);                                 // verdict + copy + barrier
-    return;
+    return *s_code;
   }
   if (threadIdx.x == 0) {
     float A[36], b[6], x[6], T[16], ncur[16];
@@ -404,6 +408,7 @@ __device__ __forceinline__ void apply_step(const TrackArgs& a, const float* s_to
     *s_code = code;
   }
   __syncthreads();
+  return *s_code;
 }
 
 // Common prologue of a step launch: load the running transform, fold + apply the previous step if asked.
@@ -701,9 +706,11 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     else kf_bilateral_tile<4, false>(L.bil, tt % L.bil_gx, tt / L.bil_gx, (int)(threadIdx.x & 255), tile);
     return;
   }
-  __shared__ float s_cur[16], s_linv[16];
+  __shared__ float s_pose[2][16], s_linv[16];                                  // the running transform lives in one of two buffers: a step writes the other one
   __shared__ float s_wave[27 * (ICP_THREADS / 16)], s_tot[(ICP_THREADS / 32) * 32];
-  __shared__ int s_code, s_abort;
+  __shared__ int s_abort;
+  int s_code = STEP_APPLIED, cur_buf = 0;
+  float* s_cur = s_pose[0];
   KfTrackState* st = L.track;
   if (threadIdx.x < 16) s_cur[threadIdx.x] = st->pose[threadIdx.x];            // ICP.cpp:62 cur_transform = _pose
   if (threadIdx.x == 0) s_abort = 0;
@@ -755,8 +762,8 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
 #ifdef KF_EXPERIMENTS
         if (KF_EXP_MODE(L) == 8 && threadIdx.x == 0) L.slots[(size_t)24 * KF_ICP_LOOP_MAX_WG * 32 + (size_t)(step - 1) * 1024 + blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
-        if (KF_EXP_MODE(L) == 1) { if (threadIdx.x == 0) s_code = STEP_APPLIED; __syncthreads(); } else     // timing only: skip the 6x6 solve
-        apply_step(a, s_tot, s_cur, &s_code);
+        if (KF_EXP_MODE(L) == 1) { s_code = STEP_APPLIED; __syncthreads(); } else     // timing only: skip the 6x6 solve
+        { s_code = apply_step(a, s_tot, s_cur, nullptr, s_pose[cur_buf ^ 1]); if (s_code == STEP_APPLIED) { cur_buf ^= 1; s_cur = s_pose[cur_buf]; } }
         if (s_code != STEP_APPLIED) {                                            // same verdict in every workgroup
           if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; }
           return;
@@ -797,7 +804,8 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   // the last step's system, then commit _pose (ICP.cpp:84)
   fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort);
   if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; __hip_atomic_store(L.stall_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } return; }
-  apply_step(a, s_tot, s_cur, &s_code);
+  s_code = apply_step(a, s_tot, s_cur, nullptr, s_pose[cur_buf ^ 1]);
+  if (s_code == STEP_APPLIED) { cur_buf ^= 1; s_cur = s_pose[cur_buf]; }
   if (blockIdx.x != 0) return;
   if (threadIdx.x < 27 && KF_EXP_MODE(L) != 7) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
   if (s_code != STEP_APPLIED) { if (threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; } return; }
