@@ -2,7 +2,7 @@
 # usage: tools/asm_memops.sh <file.hip> <mangled-kernel-substring> ["extra flags"]: device assembly of one kernel reduced to its memory
 # operations, waits and readfirstlanes (are the loads of an iteration in flight together, or does each one get its own wait?)
 cd "$(dirname "$0")/.."
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -Wno-unused-value -Iinclude $3 -S --cuda-device-only -o /tmp/asm_memops.s hybkinectfu_amd/csrc/$1 || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -std=c++17 -Wno-unused-value -Iinclude $3 -S --cuda-device-only -o /tmp/asm_memops.s hybkinectfu_amd/csrc/$1 || exit 1
 python3 - "$2" <<'PY'
 import re, sys
 txt = open('/tmp/asm_memops.s').read()
