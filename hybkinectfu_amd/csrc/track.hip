@@ -647,18 +647,24 @@ __device__ __forceinline__ void fold_partials_tagged(const unsigned long long* s
 #ifndef KF_ICP_POLL_DEPTH
 #define KF_ICP_POLL_DEPTH 2
 #endif
+      // the batch's addresses are fixed before the loop and a lane without a publisher for slot j polls its own FIRST word once more
+      // (not one shared word: 170 of a coarse level's 208 slots are of this kind and would all hammer one publisher's line; the value is dropped below): no branch around a load, no exec-mask juggling per slot --
+      // the poll iteration was 265 instructions, i.e. the loop noticed a publication up to 0.4 us late
       unsigned long long u[KF_ICP_POLL_DEPTH][ICP_FOLD_BATCH];
+      const unsigned long long* src[ICP_FOLD_BATCH];
+#pragma unroll
+      for (int j = 0; j < ICP_FOLD_BATCH; ++j) { const int w = w0 + j * parts; src[j] = slots + (size_t)((w < n_wg ? w : w0) * 32 + k); }
 #pragma unroll
       for (int d = 0; d < KF_ICP_POLL_DEPTH; ++d) {
         if (d) __builtin_amdgcn_s_sleep(KF_ICP_POLL_PIPE);
 #pragma unroll
-        for (int j = 0; j < ICP_FOLD_BATCH; ++j) { const int w = w0 + j * parts; u[d][j] = (w < n_wg) ? __hip_atomic_load(&slots[w * 32 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32); }
+        for (int j = 0; j < ICP_FOLD_BATCH; ++j) u[d][j] = __hip_atomic_load(src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       for (;;) {
-        bool ok = true;
+        unsigned stale = 0u;
 #pragma unroll
-        for (int j = 0; j < ICP_FOLD_BATCH; ++j) ok = ok && (unsigned)(u[0][j] >> 32) == tag;
-        if (ok) break;
+        for (int j = 0; j < ICP_FOLD_BATCH; ++j) stale |= (unsigned)(u[0][j] >> 32) ^ tag;
+        if (stale == 0u) break;
         if (++spins > ICP_SPIN_LIMIT) { *s_abort = 1; break; }
 #pragma unroll
         for (int d = 0; d + 1 < KF_ICP_POLL_DEPTH; ++d)
@@ -666,7 +672,7 @@ __device__ __forceinline__ void fold_partials_tagged(const unsigned long long* s
           for (int j = 0; j < ICP_FOLD_BATCH; ++j) u[d][j] = u[d + 1][j];
         __builtin_amdgcn_s_sleep(KF_ICP_POLL_PIPE);
 #pragma unroll
-        for (int j = 0; j < ICP_FOLD_BATCH; ++j) { const int w = w0 + j * parts; u[KF_ICP_POLL_DEPTH - 1][j] = (w < n_wg) ? __hip_atomic_load(&slots[w * 32 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32); }
+        for (int j = 0; j < ICP_FOLD_BATCH; ++j) u[KF_ICP_POLL_DEPTH - 1][j] = __hip_atomic_load(src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
 #pragma unroll
       for (int j = 0; j < ICP_FOLD_BATCH; ++j) v[j] = (w0 + j * parts < n_wg) ? __uint_as_float((unsigned)u[0][j]) : 0.f;
