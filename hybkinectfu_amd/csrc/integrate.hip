@@ -781,20 +781,25 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
     if (a.sat_cull) hipLaunchKernelGGL(k_integrate_cull<true>, dim3((n_macro + CULL_WAVES - 1) / CULL_WAVES), dim3(CULL_WAVES * 64), 0, c->stream, a);
     else hipLaunchKernelGGL(k_integrate_cull<false>, dim3((n_macro + CULL_WAVES - 1) / CULL_WAVES), dim3(CULL_WAVES * 64), 0, c->stream, a);
   }
-  // Workgroups walking the queue.  Large volumes (>= 2^20 stored bricks: the queue holds >~100k bricks): 8192 workgroups with four bricks in
-  // flight each.  Smaller ones: ONE brick in flight and exactly as many workgroups as the chip holds at once (8 per CU) -- at 512^3 the queue
+  // Workgroups walking the queue.  Large volumes (>= 2^20 stored bricks: the queue holds >~100k bricks): four bricks in flight per workgroup and
+  // EIGHT TIMES as many workgroups as the chip holds at once (6 per CU x 256 = 1536 -> 12288: whole rounds; 8192 = 5.33 rounds ended on a third
+  // of the chip: 305.6 -> 297 us at 1024^3, every multiple of 1536 from 7680 to 15360 within 1 % of that).  Smaller ones: ONE brick in flight and exactly as many workgroups as the chip holds at once (8 per CU) -- at 512^3 the queue
   // is ~9 k bricks, i.e. 2.2 rounds of 4.5 k two-brick workgroups of which the last is a fifth full; 2048 resident workgroups that each walk
   // 4-5 bricks with the look-ahead end together: 20.0 -> 18.5 us at 512^3, 11.8 -> 9.6 us at 256^3, one box (at 1024^3 the same form loses: 324 vs
   // 304 us).  KF_INTEGRATE_GRID / KF_INTEGRATE_BR override.
-  static unsigned grid_env = 0, resident = 0;
+  static unsigned grid_env = 0, resident = 0, resident4 = 0;
   if (!grid_env) { const char* e = getenv("KF_INTEGRATE_GRID"); grid_env = e ? (unsigned)atoi(e) : 1u; if (grid_env != 1u && (grid_env < 64u || grid_env > 65536u)) grid_env = 1u; }
   if (!resident) {
     int per_cu = 0; hipDeviceProp_t prop;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_integrate_pairs<1, false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 8;
-    resident = (hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0) ? (unsigned)(prop.multiProcessorCount * per_cu) : 2048u;
+    const unsigned cus = (hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0) ? (unsigned)prop.multiProcessorCount : 256u;
+    resident = cus * (unsigned)per_cu;
+    int per_cu4 = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, k_integrate_pairs<4, false>, 256, 0) != hipSuccess || per_cu4 < 1) per_cu4 = 6;
+    resident4 = cus * (unsigned)per_cu4;
   }
   const bool big = c->n_stored_bricks >= ((size_t)1 << 20);
-  const unsigned grid_cap = grid_env != 1u ? grid_env : (big || has_color ? 8192u : resident);
+  const unsigned grid_cap = grid_env != 1u ? grid_env : (big && !has_color ? 8u * resident4 : (has_color ? 8192u : resident));
   unsigned grid = (unsigned)(c->n_stored_bricks < grid_cap ? c->n_stored_bricks : grid_cap);
   // the roofline kernel's live timer: the event pair rides on the dispatch itself (kf_evt_attach), so what is measured is the kernel, as rocprofv3 sees it
   hipEvent_t ke0 = nullptr, ke1 = nullptr;
