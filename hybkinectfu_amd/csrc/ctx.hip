@@ -110,7 +110,7 @@ extern "C" int kf_destroy(kf_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->own_stream) hipStreamSynchronize(c->own_stream);
   void* ptrs[] = {c->up_dev[0], c->up_dev[1], c->raw_depth, c->trunced_depth, c->filtered_depth, c->raw_rgb, c->raycast_rgb, c->icp_partials, c->icp_loop_slots,
-                  c->track, c->counters, c->grid_barrier, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macrobits, c->vol.negbits, c->active_bricks,
+                  c->track, c->counters, c->grid_barrier, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macrobits, c->vol.negbits, c->vol.pend, c->active_bricks,
                   c->tile_max_depth, c->triangles, c->mc_block_counts, c->mc_list, c->mc_nbr_bits, c->mc_partials, c->mc_codes, c->mc_surv, c->mc_block_bits, c->mc_recs, c->mc_d1_list};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->up_stream) { hipStreamSynchronize(c->up_stream); hipStreamDestroy(c->up_stream); }
@@ -163,7 +163,7 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
 #define TRY(x) do { st = (x); if (st) { kf_destroy(c); return st; } } while (0)
   TRY((int)hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   const size_t npx = (size_t)c->cols * c->rows;
-  c->pending_slot = -1;
+  c->pending_slot = -1; c->defer_override = -1;
   TRY(dev_alloc(&c->raw_depth, npx)); TRY(dev_alloc(&c->trunced_depth, npx)); TRY(dev_alloc(&c->filtered_depth, npx));
   const size_t nrgb = (size_t)cfg->rgb_camera.cols * cfg->rgb_camera.rows;
   if (cfg->has_color) { TRY(dev_alloc(&c->raw_rgb, nrgb ? nrgb : npx)); TRY(dev_alloc(&c->raycast_rgb, npx)); }
@@ -205,6 +205,7 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
   v.macro_words = kf_bit_words((size_t)v.nm * v.nm * v.nm); v.super_words = kf_bit_words((size_t)v.ns * v.ns * v.ns);
   TRY(dev_alloc(&v.macrobits, (size_t)(v.macro_words + v.super_words)));
   TRY(dev_alloc(&v.negbits, kf_negbit_words(c->n_stored_bricks)));
+  TRY(dev_alloc(&v.pend, c->n_stored_bricks));
   TRY(dev_alloc(&c->active_bricks, c->n_stored_bricks + 8));       // + 16 aligned spare bytes behind the queue (integrate.hip: queue_pad; +8 words keeps them aligned for any count)
   {                                                          // tile maxima over 8- and 16-pixel tiles, see integrate.hip
     size_t n = 0;
@@ -236,8 +237,9 @@ extern "C" int kf_reset_volume(kf_ctx* c) {
   KF_CHECK(hipMemsetAsync(c->vol.flags, 0, c->n_stored_bricks, c->stream));
   KF_CHECK(hipMemsetAsync(c->vol.macrobits, 0, (size_t)(c->vol.macro_words + c->vol.super_words) * sizeof(unsigned), c->stream));
   KF_CHECK(hipMemsetAsync(c->vol.negbits, 0, kf_negbit_words(c->n_stored_bricks) * sizeof(unsigned), c->stream));
+  KF_CHECK(hipMemsetAsync(c->vol.pend, 0, c->n_stored_bricks * sizeof(unsigned long long), c->stream));
   KF_CHECK(hipMemsetAsync(c->counters, 0, sizeof(KfCounters), c->stream));
-  ++c->vol_flags_serial; c->fuse_calls = 0;
+  ++c->vol_flags_serial; c->pend_live = 0;
   return 0;
 }
 
@@ -412,7 +414,9 @@ __global__ void __launch_bounds__(256) k_volume_export(KfVolume v, int z_begin, 
     int x = (int)(i % v.res), y = (int)((i / v.res) % v.res), z = z_begin + (int)(i / ((size_t)v.res * v.res));
     size_t idx = kf_vox_index(v, x, y, z);
     float2 q = v.tw[idx];
-    tsdf[i] = q.x; weight[i] = q.y;
+    // a quarter brick in a deferred state: the pending whole-quarter free-space steps belong to the weight (kf_internal.h, KF_PEND_SAT)
+    const unsigned pq = reinterpret_cast<const unsigned short*>(v.pend)[(idx >> 9) * 4u + ((idx >> 7) & 3u)];
+    tsdf[i] = q.x; weight[i] = kf_pend_weight(q.y, pq, v.max_weight);
     if (color && v.color) { uchar4 cc = v.color[idx]; color[3 * i] = cc.x; color[3 * i + 1] = cc.y; color[3 * i + 2] = cc.z; }
   }
 }
@@ -489,7 +493,10 @@ extern "C" int kf_download_volume(kf_ctx* c, uint32_t z0, uint32_t z1, float* ts
 extern "C" int kf_upload_volume(kf_ctx* c, uint32_t z0, uint32_t z1, const float* tsdf, const float* weight, const uint8_t* color) {
   if (!c || !tsdf || !weight) return KF_ERR_ARG;
   if (z0 >= z1 || (int)z0 < c->vol.bz0 * KF_BRICK || (int)z1 > c->vol.bz1 * KF_BRICK) return KF_ERR_ARG;       // volume_xfer's own checks, before any bookkeeping moves
-  ++c->vol_flags_serial; c->fuse_calls = 0;                // the upload rebuilds the brick flags: some may be cleared
+  ++c->vol_flags_serial;                                   // the upload rebuilds the brick flags: some may be cleared
+  // pending weight steps are applied first (the upload may cover part of a quarter brick), then every deferred-weight word is dropped
+  { const int fs = kf_flush_pending(c); if (fs) return fs; }
+  KF_CHECK(hipMemsetAsync(c->vol.pend, 0, c->n_stored_bricks * sizeof(unsigned long long), c->stream)); c->pend_live = 0;
   return volume_xfer(c, z0, z1, (float*)tsdf, (float*)weight, (uint8_t*)color, false);
 }
 

@@ -38,7 +38,8 @@ struct IntegrateArgs {
   int exp_mode;                  // timing experiments only (KF_INTEGRATE_EXP): 1 = no store, 2 = no load/store
   int parity;                    // which of the double-buffered counter sets (KfCounters) this call uses
   int clear_tiles, n_tile_floats;   // the fusion pass clears the tile tables (maxima to 0, minima to +inf) once the cull has read them
-  int sat_cull;                  // the saturation bits are in use (k_integrate_pairs<.., SAT>): the cull may retire whole saturated bricks
+  int defer_cull;                // deferred-weight words are in use (k_integrate_pairs<.., DEFER>) and the tile minima describe this depth map: the cull may
+                                 // retire whole free-space bricks (counted, their pending counts bumped, never queued)
   int free_ok;                   // sdf_trunc > 0 (and the shortcut not disabled): free-space waves skip the quotients (k_integrate_pairs)
 };
 
@@ -126,10 +127,18 @@ __device__ __forceinline__ bool cull_sphere_visible(const IntegrateArgs& a, cons
   return true;
 }
 
+// one more whole-quarter free-space observation of a quarter in a deferred state p >= 1 (k = p - 1 pending): p + 1, or KF_PEND_SAT once
+// k + 1 >= max_weight - 1 -- every stored weight is >= 1, so every true weight fminf(w + k + 1, max) has then reached max_weight
+__device__ __forceinline__ unsigned kf_pend_step(unsigned p, float max_weight) {
+  if (p >= KF_PEND_SAT) return KF_PEND_SAT;
+  const unsigned n = p + 1u;
+  return ((float)n >= max_weight || n >= KF_PEND_SAT) ? KF_PEND_SAT : n;
+}
+
 #define CULL_WAVES 16
-// SAT: the saturation bits are in use -> whole saturated free-space bricks can be retired here (see below); a separate instantiation
-// because the extra test costs registers the plain cull needs for two workgroups per CU
-template <bool SAT>
+// DEFER: the deferred-weight words are in use -> whole free-space bricks in a deferred state can be retired here (see below); a separate
+// instantiation because the extra test costs registers the plain cull needs for two workgroups per CU
+template <bool DEFER>
 __global__ void __launch_bounds__(CULL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) k_integrate_cull(IntegrateArgs a) {
   if (a.track && !a.track->tracked) {                        // HybKinectfu.cpp:123: integrate only when tracking succeeded
     if (blockIdx.x == 0 && threadIdx.x == 0) a.cnt->frames_lost += 1;
@@ -203,21 +212,28 @@ __global__ void __launch_bounds__(CULL_WAVES * 64) __attribute__((amdgpu_waves_p
           for (int i = 0; i < 4; ++i) dmax = fmaxf(dmax, tbl[min(ty0 + j, ty1) * tw + min(tx0 + i, tx1)]);
         if (dmax == 0.f) keep = false;                                     // no pixel under the brick can integrate
         else if (zn >= dmax + a.sdf_trunc) keep = false;                   // every voxel lies behind every surface it can see
-        else if (SAT && all_inside) {
-          // Saturated free space seen as free space again: all four saturation bits of the brick are set (its 512 voxels are
-          // exactly (tsdf 1, weight max_weight)), every voxel projects inside the image window, every pixel it can land on holds a
-          // depth that integrates (tile minimum > 0 means: all valid, all < max_dist) and that depth is at least one truncation
-          // distance behind the brick's far side -> every voxel passes the reference's predicate (:39-67), observes tsdf
-          // min(1, sdf / trunc) = 1, and (1 * w + 1) / (w + 1) = 1, min(w + 1, max) = w leave it as it is.  Nothing to do but count.
-          const unsigned f = v.flags[kf_brick_slot(v, bx, by, bz)];
-          if ((f & (15u * KF_FLAG_SAT0)) == 15u * KF_FLAG_SAT0) {
+        else if (DEFER && all_inside) {
+          // Free space in a deferred state seen as free space again: all four quarters of the brick carry a deferred-weight word (its 512
+          // voxels hold tsdf 1 and a weight >= 1), every voxel projects inside the image window, every pixel it can land on holds a depth that
+          // integrates (tile minimum > 0 means: all valid, all < max_dist) and that depth is at least one truncation distance behind the
+          // brick's far side -> every voxel passes the reference's predicate (:39-67), observes tsdf min(1, sdf / trunc) = 1, and
+          // (1 * w + 1) / (w + 1) = 1 leaves the tsdf as it is; the weight's min(w + 1, max) is one more pending step of each quarter
+          // (nothing at all once a quarter is saturated).  The brick is counted, not queued: no other wave touches it in this frame.
+          const unsigned slot = kf_brick_slot(v, bx, by, bz);
+          const unsigned long long pp = v.pend[slot];
+          const unsigned q0 = (unsigned)(pp & 0xFFFFull), q1 = (unsigned)((pp >> 16) & 0xFFFFull), q2 = (unsigned)((pp >> 32) & 0xFFFFull), q3 = (unsigned)(pp >> 48);
+          if (q0 && q1 && q2 && q3) {
             const float* tmn = tbl + a.n_tile_floats;
             float dmin = __builtin_huge_valf();
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
               for (int i = 0; i < 4; ++i) dmin = fminf(dmin, tmn[min(ty0 + j, ty1) * tw + min(tx0 + i, tx1)]);
-            if (dmin > 0.f && dmin - zf >= a.sdf_trunc + eps) { keep = false; noop = true; }
+            if (dmin > 0.f && dmin - zf >= a.sdf_trunc + eps) {
+              keep = false; noop = true;
+              if (pp != ~0ull) v.pend[slot] = (unsigned long long)kf_pend_step(q0, v.max_weight) | ((unsigned long long)kf_pend_step(q1, v.max_weight) << 16) |
+                                              ((unsigned long long)kf_pend_step(q2, v.max_weight) << 32) | ((unsigned long long)kf_pend_step(q3, v.max_weight) << 48);
+            }
           }
         }
       }                                                                    // larger footprints (bricks close to the eye) are kept
@@ -226,7 +242,7 @@ __global__ void __launch_bounds__(CULL_WAVES * 64) __attribute__((amdgpu_waves_p
   // compaction: ONE atomic per 16 macro cells (an address takes ~11 ns per atomic; per-wave atomics made this pass
   // cost more than the fusion itself at 1024^3)
   const unsigned long long mask = __ballot(keep);
-  const unsigned n_noop = SAT ? (unsigned)__popcll(__ballot(noop)) : 0u;
+  const unsigned n_noop = DEFER ? (unsigned)__popcll(__ballot(noop)) : 0u;
   if (lane == 0) { s_cnt[wid] = (unsigned)__popcll(mask); s_noop[wid] = n_noop; }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -362,10 +378,8 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(IntegrateArgs a) {
           atomicOr(&v.negbits[slot[b] >> 5], 1u << (slot[b] & 31u));
         }
       }
-      // this kernel does not keep the saturation bits of k_integrate_pairs<.., true> current: a wave that writes drops its quarter's bit
-      const unsigned satbit = KF_FLAG_SAT0 << (threadIdx.x >> 6);
-      if ((fold[b] & satbit) && __ballot(flags & KF_FLAG_OBSERVED) && (threadIdx.x & 63) == 0)
-        atomicAnd(reinterpret_cast<unsigned*>(v.flags) + (slot[b] >> 2), ~(satbit << (8u * (slot[b] & 3u))));
+      // (this kernel knows nothing of the deferred-weight words of k_integrate_pairs<.., DEFER>: kf_integrate_volume flushes them before it
+      // runs and clears them behind it)
     }
   }
   // N_upd: wave sum -> LDS -> ONE atomic per workgroup, spread over 64 counter lines
@@ -433,20 +447,26 @@ __device__ __forceinline__ uint2 integrate_color_update2(uint2 oc, unsigned col0
   return make_uint2(u0 ? w0 : oc.x, u1 ? w1 : oc.y);
 }
 
-// SAT (used once max_weight frames have been fused since the last reset / upload -- before that no voxel can be saturated): free
-// space the camera keeps looking through ends up as (tsdf 1, weight max_weight), and one more free-space observation of such a voxel
-// is the identity bit for bit: (1 * w + 1) / (w + 1) == 1, min(w + 1, max) == w.  A per-brick flag bit per wave (KF_FLAG_SAT0 << wave)
-// says "these 128 voxels are all in that state"; a wave whose updating voxels all observe tsdf 1 again then neither reads nor writes
-// them -- it only counts them.  The bit is set by a wave that updated (hence read) all its 128 voxels and left nothing else behind,
-// and cleared by any wave that writes something else.  After 128 frames of the benchmark stream about half (512^3) to three quarters
-// (1024^3) of the waves that would touch memory are of this kind (tools/exp_noop_waves.py).
+// DEFER (the default without colour): free space the camera keeps looking through is observed as tsdf 1 frame after frame, and for a voxel
+// that already holds tsdf 1 the update of tsdfVolume.h:65-66 is (1 * w + 1) / (w + 1) = 1 exactly and w' = min(w + 1, max_weight) -- only the
+// weight moves, by one, for every voxel alike.  A 16-bit word per quarter brick (KfVolume::pend, kf_internal.h: the 128 voxels one wave owns)
+// says "all 128 hold tsdf 1 and a weight >= 1, and k whole-quarter free-space observations are pending"; a wave whose 128 voxels ALL pass
+// the predicate and ALL lie in front of the truncation band then neither reads nor writes them -- it bumps k (KF_PEND_SAT once every weight
+// must have reached max_weight: from then on ANY free-space wave over the quarter is the identity and is only counted).  Whoever has to
+// write into such a quarter (a surface band entering it, a partial wave at the frustum's edge or around a depth hole) first applies the
+// pending count to all 128 voxels: w <- fminf(w + k, max_weight), which equals k applications of min(w + 1, max) on these small integers bit
+// for bit.  The word is (re)established by a wave that knows all 128 voxels and leaves nothing but (tsdf 1, weight >= 1) behind.  Readers of
+// the volume (raycast, marching cubes, SDF tracker) look at tsdf and at weight != 0 only -- a deferred quarter's stored weights are >= 1 --
+// and kf_download_volume applies the pending count on the fly.  From the second frame of a stream on, two thirds (512^3) to three quarters
+// (1024^3) of the waves that would touch memory are of this kind.
 // COLOR (the reference's use_color, optionally color_angle_weight: its stock switches): the colour plane rides along -- the voxel's colour
 // projection (integrateVolume.cu:56-63) joins the update predicate, the pair's two colour words are one more 8-byte read-modify-write,
 // the running average of tsdfVolume.h:68-70 keeps the reference's double-precision weight expression and its IEEE quotients.  Colour
-// changes even where (tsdf, weight) no longer do, so COLOR excludes SAT; a wave that writes drops its quarter's saturation bit.
-template <int BR, bool SAT, bool COLOR = false>
+// changes even where (tsdf, weight) no longer do and blends with the weight, so COLOR excludes DEFER (pending counts are flushed before a
+// colour frame and the words cleared behind it: kf_integrate_volume).
+template <int BR, bool DEFER, bool COLOR = false>
 __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
-  static_assert(!(SAT && COLOR), "colour changes where (tsdf, weight) are saturated: no skipping");
+  static_assert(!(DEFER && COLOR), "colour changes where (tsdf, weight) do not, and blends with the weight: no deferral");
   const KfVolume& v = a.vol;
   const unsigned n_active = a.cnt->n_active[a.parity] >> ((KF_EXP_MODE(a) == 8 || KF_EXP_MODE(a) == 9) ? KF_EXP_MODE(a) - 7 : 0);     // exp_mode 8 / 9: half / quarter of the queue (timing only)
   if (blockIdx.x == 0) integrate_maintenance(a);
@@ -457,8 +477,9 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   const KfRecip rt = kf_recip(a.sdf_trunc);
   KfRecip2 rtrunc; rtrunc.den = f2_splat(rt.den); rtrunc.r = f2_splat(rt.r);
   const unsigned xlim = (unsigned)(a.dcam.cols - 2), ylim = (unsigned)(a.dcam.rows - 2);
-  const unsigned satbit = KF_FLAG_SAT0 << (threadIdx.x >> 6);           // this wave's quarter of the brick (z layers 2w, 2w + 1)
+  const unsigned quarter = threadIdx.x >> 6;                            // this wave's quarter of the brick (z layers 2w, 2w + 1)
   const unsigned sat_w = __float_as_uint(v.max_weight), one_f = __float_as_uint(1.0f);
+  unsigned short* const pend16 = reinterpret_cast<unsigned short*>(v.pend);      // quarter q of brick slot s: pend16[4 s + q]
   const KfRecip2 r075 = kf_recip2(f2_splat(0.75f));                     // COLOR: the angle weight's |nz| / 0.75
   __shared__ unsigned s_upd;
   unsigned upd_total = 0;
@@ -481,7 +502,7 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   for (int b = 0; b < BR; ++b) { const unsigned i = kf_opaque(blockIdx.x * BR + b); ahead[b] = a.queue[i < a.queue_cap ? i : 0u]; }
 #endif
   for (unsigned q0 = blockIdx.x * BR; q0 < n_active; q0 += gridDim.x * BR) {
-    unsigned slot[BR], fold[BR]; int bx[BR], by[BR], bz[BR];
+    unsigned slot[BR], fold[BR], ent[BR];                        // ent: the packed brick coordinates (decoded where needed: scalar registers are scarce here)
     kf_f2 pfz[BR], d[BR]; int pix0[BR], pix1[BR]; bool ok0[BR], ok1[BR];
     int cpix0[BR], cpix1[BR]; bool okc0[BR], okc1[BR];          // COLOR: the voxels' pixels in the colour image, and whether they lie inside its window
 #ifndef KF_INT_NO_QPREFETCH
@@ -494,8 +515,8 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
       for (int b = 0; b < BR; ++b) { const unsigned i = kf_opaque(qn + b); ahead[b] = (i < n_active) ? a.queue[i] : 0u; }
     }
 #endif
-    // the bricks' flag bytes (the atomics below are only issued when a bit is new; SAT reads the saturation bits): requested together
-    unsigned fold_v[BR];
+    // the bricks' flag bytes (the atomics below are only issued when a bit is new) and, DEFER, the quarter's deferred-weight word: requested together
+    unsigned fold_v[BR], pend_v[BR];
 #pragma unroll
     for (int b = 0; b < BR; ++b) {
 #ifndef KF_INT_NO_QPREFETCH
@@ -505,6 +526,7 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
 #endif
       const unsigned sl = ((packed >> 20) * (unsigned)v.nb + ((packed >> 10) & 1023u)) * (unsigned)v.nb + (packed & 1023u);
       fold_v[b] = v.flags[kf_opaque(sl)];
+      pend_v[b] = DEFER ? (unsigned)pend16[kf_opaque(sl * 4u + quarter)] : 0u;
     }
     // Phase A: project both voxels (tsdfVolume.h:38-49 voxel centre; Mat.h:230-238 row * vector summed left to right)
 #pragma unroll
@@ -515,12 +537,13 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
 #else
       const unsigned packed = live ? a.queue[q0 + b] : 0u;
 #endif
-      bx[b] = (int)(packed & 1023u); by[b] = (int)((packed >> 10) & 1023u); bz[b] = (int)(packed >> 20) + v.bz0;
-      slot[b] = ((unsigned)(bz[b] - v.bz0) * (unsigned)v.nb + (unsigned)by[b]) * (unsigned)v.nb + (unsigned)bx[b];
-      const float x0 = (float)(bx[b] * 8 + lx);
+      ent[b] = packed;
+      const int bx = (int)(packed & 1023u), by = (int)((packed >> 10) & 1023u), bz = (int)(packed >> 20) + v.bz0;
+      slot[b] = ((unsigned)(bz - v.bz0) * (unsigned)v.nb + (unsigned)by) * (unsigned)v.nb + (unsigned)bx;
+      const float x0 = (float)(bx * 8 + lx);
       kf_f2 xi = {x0, x0 + 1.0f};                           // (float)(x + 1) == (float)x + 1 for these small integers
       const kf_f2 wx = (xi + f2_splat(0.5f)) * f2_splat(cell);
-      const float wy = ((float)(by[b] * 8 + ly) + 0.5f) * cell, wz = ((float)(bz[b] * 8 + lz) + 0.5f) * cell;
+      const float wy = ((float)(by * 8 + ly) + 0.5f) * cell, wz = ((float)(bz * 8 + lz) + 0.5f) * cell;
       const kf_f2 pfx = ((f2_splat(m0) * wx + f2_splat(m1 * wy)) + f2_splat(m2 * wz)) + f2_splat(m3 * 1.0f);
       const kf_f2 pfy = ((f2_splat(m4) * wx + f2_splat(m5 * wy)) + f2_splat(m6 * wz)) + f2_splat(m7 * 1.0f);
       pfz[b] = ((f2_splat(m8) * wx + f2_splat(m9 * wy)) + f2_splat(m10 * wz)) + f2_splat(m11 * 1.0f);
@@ -563,16 +586,42 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
     // Free space, decided per wave before the voxels are even requested: when no updating voxel of the wave lies inside the truncation
     // band (sdf >= trunc for all of them) every one observes tsdf = fminf(1, sdf / trunc) = 1 EXACTLY -- x >= t > 0 implies RN(x / t) >= 1
     // because rounding is monotone -- so the quotient is never formed (FREE; a non-positive or NaN truncation distance turns this off).
-    // SAT: a wave whose quarter is saturated free space and which observes free space again skips the memory side altogether.
-    bool free_wave[BR], skip[BR];
+    // DEFER: a free-space wave over a saturated quarter, or one that updates ALL 128 voxels of a quarter in a deferred state, skips the memory
+    // side altogether (skip); any other wave that updates something in a quarter with pending steps applies them to all 128 voxels (all_lanes).
+    bool free_wave[BR], skip[BR], all_lanes[BR]; unsigned pnd[BR];
 #pragma unroll
-    for (int b = 0; b < BR; ++b) fold[b] = (unsigned)__builtin_amdgcn_readfirstlane((int)fold_v[b]);
+    for (int b = 0; b < BR; ++b) { fold[b] = (unsigned)__builtin_amdgcn_readfirstlane((int)fold_v[b]); pnd[b] = DEFER ? (unsigned)__builtin_amdgcn_readfirstlane((int)pend_v[b]) : 0u; }
 #pragma unroll
     for (int b = 0; b < BR; ++b) {
       const bool band = (upd0[b] && sdf[b].x < a.sdf_trunc) || (upd1[b] && sdf[b].y < a.sdf_trunc);
-      free_wave[b] = a.free_ok && __ballot(band) == 0ull;
-      skip[b] = SAT && (fold[b] & satbit) != 0u && (a.free_ok ? free_wave[b] : __ballot(band) == 0ull && a.sdf_trunc > 0.f);
+      const bool no_band = __ballot(band) == 0ull;
+      free_wave[b] = a.free_ok && no_band;
+      skip[b] = false; all_lanes[b] = false;
+      if (DEFER) {
+        const bool free_exact = no_band && a.sdf_trunc > 0.f;                                  // (what free_wave says when the shortcut is not switched off)
+        const bool whole = __ballot(upd0[b] && upd1[b]) == ~0ull;                              // all 128 voxels of the quarter pass the predicate
+        skip[b] = free_exact && (pnd[b] == KF_PEND_SAT || (pnd[b] != 0u && whole));
+        all_lanes[b] = !skip[b] && pnd[b] >= 2u && __ballot(upd0[b] || upd1[b]) != 0ull;      // pending steps + a writer: the quarter is flushed
+      }
     }
+#ifdef KF_EXPERIMENTS
+    // what the fusion pass's waves do (tools/exp_wave_kinds.py); packed counts per word
+    if (KF_EXP_MODE(a) == 13) {
+#pragma unroll
+      for (int b = 0; b < BR; ++b) {
+        const bool live = q0 + b < n_active;
+        const bool any = __ballot(upd0[b] || upd1[b]) != 0ull, whole = __ballot(upd0[b] && upd1[b]) == ~0ull;
+        if (live && (threadIdx.x & 63) == 0) {
+          const unsigned sh = (blockIdx.x & 63) * 16;
+          if (skip[b]) atomicAdd(&a.cnt->rc_steps[sh], pnd[b] == KF_PEND_SAT ? 1ull : (1ull << 32));           // skipped: saturated | deferred
+          else if (!any) ;                                                                                       // nothing to update (= queued waves - the rest)
+          else if (all_lanes[b]) atomicAdd(&a.cnt->rc_hits[sh], 1ull);                                           // flush + write
+          else if (!free_wave[b]) atomicAdd(&a.cnt->rc_hits[sh], 1ull << 32);                                    // written: some voxel in the band
+          else atomicAdd(&a.cnt->mc_blocks[sh], whole ? 1ull : (1ull << 32));                                    // written: whole free space | partial free space
+        }
+      }
+    }
+#endif
     // one 16-byte read-modify-write per lane and brick, only where a voxel of the pair passed; the loads go out together
     float4* p[BR]; float4 q[BR]; bool rw[BR];
 #pragma unroll
@@ -582,7 +631,7 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
       // value is not used) -- with a conditional load the compiler parks a register copy, and with it a wait, behind EACH of the BR
       // loads, and they no longer travel together
       const bool touch = upd0[b] || upd1[b];
-      rw[b] = touch && !skip[b];
+      rw[b] = (touch || all_lanes[b]) && !skip[b];
       const float4* src = (rw[b] && KF_EXP_MODE(a) != 2) ? p[b] : reinterpret_cast<const float4*>(a.queue_pad);
       q[b] = *src;
     }
@@ -601,9 +650,15 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
     }
 #pragma unroll
     for (int b = 0; b < BR; ++b) {
-      if (SAT && skip[b]) { upd_total += (upd0[b] ? 1u : 0u) + (upd1[b] ? 1u : 0u); continue; }       // uniform: counted, nothing else to do
+      if (DEFER && skip[b]) {                                               // uniform: counted; one more pending step unless the quarter is saturated
+        upd_total += (upd0[b] ? 1u : 0u) + (upd1[b] ? 1u : 0u);
+        if (pnd[b] != KF_PEND_SAT && (threadIdx.x & 63) == 0) pend16[slot[b] * 4u + quarter] = (unsigned short)kf_pend_step(pnd[b], v.max_weight);
+        continue;
+      }
       // tsdfVolume.h:63-66 on both voxels; a voxel that failed the predicate keeps its stored value
-      const kf_f2 ot = {q[b].x, q[b].z}, ow = {q[b].y, q[b].w};
+      const kf_f2 ot = {q[b].x, q[b].z};
+      kf_f2 ow = {q[b].y, q[b].w};
+      if (DEFER && all_lanes[b]) { const float k = (float)(pnd[b] - 1u); ow.x = fminf(ow.x + k, v.max_weight); ow.y = fminf(ow.y + k, v.max_weight); }   // the quarter's pending steps, applied
       const kf_f2 ow1 = ow + f2_splat(1.f);
       // A free-space wave whose updating voxels all hold tsdf 1 already (weight any value in [0, 2^24]): (1 * w + 1) / (w + 1) has the
       // SAME rounded sum RN(w + 1) above and below the line (1 * w is exact), a finite non-zero number divided by itself: nt = 1
@@ -622,9 +677,11 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
       }
       const float nw0 = fminf(ow1.x, v.max_weight), nw1 = fminf(ow1.y, v.max_weight);
       unsigned flags = 0;
-      bool lane_sat = false;
+      // DEFER: what this lane knows of its two voxels afterwards.  A lane that loads nothing knows them through the quarter's word alone
+      // (p >= 1: tsdf 1, weight >= 1; whether saturated is not known)
+      bool lane_unit = DEFER && pnd[b] != 0u, lane_sat = false;
       if (rw[b]) {
-        float4 r = q[b];
+        float4 r = make_float4(ot.x, ow.x, ot.y, ow.y);                     // the stored pair (with the pending steps applied, if any)
         if (upd0[b]) { r.x = nt.x; r.y = nw0; }
         if (upd1[b]) { r.z = nt.y; r.w = nw1; }
         if (KF_EXP_MODE(a) == 0 || KF_EXP_MODE(a) >= 8 || r.x == 123.456f) *p[b] = r;     // experiments 1 / 2: no store
@@ -632,14 +689,17 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
           const kf_f2 nz = {nz0[b], nz1[b]};
           *pc[b] = integrate_color_update2(qc[b], rgb0[b], rgb1[b], ow, nz, upd0[b], upd1[b], a.color_angled, r075);
         }
+        if (DEFER) {
+          lane_unit = __float_as_uint(r.x) == one_f && __float_as_uint(r.z) == one_f && r.y >= 1.f && r.w >= 1.f;
+          lane_sat = lane_unit && __float_as_uint(r.y) == sat_w && __float_as_uint(r.w) == sat_w;
+        }
       }
       if (upd0[b] || upd1[b]) {
-        const float4 r = make_float4(upd0[b] ? nt.x : q[b].x, upd0[b] ? nw0 : q[b].y, upd1[b] ? nt.y : q[b].z, upd1[b] ? nw1 : q[b].w);
         upd_total += (upd0[b] ? 1u : 0u) + (upd1[b] ? 1u : 0u);
         flags = KF_FLAG_OBSERVED | (((upd0[b] && nt.x < 0.f) || (upd1[b] && nt.y < 0.f)) ? KF_FLAG_HASNEG : 0u);
-        if (SAT) lane_sat = __float_as_uint(r.x) == one_f && __float_as_uint(r.z) == one_f && __float_as_uint(r.y) == sat_w && __float_as_uint(r.w) == sat_w;
 #ifdef KF_EXPERIMENTS
         if (KF_EXP_MODE(a) == 10) {                                                        // how many waves write back exactly what they read?
+          const float4 r = make_float4(upd0[b] ? nt.x : q[b].x, upd0[b] ? nw0 : q[b].y, upd1[b] ? nt.y : q[b].z, upd1[b] ? nw1 : q[b].w);
           const bool same = __float_as_uint(r.x) == __float_as_uint(q[b].x) && __float_as_uint(r.y) == __float_as_uint(q[b].y) &&
                             __float_as_uint(r.z) == __float_as_uint(q[b].z) && __float_as_uint(r.w) == __float_as_uint(q[b].w);
           if (!same) flags |= 0x80u;
@@ -661,18 +721,16 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
       if (wflags && (threadIdx.x & 63) == 0) {
         atomicOr(reinterpret_cast<unsigned*>(v.flags) + (slot[b] >> 2), wflags << (8u * (slot[b] & 3u)));
         if (wflags & KF_FLAG_HASNEG) {
-          kf_mark_macro(v, bx[b], by[b], bz[b]);
+          kf_mark_macro(v, (int)(ent[b] & 1023u), (int)((ent[b] >> 10) & 1023u), (int)(ent[b] >> 20) + v.bz0);
           atomicOr(&v.negbits[slot[b] >> 5], 1u << (slot[b] & 31u));
         }
       }
-      if (COLOR && (fold[b] & satbit) && wrote && (threadIdx.x & 63) == 0)      // colour frames do not keep the saturation bits current: a wave that writes drops its quarter's
-        atomicAnd(reinterpret_cast<unsigned*>(v.flags) + (slot[b] >> 2), ~(satbit << (8u * (slot[b] & 3u))));
-      if (SAT && wrote) {                                                  // the quarter's saturation bit follows what this wave left behind
-        const bool now_sat = __ballot(lane_sat) == ~0ull, was_sat = (fold[b] & satbit) != 0u;      // all 64 lanes wrote: all 128 voxels known
-        if (now_sat != was_sat && (threadIdx.x & 63) == 0) {
-          unsigned* w = reinterpret_cast<unsigned*>(v.flags) + (slot[b] >> 2);
-          if (now_sat) atomicOr(w, satbit << (8u * (slot[b] & 3u))); else atomicAnd(w, ~(satbit << (8u * (slot[b] & 3u))));
-        }
+      if (DEFER && wrote) {
+        // the quarter's word follows what this wave left behind: all 128 voxels known (every lane loaded, or the word vouches for the rest)
+        // and nothing but (tsdf 1, weight >= 1) -> deferred with nothing pending (saturated when every weight is max_weight); else plain
+        const bool all_unit = __ballot(lane_unit) == ~0ull, all_sat = __ballot(lane_sat) == ~0ull;
+        const unsigned np = all_unit ? (all_sat ? KF_PEND_SAT : 1u) : 0u;
+        if (np != pnd[b] && (threadIdx.x & 63) == 0) pend16[slot[b] * 4u + quarter] = (unsigned short)np;
       }
     }
   }
@@ -720,11 +778,44 @@ static inline KfCam to_cam(const kf_camera_params* p) {
   KfCam c; c.cols = (int)p->cols; c.rows = (int)p->rows; c.cx = p->cx; c.cy = p->cy; c.fx = p->fx; c.fy = p->fy; return c;
 }
 
-// KF_INTEGRATE_SAT: 0 never, 2 from the first frame, default 1 = after max_weight fused frames
-bool kf_sat_regime(const kf_ctx* c) {
-  static int sat_env = -1;
+// KF_INTEGRATE_SAT=0: never defer (the plain fusion kernel on every frame: what the roofline line is measured on); default: deferral from the first frame
+bool kf_defer_enabled(const kf_ctx* c) {
+  static int sat_env = -1, pairs_env = -1;
   if (sat_env < 0) { const char* e = getenv("KF_INTEGRATE_SAT"); sat_env = e ? atoi(e) : 1; }
-  return sat_env == 2 || (sat_env == 1 && (float)c->fuse_calls >= c->vol.max_weight);
+  if (pairs_env < 0) { const char* e = getenv("KF_INTEGRATE_PAIRS"); pairs_env = e ? atoi(e) : 1; }
+  if (c->defer_override >= 0) return c->defer_override != 0 && pairs_env && c->vol.pend && c->vol.max_weight >= 1.f && c->vol.max_weight <= KF_PEND_MAX_WEIGHT;
+  return sat_env != 0 && pairs_env != 0 && c->vol.pend && c->vol.max_weight >= 1.f && c->vol.max_weight <= KF_PEND_MAX_WEIGHT;
+}
+
+// every pending count applied to its 128 voxels (one wave per brick); the words drop to "nothing pending" and stay valid
+__global__ void __launch_bounds__(256) k_flush_pending(KfVolume v, unsigned n_bricks) {
+  const unsigned lane = threadIdx.x & 63u, n_waves = gridDim.x * 4u;
+  for (unsigned s = blockIdx.x * 4u + (threadIdx.x >> 6); s < n_bricks; s += n_waves) {
+    const unsigned long long pp = v.pend[s];
+    unsigned long long np = pp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned pq = (unsigned)((pp >> (16 * q)) & 0xFFFFull);
+      if (pq < 2u) continue;                                  // uniform
+      float4* ptr = reinterpret_cast<float4*>(v.tw + (size_t)s * KF_BRICK_VOX + q * 128) + lane;
+      float4 r = *ptr;
+      r.y = kf_pend_weight(r.y, pq, v.max_weight); r.w = kf_pend_weight(r.w, pq, v.max_weight);
+      *ptr = r;
+      if (pq != KF_PEND_SAT) np = (np & ~(0xFFFFull << (16 * q))) | (1ull << (16 * q));
+    }
+    if (lane == 0u && np != pp) v.pend[s] = np;
+  }
+}
+int kf_flush_pending(kf_ctx* c) {
+  if (!c->pend_live || !c->vol.pend) return 0;
+  const unsigned n = (unsigned)c->n_stored_bricks;
+  hipLaunchKernelGGL(k_flush_pending, dim3(n / 4u + 1u > 8192u ? 8192u : n / 4u + 1u), dim3(256), 0, c->stream, c->vol, n);
+  return (int)hipGetLastError();
+}
+extern "C" int kf_set_defer(kf_ctx* c, int mode) {
+  if (!c || mode < -1 || mode > 1) return KF_ERR_ARG;
+  c->defer_override = mode;
+  return 0;
 }
 
 extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weight_color, const kf_mat44* transform,
@@ -761,24 +852,24 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   }
   a.parity = c->int_parity; c->last_parity = c->int_parity; c->int_parity ^= 1;
   a.clear_tiles = 1; a.n_tile_floats = c->n_tile_floats;
-  // saturated free space can only exist once max_weight frames have been fused since the volume was last reset or uploaded; the
-  // saturation bits are kept by the packed-pair kernel only
-  static int pairs_env = -1;
-  if (pairs_env < 0) { const char* e = getenv("KF_INTEGRATE_PAIRS"); pairs_env = e ? atoi(e) : 1; }
-  const bool sat = !has_color && pairs_env && kf_sat_regime(c);
-  a.sat_cull = 0;                                        // decided below, once it is known whether the tile minima describe this depth map
+  // deferred free-space weights (k_integrate_pairs<.., DEFER>): the packed-pair kernel without colour.  Any other fusion kernel knows nothing of
+  // the deferred-weight words: pending counts are applied before it runs and the words cleared behind it.
+  const bool defer = !has_color && kf_defer_enabled(c);
+  const bool legacy_over_words = !defer && c->pend_live;
+  if (legacy_over_words) { const int fs = kf_flush_pending(c); if (fs) return fs; }
+  a.defer_cull = 0;                                      // decided below, once it is known whether the tile minima describe this depth map
   kf_evt_begin(c, KF_STAGE_INTEGRATE);
   // tile maxima: normally left behind by the fused preprocess kernel for exactly this depth map and distance
   const bool tiles_ready = c->tile_serial != 0 && c->tile_serial == c->trunc_serial && c->tile_built_dist == a.max_dist;
   if (!tiles_ready) { hipLaunchKernelGGL(k_integrate_prepare, dim3(a.tile_w[1] * a.tile_h[1]), dim3(256), 0, c->stream, a); c->tile_min_serial = c->trunc_serial; }
-  a.sat_cull = (sat && c->tile_min_serial == c->trunc_serial) ? 1 : 0;     // whole-brick retirement needs the minima of THIS depth map
+  a.defer_cull = (defer && c->tile_min_serial == c->trunc_serial) ? 1 : 0;     // whole-brick retirement needs the minima of THIS depth map
   c->fuse_max_dist = a.max_dist;                         // what the next preprocess builds the tables for
   c->tile_serial = 0; c->tiles_clear = 1;                // the fusion pass below clears the tables behind the cull
   c->fp_tiles = 0;                                       // (tables a raycast launch may have built for a prefetched frame are cleared with them)
   {
     const int nmxy = (c->vol.nb + 3) >> 2, nmz = ((c->vol.bz1 + 3) >> 2) - (c->vol.bz0 >> 2);
     const unsigned n_macro = (unsigned)nmxy * nmxy * nmz;                      // one wave per macro cell, sixteen per workgroup
-    if (a.sat_cull) hipLaunchKernelGGL(k_integrate_cull<true>, dim3((n_macro + CULL_WAVES - 1) / CULL_WAVES), dim3(CULL_WAVES * 64), 0, c->stream, a);
+    if (a.defer_cull) hipLaunchKernelGGL(k_integrate_cull<true>, dim3((n_macro + CULL_WAVES - 1) / CULL_WAVES), dim3(CULL_WAVES * 64), 0, c->stream, a);
     else hipLaunchKernelGGL(k_integrate_cull<false>, dim3((n_macro + CULL_WAVES - 1) / CULL_WAVES), dim3(CULL_WAVES * 64), 0, c->stream, a);
   }
   // Workgroups walking the queue.  Large volumes (>= 2^20 stored bricks: the queue holds >~100k bricks): four bricks in flight per workgroup and
@@ -832,7 +923,7 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
     else
 #endif
     if (pairs) {
-      if (sat) {
+      if (defer) {
         if (br == 1) FUSE_LAUNCH((k_integrate_pairs<1, true>));
         else if (br == 2) FUSE_LAUNCH((k_integrate_pairs<2, true>));
         else FUSE_LAUNCH((k_integrate_pairs<4, true>));
@@ -846,7 +937,8 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
 #undef FUSE_LAUNCH
   if (timed) kf_evt_attached_done(c, KF_STAGE_INTEGRATE_KERNEL);
   kf_evt_end(c, KF_STAGE_INTEGRATE);
-  if (c->fuse_calls != 0xFFFFFFFFu) ++c->fuse_calls;
+  if (defer) c->pend_live = 1;
+  if (legacy_over_words) { KF_CHECK(hipMemsetAsync(c->vol.pend, 0, c->n_stored_bricks * sizeof(unsigned long long), c->stream)); c->pend_live = 0; }
   return (int)hipGetLastError();
 }
 

@@ -13,8 +13,13 @@
 #define KF_BRICK_VOX 512           // voxels per brick: 4 KiB of (tsdf, weight) pairs, contiguous in HBM
 #define KF_FLAG_OBSERVED 1u        // some voxel of the brick has weight > 0
 #define KF_FLAG_HASNEG 2u          // some voxel of the brick has (or once had) tsdf < 0
-#define KF_FLAG_SAT0 16u           // bits 4..7: z-layer pair q (voxels of layers 2q, 2q+1) holds nothing but (tsdf 1, weight max_weight):
-                                  // free space that further free-space observations cannot change (integrate.hip)
+// Deferred free-space weights (integrate.hip, "DEFER"): one 16-bit word per QUARTER brick (the 128 voxels of z layers 2q, 2q+1 -- what one
+// wave of the fusion pass owns), KfVolume::pend[slot] holding the four of a brick.  0: the voxels are authoritative.  p >= 1: all 128 voxels
+// hold tsdf 1.0f and a stored weight w >= 1, and k = p - 1 whole-quarter free-space observations are pending: the voxel's TRUE weight is
+// fminf(w + k, max_weight) -- k applications of tsdfVolume.h:65 on small integers, while tsdfVolume.h:66 leaves tsdf at (1 * w + 1) / (w + 1) = 1.
+// KF_PEND_SAT: every true weight has reached max_weight (k >= max_weight - 1 and w >= 1): any further free-space observation is the identity.
+#define KF_PEND_SAT 0xFFFFu
+#define KF_PEND_MAX_WEIGHT 65000.f // deferral needs 1 <= max_weight <= this (w + k stays an exact integer sum; KF_PEND_SAT - 1 pending steps saturate any weight)
 #define KF_MACRO 32                // voxels per macro-cell edge (raycast empty-space skipping)
 #ifndef KF_SUPER_SHIFT
 #define KF_SUPER_SHIFT 2           // a super cell is (1 << KF_SUPER_SHIFT)^3 macro cells: 128^3 voxels, the raycast's coarsest skip level
@@ -50,6 +55,7 @@ struct KfVolume {
   unsigned* macrobits;   // two packed bit tables over the WHOLE volume, [macro_words | super_words]: bit = some voxel of the 32^3-voxel macro cell /
                          // of the 128^3-voxel super cell has (had) tsdf < 0; set with atomicOr by whoever finds a brick's first negative voxel
   unsigned* negbits;     // one bit per STORED brick slot: the brick's KF_FLAG_HASNEG, packed so the raycast can keep the table in LDS
+  unsigned long long* pend;   // per STORED brick slot: four 16-bit deferred-weight words (quarter q at bits 16q), see KF_PEND_SAT above
   int nm;                // macro cells per axis = ceil(res / 32)
   int ns;                // super cells per axis = ceil(nm / 4)
   int macro_words, super_words;   // words of the two tables (each padded to whole 16-byte vectors)
@@ -62,8 +68,15 @@ struct KfVolume {
   float max_weight;
 };
 
-// (declared in integrate.hip) may saturated free space exist -- max_weight frames fused since the last reset / upload, KF_INTEGRATE_SAT?
-bool kf_sat_regime(const struct kf_ctx* c);
+// (integrate.hip) does this context defer whole-quarter free-space weight updates (max_weight in range, KF_INTEGRATE_SAT != 0)?
+bool kf_defer_enabled(const struct kf_ctx* c);
+// (integrate.hip) apply every pending count to the voxels (the counts drop to "nothing pending"; the states stay valid)
+int kf_flush_pending(struct kf_ctx* c);
+
+// the true weight of a voxel whose quarter brick carries the deferred-weight word p (KF_PEND_SAT - 1 pending steps saturate every w >= 1)
+__host__ __device__ static inline float kf_pend_weight(float w, unsigned p, float max_weight) {
+  return p >= 2u ? fminf(w + (float)(p - 1u), max_weight) : w;
+}
 
 // Device-resident tracker state (what CameraPoseFinder keeps in _pose plus the Gauss-Newton scratch).
 struct KfTrackState {
@@ -138,6 +151,7 @@ struct kf_ctx {
   int new_pyr_ok, model_pyr_ok, alt_pyr_ok;
   hipStream_t side_stream; hipEvent_t ev_preprocessed, ev_prefetched;
   const uint16_t* prefetch_src; float prefetch_params[4]; int prefetch_valid, prefetch_in_use;
+  kf_camera_params prefetch_cam;      // the intrinsics the prefetched vertices / normals / pyramids were built with: kf_preprocess adopts the set only for the same camera
   // fused form of the prefetch (default): kf_prefetch_frame only records the request; the next kf_raycast_volume launches the raycast with the
   // next frame's gate + bilateral filter riding along (k_raycast_prefetch) and the vertices / normals launch behind it, on the context's own stream
   int fp_pending;                     // a request waits for the next raycast
@@ -177,8 +191,8 @@ struct kf_ctx {
   unsigned* mc_block_counts; size_t mc_blocks_cap;
   unsigned* mc_list; unsigned* mc_nbr_bits; unsigned* mc_partials;   // extraction scratch, allocated by the first kf_marching_cubes
   unsigned short* mc_codes; unsigned char* mc_surv; unsigned* mc_block_bits; uint2* mc_recs; unsigned* mc_d1_list;   // voxel classes, sieve bits, cell records, brick list (mcubes.hip), same scratch
-  unsigned fuse_calls;           // kf_integrate_volume CALLS (lost frames included: an upper bound of the frames fused) since the volume was last reset or
-                                 // uploaded: saturation can only exist after max_weight of them, so the bound errs on the side of checking for it
+  int defer_override;            // kf_set_defer: -1 follow the environment (default), 0 never defer, 1 defer
+  int pend_live;                 // a DEFER fusion pass has run since the volume was last reset / uploaded / flushed: deferred-weight words may be set
   unsigned vol_flags_serial, mc_zero_serial;   // bumped when brick flags may have been CLEARED (reset, upload) / the serial the class tables were last zeroed for
   void* host_pinned;                  // small pinned staging buffer (4 KiB); byte KF_PINNED_STALL_WORD: the ICP loop's stall word
   // per-stage hipEvent timers (KF_STAGE_*): bit s of timers_enabled turns stage s on

@@ -219,7 +219,7 @@ void kf_bilateral_args(kf_ctx* c, const uint16_t* mm, const float* raw_in, float
   if (build_tiles) {                                       // layout of the two tables: kf_integrate_volume (integrate.hip)
     acc.tile = reinterpret_cast<int*>(c->tile_max_depth); acc.max_dist = c->fuse_max_dist;
     acc.off0 = 0; acc.w0 = kf_div_up(c->cols, 8); acc.off1 = acc.w0 * kf_div_up(c->rows, 8); acc.w1 = kf_div_up(c->cols, 16);
-    acc.n = kf_sat_regime(c) ? c->n_tile_floats : 0;         // the minima only matter once saturated free space can exist
+    acc.n = kf_defer_enabled(c) ? c->n_tile_floats : 0;      // the minima only matter to the cull's whole-brick retirement (deferred free-space weights)
   }
   // the sentinel form needs every valid depth far below the sentinel and the sentinel's tap weight to underflow to exactly zero
   *fast = tmax < 1e15f && sd_inv * KF_LOG2E > 1e-30f && sd_inv * KF_LOG2E < 1e30f;
@@ -250,7 +250,8 @@ extern "C" int kf_preprocess(kf_ctx* c, float tmin, float tmax, float sigma_pixe
   const int radius = (int)ceil(2.0 * (double)sigma_pixel);
   const float want[4] = {tmin, tmax, sigma_pixel, sigma_depth};
   c->fp_pending = 0; c->fp_filtered = 0;                    // a recorded request no raycast has picked up is void now
-  if (c->prefetch_valid && c->pending_mm && c->pending_mm == c->prefetch_src && memcmp(want, c->prefetch_params, sizeof(want)) == 0) {
+  if (c->prefetch_valid && c->pending_mm && c->pending_mm == c->prefetch_src && memcmp(want, c->prefetch_params, sizeof(want)) == 0 &&
+      memcmp(cam, &c->prefetch_cam, sizeof(*cam)) == 0) {
     // this very frame was preprocessed ahead of time on the side stream (kf_prefetch_frame): adopt its buffers
     float* t;
     t = c->raw_depth; c->raw_depth = c->alt_raw; c->alt_raw = t;
@@ -288,7 +289,7 @@ extern "C" int kf_preprocess(kf_ctx* c, float tmin, float tmax, float sigma_pixe
     st = launch_fused_preprocess(c, c->stream, c->pending_mm, c->raw_depth, c->raw_depth, c->trunced_depth, c->filtered_depth, c->new_v[0], c->new_n[0],
                                  tmin, tmax, sigma_pixel, sigma_depth, cam, build_tiles);
     c->trunc_serial++;
-    if (build_tiles) { c->tile_serial = c->trunc_serial; c->tile_built_dist = c->fuse_max_dist; c->tiles_clear = 0; if (kf_sat_regime(c)) c->tile_min_serial = c->trunc_serial; }
+    if (build_tiles) { c->tile_serial = c->trunc_serial; c->tile_built_dist = c->fuse_max_dist; c->tiles_clear = 0; if (kf_defer_enabled(c)) c->tile_min_serial = c->trunc_serial; }
     c->pending_mm = nullptr;
     if (st == 0) st = kf_pending_depth_consumed(c);
   } else {
@@ -359,6 +360,7 @@ extern "C" int kf_prefetch_frame(kf_ctx* c, const uint16_t* dev_mm, uint32_t col
   KF_CHECK(hipEventRecord(c->ev_prefetched, c->side_stream));
   c->prefetch_src = dev_mm;
   c->prefetch_params[0] = tmin; c->prefetch_params[1] = tmax; c->prefetch_params[2] = sigma_pixel; c->prefetch_params[3] = sigma_depth;
+  c->prefetch_cam = *cam;
   c->prefetch_valid = 1;
   return 0;
 }

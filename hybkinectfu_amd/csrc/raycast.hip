@@ -421,6 +421,7 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
       }
       c->alt_pyr_ok = (behind && ft.pyr.v1) ? 1 : 0;
       c->prefetch_src = c->fp_src; memcpy(c->prefetch_params, c->fp_params, sizeof(c->prefetch_params));
+      c->prefetch_cam = c->fp_cam;
       c->prefetch_valid = 1; c->fp_done = 1;
       c->fp_tiles = build_tiles ? 1 : 0; c->fp_tiles_dist = c->fuse_max_dist; c->fp_tiles_min = (build_tiles && b.acc.n) ? 1 : 0;
       if (build_tiles) c->tiles_clear = 0;

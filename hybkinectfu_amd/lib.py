@@ -85,7 +85,7 @@ SYMBOLS = [
     "kf_upload_map", "kf_download_volume", "kf_upload_volume", "kf_get_volume_stats", "kf_stored_z_range",
     "kf_stage_timers", "kf_read_stage_ms", "kf_read_work_counters", "kf_set_stream", "kf_raycast_volume_slab", "kf_slab_mask_candidates", "kf_set_model_maps_device", "kf_raycast_volume_slab_rays", "kf_slab_mask_rays", "kf_set_model_maps_rays", "kf_selftest_div",
     "kf_icp_partition_begin", "kf_icp_partition_steps", "kf_icp_partition_step", "kf_icp_partition_finish",
-    "kf_sdf_partition_begin", "kf_sdf_partition_step", "kf_sdf_partition_finish",
+    "kf_sdf_partition_begin", "kf_sdf_partition_step", "kf_sdf_partition_finish", "kf_set_defer",
 ]
 
 
@@ -305,6 +305,10 @@ class Context:
         tp = C.byref(Mat44.of(pose)) if pose is not None else None
         _chk(self.lib.kf_integrate_volume(self.h, int(has_color), int(angle_weight), tp, C.byref(ip), C.byref(self.cam),
                                           C.byref(self.rgb_cam)), "kf_integrate_volume")
+
+    def set_defer(self, mode):
+        """deferred free-space weights: 1 on, 0 off (the plain fusion kernel on every frame), -1 follow the environment"""
+        _chk(self.lib.kf_set_defer(self.h, int(mode)), "kf_set_defer")
 
     def raycast(self, pose, inc, near, far, has_color=False):
         rp = RaycastParams(inc)

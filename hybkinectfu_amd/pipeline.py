@@ -18,7 +18,7 @@ class SingleGpuPipeline:
         self.integ_dist = wl.get("integ_dist", P["integrate_depth_trunc"])
         self.tracker = wl.get("tracker", "icp")                # "icp": CameraPoseFinderICP, "sdf": CameraPoseFinderSDF
         self.color = bool(wl.get("color", False))              # the reference's stock switches use_color=1, color_angle_weight=1 (src/config.ini:2,7)
-        self.ctx = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=max_triangles, device=device, has_color=self.color)
+        self.ctx = K.Context(kcam, res, size, wl.get("max_weight", P["volume_max_weight"]), levels=3, max_triangles=max_triangles, device=device, has_color=self.color)
         self.ctx.set_pose(S.pose0(size))                       # HybKinectfu::init  src/HybKinectfu.cpp:51-57
         self.inc = P["raycast_increment_factor"] * P["integrate_sdf_trunc"]     # AppParamsProducer.cpp:113-117
 

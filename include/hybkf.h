@@ -162,6 +162,13 @@ int kf_wait_track_result(kf_ctx* ctx, kf_track_result* out);
 int kf_integrate_volume(kf_ctx* ctx, int has_color, int use_angle_weight_color, const kf_mat44* transform,
                         const kf_integrate_params* integrate_params, const kf_camera_params* depth_camera,
                         const kf_camera_params* rgb_camera);
+/* Deferred free-space weights (no reference counterpart: a property of this implementation of integrateKernel / updateVoxel,
+ * src/cuda/integrateVolume.cu:15-77, src/cuda/tsdfVolume.h:57-75 -- results are bit-identical either way).  A wave of the fusion pass
+ * whose 128 voxels all hold tsdf 1 and are all observed as free space again only counts the observation; the count is applied to the
+ * weights (w <- fminf(w + k, max_weight)) when anything else writes into those voxels and by kf_download_volume.  mode 1: on, 0: off (the
+ * plain read-modify-write kernel on every frame), -1: follow the environment (KF_INTEGRATE_SAT=0 turns it off; default on).  Needs
+ * 1 <= max_weight <= 65000 and no colour; otherwise the plain kernel runs whatever the mode. */
+int kf_set_defer(kf_ctx* ctx, int mode);
 /* cudaRaycastingVolume  src/cuda/raycastingVolume.cu:158-176.  transform == NULL: device-resident pose. */
 int kf_raycast_volume(kf_ctx* ctx, int has_color, const kf_mat44* transform, const kf_raycast_params* raycast_params,
                       const kf_camera_params* depth_camera, float near_plane, float far_plane);

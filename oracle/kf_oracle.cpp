@@ -83,8 +83,17 @@ inline void project_to_screen(f3 v, const okf_cam& c, int& sx, int& sy) {
 }
 
 /* ---- volume helpers: src/cuda/tsdfVolume.h ---- */
+static uint64_t g_band_violations = 0;
+static const okf_voxel g_unobserved = {0.f, 0.f, {0, 0, 0}, 0};
+inline int first_layer(const okf_volume* v) { return v->z_layers ? v->z_base : 0; }
+inline int stored_layers(const okf_volume* v) { return v->z_layers ? v->z_layers : v->res; }
 inline const okf_voxel& vox_at(const okf_volume* v, int x, int y, int z) {
-  return v->data[((size_t)z * v->res + y) * v->res + x];
+  const int zl = z - first_layer(v);
+  if ((unsigned)zl >= (unsigned)stored_layers(v)) {       /* only a z-band volume can get here */
+    __atomic_fetch_add(&g_band_violations, (uint64_t)1, __ATOMIC_RELAXED);
+    return g_unobserved;
+  }
+  return v->data[((size_t)zl * v->res + y) * v->res + x];
 }
 /* tsdfVolume.h:38-49 */
 inline f3 voxel_to_world(const okf_volume* v, int x, int y, int z) {
@@ -635,6 +644,10 @@ uint64_t okf_integrate(okf_volume* vol, int z0, int z1, const float* depth, cons
   okf_mat44_inverse(pose, tinv);                                   /* :84 */
   const int R = vol->res;
   uint64_t n_upd = 0;
+  if (z0 < first_layer(vol) || z1 > first_layer(vol) + stored_layers(vol)) {     /* a z-band volume asked for layers it does not hold */
+    __atomic_fetch_add(&g_band_violations, (uint64_t)1, __ATOMIC_RELAXED);
+    return 0;
+  }
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : n_upd)
   for (int y = 0; y < R; ++y)
     for (int x = 0; x < R; ++x)
@@ -661,7 +674,7 @@ uint64_t okf_integrate(okf_volume* vol, int z0, int z1, const float* depth, cons
           float sdf = d - pf.z;
           if (sdf > -sdf_trunc) {
             float tsdf = fminf(1.0f, sdf / sdf_trunc);
-            okf_voxel& v = vol->data[((size_t)z * R + y) * R + x];
+            okf_voxel& v = vol->data[((size_t)(z - first_layer(vol)) * R + y) * R + x];
             float ow = v.weight, ot = v.tsdf;
             float w = 1.f;
             float nw = fminf(ow + w, vol->max_weight);
@@ -683,8 +696,10 @@ uint64_t okf_integrate(okf_volume* vol, int z0, int z1, const float* depth, cons
   return n_upd;
 }
 
+uint64_t okf_band_violations(void) { return __atomic_exchange_n(&g_band_violations, (uint64_t)0, __ATOMIC_RELAXED); }
+
 uint64_t okf_count_weight_gt0(const okf_volume* vol) {
-  size_t n = (size_t)vol->res * vol->res * vol->res; uint64_t c = 0;
+  size_t n = (size_t)vol->res * vol->res * stored_layers(vol); uint64_t c = 0;
 #pragma omp parallel for reduction(+ : c)
   for (size_t i = 0; i < n; ++i) c += vol->data[i].weight > 0 ? 1 : 0;
   return c;

@@ -32,11 +32,15 @@ typedef struct okf_cam { uint32_t cols, rows; float cx, cy, fx, fy; } okf_cam;
 typedef struct okf_voxel { float tsdf; float weight; uint8_t color[3]; uint8_t pad_; } okf_voxel;
 
 typedef struct okf_volume {
-  okf_voxel* data;      /* res^3 voxels */
+  okf_voxel* data;      /* res^3 voxels -- or, for a z-band (z_layers != 0), only layers [z_base, z_base + z_layers) of the res^3 grid */
   int32_t res;          /* cubic resolution (tsdfVolume.h:32) */
   float size;           /* metres (tsdfVolume.h:31) */
   float max_weight;     /* tsdfVolume.h:33 */
+  int32_t z_base;       /* z-band (tests of volumes too large for host memory, e.g. 2048^3 = 103 GB): first stored layer */
+  int32_t z_layers;     /* z-band: stored layers; 0 = the whole volume (z_base ignored) */
 } okf_volume;
+/* a z-band volume answers reads outside its layers with an unobserved voxel and counts them: a test that stays inside its band reads 0 here */
+uint64_t okf_band_violations(void);     /* returns the count and resets it */
 
 /* src/cuda/MarchingcubeData.h:15-27 -- 72-byte triangle */
 typedef struct okf_vertex { float pos[3]; float color[3]; } okf_vertex;

@@ -29,7 +29,8 @@ class Cam(C.Structure):
 
 
 class Volume(C.Structure):
-    _fields_ = [("data", C.c_void_p), ("res", C.c_int32), ("size", C.c_float), ("max_weight", C.c_float)]
+    _fields_ = [("data", C.c_void_p), ("res", C.c_int32), ("size", C.c_float), ("max_weight", C.c_float),
+                ("z_base", C.c_int32), ("z_layers", C.c_int32)]
 
 
 VOXEL_DTYPE = np.dtype([("tsdf", "<f4"), ("weight", "<f4"), ("color", "u1", (3,)), ("pad", "u1")])
@@ -68,24 +69,32 @@ def m16(m):
 
 
 class OVolume:
-    """Dense 12-byte-voxel volume for the oracle."""
+    """Dense 12-byte-voxel volume for the oracle.  band=(z_base, z_layers): only those layers of the res^3 grid are held (volumes too
+    large for host memory: 2048^3 is 103 GB); reads outside the band count as violations (band_violations())."""
 
-    def __init__(self, res, size, max_weight):
+    def __init__(self, res, size, max_weight, band=None):
         self.res, self.size, self.max_weight = int(res), float(size), float(max_weight)
-        self.vox = np.zeros(self.res ** 3, dtype=VOXEL_DTYPE)
-        self.c = Volume(self.vox.ctypes.data, self.res, self.size, self.max_weight)
+        self.z_base, self.layers = (0, self.res) if band is None else (int(band[0]), int(band[1]))
+        self.vox = np.zeros(self.res * self.res * self.layers, dtype=VOXEL_DTYPE)
+        self.c = Volume(self.vox.ctypes.data, self.res, self.size, self.max_weight, self.z_base, 0 if band is None else self.layers)
 
     @property
     def tsdf(self):
-        return self.vox["tsdf"].reshape(self.res, self.res, self.res)   # [z][y][x]
+        return self.vox["tsdf"].reshape(self.layers, self.res, self.res)   # [z - z_base][y][x]
 
     @property
     def weight(self):
-        return self.vox["weight"].reshape(self.res, self.res, self.res)
+        return self.vox["weight"].reshape(self.layers, self.res, self.res)
 
     @property
     def color(self):
-        return self.vox["color"].reshape(self.res, self.res, self.res, 3)
+        return self.vox["color"].reshape(self.layers, self.res, self.res, 3)
+
+
+def band_violations():
+    """reads outside a z-band volume's layers since the last call (must be 0 for a test that claims to stay inside its band)"""
+    lib().okf_band_violations.restype = C.c_uint64
+    return int(lib().okf_band_violations())
 
 
 def depth_mm_to_m(mm):

@@ -5,7 +5,8 @@ C1  256^3 @ 3 m, 3-level ICP, frames read by DataSourceProducerRGBDDataset from 
 C2  512^3 @ 4 m, VGA: raycast maps and marching-cubes triangle sequence vs the oracle (integrate is in test_gpu_parity.py)
 C3  512^3 @ 4 m, VGA, CameraPoseFinderSDF: 27 sums and tracked poses vs okf_sdf_* on identical inputs
 C4  1024^3 @ 6 m, depth gates opened: update counts + planes vs the oracle, and 2 z-slabs == whole volume
-(C5 geometry, 2048^3 with 1280x960 depth: test_gpu_parity.py::test_maximum_configuration_2048_cubed)
+C5  2048^3 @ 8 m, 1280x960: three z-bands of the 68.7 GB volume against a z-band oracle (update counts, planes, marching cubes), voxel
+    indices beyond 2^31 and 2^32 (the tracked pipeline at this size: test_gpu_parity.py::test_maximum_configuration_2048_cubed)
 """
 import ctypes as C
 
@@ -274,4 +275,65 @@ def test_c4_integrate_1024_cubed_and_two_slabs():
     assert np.array_equal(bits(merged[0]), bits(wv)) and np.array_equal(bits(merged[1]), bits(wn))
     assert all(int(torch.isfinite(b[0]).sum()) > 1000 for b in bufs)        # both slabs really contribute crossings
     for c in [whole] + slabs:
+        c.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# C5: 2048^3 @ 8 m, 1280x960 -- the volume is 103 GB in the oracle's layout, so the oracle holds one z-band of it at a time
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_c5_2048_cubed_z_bands_against_the_oracle():
+    """BASELINE.json's largest configuration, bit for bit where the oracle can reach it: three 64-layer bands of the whole 2048^3 volume
+    (free space in front of the room; the central sphere's cap, voxel indices beyond 2^31; the back wall, beyond 2^32) after two fused
+    frames -- update count of the band per frame (a slab context of exactly those layers), tsdf / weight planes downloaded from the
+    WHOLE-volume context (64-bit voxel addressing, > 1 M-entry brick queue, the 12288-workgroup grid, deferred free-space weights at
+    scale), and the marching-cubes triangle sequence of an inner range (slab extraction).  Reference: integrateVolume.cu:15-77,
+    tsdfVolume.h:57-60, marchingcube.cu:41-152."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 90 * 2**30:
+        pytest.skip("needs ~80 GB of free HBM")
+    if host_ram_gib() < 10:
+        pytest.skip("a 64-layer band of the oracle's 2048^3 volume needs 3.2 GB of host memory")
+    res, size, cam = 2048, 8.0, S.vga_camera(2)
+    tmax = dist = 8.0
+    ocam, kcam = O.Cam.make(*cam), K.camera(*cam)
+    maxw, trunc = P["volume_max_weight"], P["integrate_sdf_trunc"]
+    thr = 300 * size / res
+    # (band layers, marching-cubes layers inside them): 1.25-1.5 m free space | sphere cap at 2.8 m | back wall at 6 m
+    bands = [((320, 384), None), ((704, 768), (712, 728)), ((1504, 1568), (1528, 1544))]
+    whole = K.Context(kcam, res, size, maxw, levels=3)
+    slab = [K.Context(kcam, res, size, maxw, levels=3, slab=b) for b, _ in bands]
+    mcs = [K.Context(kcam, res, size, maxw, levels=3, slab=m, halo=8, max_triangles=3_000_000) if m else None for _, m in bands]
+    frames, n_slab = [], []
+    for k in (0, 6):
+        pose = S.trajectory_pose(k, size).astype(np.float32)
+        mm = S.render_depth_mm(pose, cam, size)
+        tr, fl, v, n = oracle_preprocess(mm, ocam, tmax)
+        frames.append((pose, tr, n))
+        for c in [whole] + slab + [m for m in mcs if m]:
+            c.upload_depth_mm(mm)
+            c.preprocess(P["depth_trunc_min"], tmax, P["filter_sigma_pixel"], P["filter_sigma_depth"])
+            c.integrate(pose, trunc, dist)
+        n_slab.append([c.stats()["updated_last"] for c in slab])
+    st = whole.stats()
+    assert st["updated_last"] > 4e8 and st["bricks_active"] > 300_000        # (second frame: whole free-space bricks are retired by the cull, not queued)
+    for i, ((z0, z1), mz) in enumerate(bands):
+        ovol = O.OVolume(res, size, maxw, band=(z0, z1 - z0))
+        for f, (pose, tr, n) in enumerate(frames):
+            n_o = O.integrate(ovol, tr, n, None, False, False, pose, trunc, dist, ocam, ocam, z0, z1)
+            assert n_o == n_slab[f][i] and n_o > 1_000_000, (i, f, n_o, n_slab[f][i])
+        t, w = whole.download_volume(z0, z1)                       # voxel index (z * 2048 + y) * 2048 + x of the 2048^3 grid: up to 6.6e9
+        assert np.array_equal(bits(t), bits(ovol.tsdf)) and np.array_equal(bits(w), bits(ovol.weight)), (z0, z1)
+        t, w = slab[i].download_volume(z0, z1)
+        assert np.array_equal(bits(t), bits(ovol.tsdf)) and np.array_equal(bits(w), bits(ovol.weight)), (z0, z1)
+        assert int((ovol.weight == 2).sum()) > 500_000              # both frames really landed in the band
+        if mz:
+            ot = O.marching_cubes(ovol, False, thr, 3_000_000, mz[0], mz[1])
+            mcs[i].marching_cubes(thr)
+            gt = mcs[i].triangles()
+            assert len(ot) > 10_000, (mz, len(ot))
+            assert len(gt) == len(ot) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32)), (mz, len(gt), len(ot))
+        assert O.band_violations() == 0
+        del ovol
+    for c in [whole] + slab + [m for m in mcs if m]:
         c.close()

@@ -183,3 +183,32 @@ def test_color_weight_fp32_form_equals_reference_double_form():
     assert mismatches(m.view(np.float32)) == 0                                  # zero and the denormals
     rng = np.random.default_rng(5)
     assert mismatches(np.exp(rng.uniform(-80, 3, 2_000_000))) == 0
+
+
+def test_z_band_volume_equals_the_same_layers_of_the_whole_volume():
+    """A z-band oracle volume (layers [z_base, z_base + n) of the grid only: how 2048^3, 103 GB as a whole, gets under the oracle) must be the
+    whole-volume oracle restricted to those layers: integrate counts and planes, marching cubes over an inner range, no read outside the band --
+    and a read that does leave the band is counted, not answered silently."""
+    cam = (160, 120, 79.5, 59.5, 131.25, 131.25)
+    ocam = O.Cam.make(*cam)
+    size, res, trunc = 3.0, 64, 0.1
+    whole = O.OVolume(res, size, 128.0)
+    band = O.OVolume(res, size, 128.0, band=(22, 28))              # layers 22 .. 49
+    for k in (0, 5):
+        pose = S.trajectory_pose(k, size).astype(np.float32)
+        tr = O.trunc_depth(O.depth_mm_to_m(S.render_depth_mm(pose, cam, size)), 0.3, 4.0)
+        n = O.vertices_to_normals(O.depth_to_vertices(tr, ocam))
+        O.integrate(whole, tr, n, None, False, False, pose, trunc, 2.5, ocam, ocam)
+        n_band = O.integrate(band, tr, n, None, False, False, pose, trunc, 2.5, ocam, ocam, 22, 50)
+        ref = O.OVolume(res, size, 128.0)                           # the same count from a whole volume restricted to the layers
+        assert n_band == O.integrate(ref, tr, n, None, False, False, pose, trunc, 2.5, ocam, ocam, 22, 50)
+    assert np.array_equal(bits(band.tsdf), bits(whole.tsdf[22:50])) and np.array_equal(bits(band.weight), bits(whole.weight[22:50]))
+    assert O.count_weight_gt0(band) == int((whole.weight[22:50] > 0).sum()) > 1000
+    thr = 300 * size / res
+    a = O.marching_cubes(whole, False, thr, 400000, 24, 48)
+    b = O.marching_cubes(band, False, thr, 400000, 24, 48)         # corner interpolations reach one layer beyond the cells: inside the band
+    assert len(a) > 200 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert O.band_violations() == 0
+    O.marching_cubes(band, False, thr, 400000, 20, 24)             # leaves the band below: counted
+    assert O.band_violations() > 0
+    assert O.integrate(band, tr, n, None, False, False, pose, trunc, 2.5, ocam, ocam, 0, 64) == 0 and O.band_violations() == 1

@@ -1,19 +1,21 @@
 #!/usr/bin/env python3
-"""The saturation-aware fusion (KF_INTEGRATE_SAT=1, default) against the plain kernels (KF_INTEGRATE_SAT=0) on the benchmark stream
-at full size: same update counts and the same voxel bits after n frames.  The switch is read once per process, so the parent runs
-one child per setting (one after the other; the parent itself touches no GPU) and compares what they print.
-    python tools/sat_equivalence.py [c2|c4] [frames]"""
+"""The fusion pass with deferred free-space weights (KF_INTEGRATE_SAT=1, default: from the first frame) against the plain kernels
+(KF_INTEGRATE_SAT=0) on the benchmark stream at full size: same update counts and the same voxel bits after n frames.  The switch is
+read once per process, so the parent runs one child per setting (one after the other; the parent itself touches no GPU) and compares
+what they print.  max_weight 128 (stock) stays in the pending-count state for 127 frames, max_weight 3 saturates after three.
+    python tools/sat_equivalence.py [c2|c4] [frames] [max_weight]"""
 import hashlib, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def child(cfg, n):
+def child(cfg, n, maxw):
     sys.path.insert(0, ROOT)
     import numpy as np, torch
     from hybkinectfu_amd import lib as K, scene as S
     from hybkinectfu_amd.pipeline import SingleGpuPipeline
     import bench
     wl = bench.workload(1, cfg)
+    wl = dict(wl, max_weight=maxw)
     cam = wl["cam"]
     frames, _ = S.make_stream(100, cam, wl["size"])
     dev = torch.from_numpy(frames.astype(np.int16)).cuda()
@@ -35,14 +37,15 @@ def child(cfg, n):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
-        child(sys.argv[2], int(sys.argv[3]))
+        child(sys.argv[2], int(sys.argv[3]), float(sys.argv[4]))
         sys.exit(0)
     cfg = sys.argv[1] if len(sys.argv) > 1 else "c4"
     n = sys.argv[2] if len(sys.argv) > 2 else "200"
+    maxw = sys.argv[3] if len(sys.argv) > 3 else "128"
     out = {}
     for mode in ("0", "1"):
         env = dict(os.environ, KF_INTEGRATE_SAT=mode)
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", cfg, n], env=env, capture_output=True, text=True)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", cfg, n, maxw], env=env, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
         if r.returncode or not line:
             print(r.stdout, r.stderr); sys.exit(1)
@@ -50,5 +53,5 @@ if __name__ == "__main__":
         print("KF_INTEGRATE_SAT=%s %s" % (mode, line[0]))
     a, b = out["0"].split(), out["1"].split()
     same = [x for x in a if not x.startswith("bricks_active_last")] == [x for x in b if not x.startswith("bricks_active_last")]
-    print("EQUIVALENT" if same else "DIFFERENT", "(%s, %s frames; the queue of the last frame differs by design: retired bricks are counted, not queued)" % (cfg, n))
+    print("EQUIVALENT" if same else "DIFFERENT", "(%s, %s frames, max_weight %s; the queue of the last frame differs by design: retired bricks are counted, not queued)" % (cfg, n, maxw))
     sys.exit(0 if same else 2)
