@@ -13,8 +13,11 @@ The N=1 line also carries `multi_gpu_workload_on_1_gpu` (C4 unpartitioned on thi
 N=2/4/8 lines), `other_configs` (C1: 256^3 @ 3 m, C3: 512^3 with the SDF tracker, C5: 2048^3 @ 8 m with 1280x960 depth and mesh
 extraction, a few dozen frames each) and `steady_state`; the headline `value` at N=1 is C2, as BASELINE.json's metric states.
 The N>1 line carries `per_rank` (what every z-slab rank fused and how long its integrate / raycast / merge stages took) and a short
-`c5` block (2048^3 @ 8 m on the same ranks).  `config.env` lists every KF_* variable that was set; `regime` says which side of the
-weight saturation the timed frames ran on.
+`c5` block (2048^3 @ 8 m on the same ranks).  `config.env` lists every KF_* variable that was set.
+`roofline` is the PLAIN read-modify-write form of the fusion kernel (algorithmic bytes / its live dispatch time, measured right after the timed
+region with kf_set_defer(0)); `roofline.in_timed_region` is the DEFER form the timed frames run, with the bytes it really moves.  `value` =
+`value_resident`; `value_pcie_inclusive` beside it; `parity_witness` compares the HIP path's pose and update count with the oracle's on the
+frames the cpu_baseline leg ran; `scene_noise` repeats the headline on a stream with sensor noise.
 """
 import argparse
 import json
@@ -60,9 +63,12 @@ def workload(n_gpus, name="auto"):
                      ("whole volume on 1 GPU" if n_gpus == 1 else "z-slab per GPU, %d GPUs" % n_gpus))
 
 
-def cpu_baseline(wl, frames_mm, n_sample=150):
+def cpu_baseline(wl, frames_mm, n_sample=150, witness=None):
     """The CPU oracle (oracle/, 'port') on the first n_sample frames of the same stream (about 10-15 s of CPU work on the
-    GPU box's 16-core share), OpenMP over the box's cores."""
+    GPU box's 16-core share), OpenMP over the box's cores.
+    witness = (GPU pose after frame n_sample - 1 of the same frames, voxels the GPU fused on that frame): the oracle's own pose at that
+    frame is compared with the GPU's, and the oracle counts the voxels that frame updates under the GPU's pose (the update predicate,
+    integrateVolume.cu:39-67, depends on the depth map and the pose only) -- returned as the second value, outside the timed work."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     # the GPU box gives one GPU job a 16-core share of the host; more OpenMP threads than that only oversubscribe it
@@ -73,6 +79,7 @@ def cpu_baseline(wl, frames_mm, n_sample=150):
     vol = O.OVolume(wl["res"], wl["size"], P["volume_max_weight"])
     pose = S.pose0(wl["size"])
     mv = mn = None
+    ok = True
     t0 = time.perf_counter()
     for k in range(n_sample):
         tr = O.trunc_depth(O.depth_mm_to_m(frames_mm[k % len(frames_mm)]), P["depth_trunc_min"], wl["trunc_max"])
@@ -87,8 +94,42 @@ def cpu_baseline(wl, frames_mm, n_sample=150):
         O.integrate(vol, tr, n, None, False, False, pose, P["integrate_sdf_trunc"], wl["integ_dist"], ocam, ocam)
         mv, mn, _ = O.raycast(vol, False, pose, P["raycast_increment_factor"] * P["integrate_sdf_trunc"], ocam, P["depth_trunc_min"], wl["trunc_max"])
     dt = time.perf_counter() - t0
-    return dict(value=round(n_sample / dt, 4), unit="frames/s", cores=int(cores), kind="port",
+    base = dict(value=round(n_sample / dt, 4), unit="frames/s", cores=int(cores), kind="port",
                 sample="%d frames of the same stream through oracle/libkforacle.so (preprocess+ICP+integrate+raycast), %.1f s" % (n_sample, dt))
+    wit = None
+    if witness is not None:
+        gpu_pose, gpu_n_upd, gpu_tracked = witness
+        gp, op = np.asarray(gpu_pose, np.float64).reshape(4, 4), np.asarray(pose, np.float64).reshape(4, 4)
+        dr = gp[:3, :3].T @ op[:3, :3]
+        ang = float(np.arccos(np.clip((np.trace(dr) - 1.0) / 2.0, -1.0, 1.0)))
+        n_o = O.integrate(vol, tr, n, None, False, False, np.asarray(gpu_pose, np.float32), P["integrate_sdf_trunc"], wl["integ_dist"], ocam, ocam)
+        d_t = float(np.linalg.norm(gp[:3, 3] - op[:3, 3]))
+        wit = dict(frame=n_sample - 1, frames_tracked_by_both=n_sample - 1, oracle_tracked=bool(ok), gpu_tracked=bool(gpu_tracked),
+                   pose_translation_diff_m=d_t, pose_rotation_diff_rad=ang, tolerance="1e-4 m / 1e-4 rad (BASELINE.json north_star)",
+                   pose_within_tolerance=bool(ok and gpu_tracked and d_t <= 1e-4 and ang <= 1e-4),
+                   n_upd_gpu=int(gpu_n_upd), n_upd_oracle_with_gpu_pose=int(n_o), n_upd_equal=bool(int(gpu_n_upd) == int(n_o)),
+                   note="the HIP path and the oracle each tracked and fused the same %d frames on their own (the cpu_baseline leg); poses compared at the "
+                        "last frame, and the oracle's count of voxels passing the update predicate for that frame under the GPU's pose against the GPU's "
+                        "device counter (bit-exact gate; the full parity suite is tests/ -m gpu)" % n_sample)
+    return base, wit
+
+
+def gpu_witness_run(wl, frames_mm, n_sample):
+    """the same first n_sample frames through a fresh HIP pipeline: (pose after the last frame, voxels fused on it, tracked)"""
+    import torch
+    from hybkinectfu_amd.pipeline import SingleGpuPipeline
+    cam = wl["cam"]
+    n_u = len(frames_mm)
+    dev = torch.from_numpy(np.ascontiguousarray(frames_mm).astype(np.int16)).cuda()
+    fb = cam[0] * cam[1] * 2
+    pipe = SingleGpuPipeline(K.camera(*cam), wl["res"], wl["size"], wl, device=torch.cuda.current_device())
+    for k in range(n_sample):
+        pipe.process_frame_device(dev.data_ptr() + (k % n_u) * fb, k, dev.data_ptr() + ((k + 1) % n_u) * fb)
+    pipe.sync()
+    tracked, pose, status, iters = pipe.track_result()
+    n_last = pipe.stats()["updated_last"]
+    pipe.close()
+    return pose, n_last, tracked
 
 
 def env_knobs():
@@ -156,10 +197,10 @@ def single_gpu_reference(name, n_frames=50, warmup=10, n_unique=None, overrides=
 
 
 def steady_state(name, n_timed=100):
-    """The same stream after max_weight frames: free space the camera keeps looking through has saturated at (tsdf 1, weight
-    max_weight), one more free-space observation of it is the identity, and the fusion pass no longer reads or writes it
-    (integrate.hip, k_integrate_pairs<.., SAT>).  Reported next to -- never instead of -- the early-regime numbers: frames/s, the
-    fusion kernel's time, and the reference's bytes (N_upd x 16 B + the depth image) over that time."""
+    """The same stream after max_weight + 32 frames: free space the camera keeps looking through has saturated at (tsdf 1, weight
+    max_weight); ANY free-space observation of a saturated quarter brick is the identity (before saturation only whole-quarter
+    observations are deferred: integrate.hip, k_integrate_pairs<.., DEFER>).  Reported next to the headline: frames/s, the fusion
+    kernel's time, the reference's bytes (N_upd x 16 B + the depth image) over that time -- not an HBM rate -- and what the kernel moves."""
     import torch
     from hybkinectfu_amd.pipeline import SingleGpuPipeline
     wl = workload(1, name)
@@ -186,25 +227,64 @@ def steady_state(name, n_timed=100):
     alg = n_upd * 16.0 + cam[0] * cam[1] * 4.0
     k_ms = float(ms[5]) / max(int(cnt[5]), 1)
     out = dict(workload=wl["desc"], frames_fused_before=n_pre, steps=n_timed, value=round(n_timed / dt, 2), unit="frames/s",
-               frames_lost=int(s1["frames_lost"] - s0["frames_lost"]), kernel="k_integrate_pairs<.., SAT>", kernel_ms=round(k_ms, 5),
+               frames_lost=int(s1["frames_lost"] - s0["frames_lost"]), kernel=("k_integrate_pairs<.., DEFER> past saturation" if wl["res"] >= 768 else "k_integrate_pairs (plain: volumes below 768^3 do not defer by default)"), kernel_ms=round(k_ms, 5),
                launches_timed=int(cnt[5]), reference_bytes_per_launch=int(alg),
                reference_bytes_rate=round(alg / (k_ms * 1e-3) / 1e9, 2) if k_ms > 0 else None, unit_rate="GB/s",
                reference_bytes_rate_over_peak=round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
                note="reference_bytes = what the REFERENCE's update moves for these frames (N_upd x 16 B + the depth image); the kernel itself moves fewer -- "
-                    "saturated free space is counted, not touched -- so reference_bytes_rate is NOT an HBM rate and may exceed the 8 TB/s peak; "
+                    "deferred / saturated free space is counted, not touched -- so reference_bytes_rate is NOT an HBM rate and may exceed the 8 TB/s peak; "
                     "kernel_traffic_* is what the kernel really moves")
     # what the SAT kernel really moves per launch: rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, separate passes) from the builder's own profile run
     tpath = os.path.join(ROOT, "profiles", "integrate_traffic.json")
     try:
         tj = json.load(open(tpath))
-        tr = tj.get(wl["name"] + "_sat")
+        tr = tj.get(wl["name"] + "_saturated")
     except Exception:
         tj, tr = {}, None
     out["kernel_traffic_bytes_per_launch"] = tr
     out["kernel_traffic_rate"] = round(tr / (k_ms * 1e-3) / 1e9, 2) if (tr and k_ms > 0) else None
     out["kernel_traffic_frac_of_hbm_peak"] = round(tr / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (tr and k_ms > 0) else None
-    out["kernel_traffic_source"] = tj.get("source_sat") if tr else None
+    out["kernel_traffic_source"] = tj.get("source") if tr else None
     return out
+
+
+def scene_noise_block(wl, n_frames=110, warmup=10):
+    """The headline workload on a NOISY stream: Scene S with the LCG-12345 sensor noise of scene.add_sensor_noise (axial noise growing with depth,
+    2 % drop-outs).  Every other number of the line comes from the noise-free scene, and several tuning constants were fitted to it; this block
+    says what the same pipeline does when bilateral early returns, ICP rejections, ray stragglers and partial fusion waves look like a sensor's.
+    Parity on these very frames: tests/test_gpu_parity.py::test_noisy_scene_parity."""
+    import torch
+    from hybkinectfu_amd.pipeline import SingleGpuPipeline
+    cam = wl["cam"]
+    frames, poses = S.make_stream(100, cam, wl["size"])
+    frames = S.add_sensor_noise(frames)
+    dev = torch.from_numpy(frames.astype(np.int16)).cuda()
+    fb = cam[0] * cam[1] * 2
+    pipe = SingleGpuPipeline(K.camera(*cam), wl["res"], wl["size"], wl, device=torch.cuda.current_device())
+    for k in range(warmup):
+        pipe.process_frame_device(dev.data_ptr() + (k % 100) * fb, k, dev.data_ptr() + ((k + 1) % 100) * fb)
+    pipe.sync(); torch.cuda.synchronize()
+    s0 = pipe.stats()
+    t0 = time.perf_counter()
+    for k in range(warmup, n_frames):
+        pipe.process_frame_device(dev.data_ptr() + (k % 100) * fb, k, dev.data_ptr() + ((k + 1) % 100) * fb)
+    pipe.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    s1 = pipe.stats()
+    tracked, pose, status, iters = pipe.track_result()
+    gt = poses[(n_frames - 1) % 100]
+    pipe.stage_timers(0x1F | (1 << 5))
+    for k in range(n_frames, n_frames + 40):
+        pipe.process_frame_device(dev.data_ptr() + (k % 100) * fb, k, dev.data_ptr() + ((k + 1) % 100) * fb)
+    pipe.sync()
+    sm, sc = pipe.read_stage_ms()
+    pipe.close()
+    return dict(workload=wl["desc"] + " + sensor noise (LCG seed 12345: sigma(z) = 1.2 mm + 1.9 mm/m^2 (z - 0.4 m)^2, 2 % drop-outs)",
+                value=round((n_frames - warmup) / dt, 2), unit="frames/s", steps=n_frames - warmup, ms_per_step=round(1000.0 * dt / (n_frames - warmup), 4),
+                frames_lost=int(s1["frames_lost"] - s0["frames_lost"]), tracked_last_frame=bool(tracked), iterations_last_frame=int(iters),
+                n_upd_per_frame=int((s1["updated_total"] - s0["updated_total"]) / max(n_frames - warmup, 1)),
+                distance_to_ground_truth_m=float(np.linalg.norm(np.asarray(pose, np.float64)[:3, 3] - gt[:3, 3])),
+                stage_us={STAGE_NAMES[i]: round(1000.0 * float(sm[i]) / max(int(sc[i]), 1), 2) for i in (1, 2, 3, 4, 5)})
 
 
 def stage_block(alg_bytes, stage_ms, how):
@@ -293,7 +373,16 @@ def pcie_inclusive(wl, frames_mm, n_frames=100, warmup=10):
                 note="every frame uploaded from host memory over PCIe inside the timed region (kf_upload_depth_mm)")
 
 
-def roofline_extra(pipe, run, first_frame, res, size, n_frames=20):
+def profiled_traffic(key):
+    """HBM-side bytes per launch from the builder's rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, profiles/integrate_traffic.json), or None"""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "integrate_traffic.json")))
+        return tj.get(key), tj.get("source")
+    except Exception:
+        return None, None
+
+
+def roofline_extra(pipe, run, first_frame, res, size, n_frames=20, wl_name="C2"):
     """Raycast and marching cubes against the HBM roofline, as SURVEY.md section 8d defines their bytes.
     raycast: what the REFERENCE's march would read -- 8 B per sample from t_min to the first crossing (or t_max) plus 64 voxels
     x 8 B per evaluated hit -- counted on the device (kf_read_work_counters) over n_frames extra frames, / the kernel's own time.
@@ -309,10 +398,17 @@ def roofline_extra(pipe, run, first_frame, res, size, n_frames=20):
     steps, hits, _, _ = c.work_counters()
     rc_ms = float(ms[7]) / max(int(cnt[7]), 1)
     rc_bytes = (steps * 8.0 + hits * 64 * 8.0) / n_frames
+    rc_traffic, tsrc = profiled_traffic(wl_name + "_raycast")
     out = dict(raycast=dict(kernel="k_raycast", bound="latency (L2 gathers)", ms=round(rc_ms, 5), reference_samples_per_frame=int(steps / n_frames),
-                            hits_per_frame=int(hits / n_frames), algorithmic_bytes_per_launch=int(rc_bytes),
-                            achieved=round(rc_bytes / (rc_ms * 1e-3) / 1e9, 2) if rc_ms > 0 else None, unit="GB/s",
-                            frac=round(rc_bytes / (rc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if rc_ms > 0 else None))
+                            hits_per_frame=int(hits / n_frames), reference_bytes_per_launch=int(rc_bytes),
+                            reference_bytes_rate=round(rc_bytes / (rc_ms * 1e-3) / 1e9, 2) if rc_ms > 0 else None, unit="GB/s",
+                            reference_bytes_rate_over_peak=round(rc_bytes / (rc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if rc_ms > 0 else None,
+                            kernel_traffic_bytes_per_launch=rc_traffic,
+                            kernel_traffic_rate=round(rc_traffic / (rc_ms * 1e-3) / 1e9, 2) if (rc_traffic and rc_ms > 0) else None,
+                            kernel_traffic_frac_of_hbm_peak=round(rc_traffic / (rc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (rc_traffic and rc_ms > 0) else None,
+                            kernel_traffic_source=tsrc if rc_traffic else None,
+                            note="reference_bytes = what the REFERENCE's march reads (8 B per sample + 64 voxels per hit); the kernel skips empty space through its "
+                                 "bit tables and moves far less: reference_bytes_rate is not an HBM rate"))
     c.marching_cubes(300.0 * size / res)             # untimed first call: allocates the extraction's scratch buffers
     c.clear_triangles()
     c.stage_timers((1 << 6) | (1 << 16))
@@ -325,9 +421,15 @@ def roofline_extra(pipe, run, first_frame, res, size, n_frames=20):
     out["marching_cubes"] = dict(kernels="k_mc_dilate + k_mc_codes + k_mc_sift + k_mc_list + k_mc_count + k_mc_scan_* + k_mc_emit_recs", bound="latency / launch (11 short kernels)",
                                  ms=round(mc_ms, 5), bricks_read=int(bricks), bricks_total=int((res // 8) ** 3), triangles=int(tris), touched_bytes=int(mc_bytes),
                                  dense_bytes=int(res ** 3 * 8 + tris * 72),
-                                 achieved=round(mc_bytes / (mc_ms * 1e-3) / 1e9, 2) if mc_ms > 0 else None, unit="GB/s",
-                                 frac=round(mc_bytes / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if mc_ms > 0 else None,
-                                 dense_equivalent_frac=round((res ** 3 * 8 + tris * 72) / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if mc_ms > 0 else None)
+                                 touched_bytes_rate=round(mc_bytes / (mc_ms * 1e-3) / 1e9, 2) if mc_ms > 0 else None, unit="GB/s",
+                                 touched_bytes_rate_over_peak=round(mc_bytes / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if mc_ms > 0 else None,
+                                 dense_reference_bytes_rate_over_peak=round((res ** 3 * 8 + tris * 72) / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if mc_ms > 0 else None,
+                                 note="touched_bytes = bricks read x 4 KiB + 72 B per triangle (counted on the device); dense_reference_bytes = R^3 x 8 B + triangles, what the "
+                                      "reference's dense sweep reads -- neither is a measured HBM rate")
+    mc_traffic, tsrc = profiled_traffic(wl_name + "_marching_cubes")
+    out["marching_cubes"].update(kernel_traffic_bytes_per_extraction=mc_traffic,
+                                 kernel_traffic_rate=round(mc_traffic / (mc_ms * 1e-3) / 1e9, 2) if (mc_traffic and mc_ms > 0) else None,
+                                 kernel_traffic_source=tsrc if mc_traffic else None)
     c.clear_triangles()
     c.stage_timers(0)
     return out
@@ -569,44 +671,71 @@ def main():
         n_upd_all = n_upd
     fps = args.steps / dt
 
-    # roofline of the dominant HBM kernel (k_integrate_pairs, the fusion pass): algorithmic bytes per launch / measured duration
-    launches = int(cnt[5])
-    kern_ms = float(ms[5]) / max(launches, 1)
+    # ---- roofline of the dominant HBM kernel: the fusion pass k_integrate_pairs ----
+    # The timed region runs the kernel with deferred free-space weights (DEFER): it provably does not move the reference's bytes, so the
+    # reference's bytes over ITS time is not an HBM rate.  The roofline fraction is therefore measured on the PLAIN read-modify-write form of
+    # the same kernel (kf_set_defer(0)), live, on the frames that follow the timed region in the same pipeline: algorithmic bytes (N_upd x 16 B
+    # + the depth image) / the kernel's own dispatch time.  The DEFER kernel of the timed region is reported beside it
+    # with what it really moves (PMC traffic from the builder's rocprofv3 passes) over its live time.
+    defer_launches = int(cnt[5])
+    defer_ms = float(ms[5]) / max(defer_launches, 1)
     stage_ms = float(ms[3]) / max(int(cnt[3]), 1)
+    n_upd_region = n_upd
+    sat_env = os.environ.get("KF_INTEGRATE_SAT", "1")      # (kf_defer_enabled, integrate.hip: by default volumes of 768^3 and finer defer)
+    deferral_on = (sat_env == "2" or (sat_env == "1" and res >= 768)) and os.environ.get("KF_INTEGRATE_PAIRS", "1") != "0" and not wl.get("color")
+    plain_frames = 24 if res <= 1024 else 12
+    pipe.ctx.set_defer(0)
+    run(base + args.warmup + args.steps, 2)                 # the first plain launch is preceded by the flush of every pending count
+    barrier()
+    sp0 = pipe.stats()
+    pipe.stage_timers((2 << 8) | (1 << 5))
+    run(base + args.warmup + args.steps + 2, plain_frames)
+    barrier()
+    pms, pcnt = pipe.read_stage_ms()
+    sp1 = pipe.stats()
+    pipe.stage_timers(0)
+    pipe.ctx.set_defer(-1)
+    run(base + args.warmup + args.steps + 2 + plain_frames, 3)     # the deferred states are re-established before any other leg
+    barrier()
+    after_roofline = base + args.warmup + args.steps + 5 + plain_frames
+    launches = int(pcnt[5])
+    kern_ms = float(pms[5]) / max(launches, 1)
+    n_upd = (sp1["updated_total"] - sp0["updated_total"]) / float(plain_frames)
     roof_rank = 0
     if dist is not None and world > 1:
         # z-slabs are not equally busy (the camera's near slabs see a narrow frustum): quote the rank that fuses the most voxels
-        mine = torch.tensor([float(n_upd), kern_ms, float(launches), stage_ms], device="cuda", dtype=torch.float64)
+        mine = torch.tensor([float(n_upd), kern_ms, float(launches), stage_ms, defer_ms, float(defer_launches), float(n_upd_region)], device="cuda", dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         roof_rank = int(max(range(world), key=lambda r: float(every[r][0])))
-        n_upd, kern_ms, launches, stage_ms = (int(every[roof_rank][0].item()), float(every[roof_rank][1].item()),
-                                              int(every[roof_rank][2].item()), float(every[roof_rank][3].item()))
-    alg_bytes = (n_upd / max(args.steps, 1)) * 16.0 + cam[0] * cam[1] * 4.0       # N_upd x 2 x 8 B + depth map
+        e = every[roof_rank]
+        n_upd, kern_ms, launches, stage_ms, defer_ms, defer_launches, n_upd_region = (float(e[0].item()), float(e[1].item()), int(e[2].item()), float(e[3].item()),
+                                                                                       float(e[4].item()), int(e[5].item()), float(e[6].item()))
+    alg_bytes = n_upd * 16.0 + cam[0] * cam[1] * 4.0       # N_upd x 2 x 8 B + depth map
+    alg_region = (n_upd_region / max(args.steps, 1)) * 16.0 + cam[0] * cam[1] * 4.0
     if launches >= 5 and kern_ms > 0:
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "integrate_traffic.json")
-        if world == 1 and os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(wl["name"])
-                traffic_source = None if traffic is None else tj.get("source", "profiles/integrate_traffic.json (builder's rocprofv3 --pmc run, not measured in this run)")
-            except Exception:
-                traffic = None
+        traffic, traffic_source = profiled_traffic(wl["name"]) if world == 1 else (None, None)
         roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                        traffic=traffic, traffic_source=traffic_source, kernel="k_integrate_pairs", kernel_ms=round(kern_ms, 5),
-                        launches_timed=int(launches), rank=roof_rank, algorithmic_bytes_per_launch=int(alg_bytes),
-                        n_upd_per_frame=int(n_upd / max(args.steps, 1)),
-                        stage=stage_block(alg_bytes, stage_ms, "HIP events over the timed region"))
-        if base + args.warmup + args.steps > P["volume_max_weight"]:
-            # frames beyond max_weight run the saturation-aware kernels: `achieved` stays the REFERENCE's bytes over the kernel time
-            roofline["note"] = ("timed frames reach past max_weight = %d fused frames: saturated free space is counted but no longer read or "
-                                "written, so the reference's bytes per launch exceed what the kernel moves (DESIGN.md section 4, steady state)" % int(P["volume_max_weight"]))
-            roofline["traffic"], roofline["traffic_source"] = None, None
+                        traffic=traffic, traffic_source=traffic_source, kernel="k_integrate_pairs (plain read-modify-write form: deferral off)", kernel_ms=round(kern_ms, 5),
+                        launches_timed=int(launches), rank=roof_rank, algorithmic_bytes_per_launch=int(alg_bytes), n_upd_per_frame=int(n_upd),
+                        measured="live in this run, HIP events stamped by the kernel's own dispatch, every 2nd of the %d frames that follow the timed region in the same "
+                                 "pipeline with kf_set_defer(0) (the timed region itself runs the DEFER form: in_timed_region)" % plain_frames)
+        dtraffic, dsrc = profiled_traffic(wl["name"] + "_deferred") if world == 1 else (None, None)
+        roofline["in_timed_region"] = dict(
+            kernel="k_integrate_pairs<.., DEFER>" if deferral_on else "k_integrate_pairs (plain)", kernel_ms=round(defer_ms, 5), launches_timed=int(defer_launches),
+            reference_bytes_per_launch=int(alg_region),
+            reference_bytes_rate=round(alg_region / (defer_ms * 1e-3) / 1e9, 2) if defer_ms > 0 else None,
+            kernel_traffic_bytes_per_launch=dtraffic,
+            kernel_traffic_rate=round(dtraffic / (defer_ms * 1e-3) / 1e9, 2) if (dtraffic and defer_ms > 0) else None,
+            kernel_traffic_frac_of_hbm_peak=round(dtraffic / (defer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (dtraffic and defer_ms > 0) else None,
+            kernel_traffic_source=dsrc if dtraffic else None, unit="GB/s",
+            stage=dict(kernels="k_integrate_cull + k_integrate_pairs (whole integrate stage)", ms=round(stage_ms, 5)) if stage_ms > 0 else None,
+            note="whole free-space quarter bricks are counted, not read or written (deferred weights): reference_bytes_rate is the reference's bytes over this "
+                 "kernel's time, NOT an HBM rate; kernel_traffic_* is what the kernel moves (PMC, 2 x FETCH_SIZE + WRITE_SIZE)")
     else:
         roofline = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None, kernel="k_integrate_pairs",
-                        launches_timed=int(launches), refused="fewer than 5 timed launches of the kernel: run with --steps >= 5")
+                        launches_timed=int(launches), refused="fewer than 5 timed launches of the kernel")
 
     mesh = None
     if wl.get("extract_mesh"):
@@ -628,14 +757,15 @@ def main():
 
     n_before = base + args.warmup
     maxw = int(P["volume_max_weight"])
-    regime = ("pre-saturation" if n_before + args.steps <= maxw else "saturated" if n_before >= maxw else "mixed")
     out = dict(metric="depth frames/sec into TSDF (integrate+ICP+raycast)", value=round(fps, 2), unit="frames/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(1000.0 * dt / args.steps, 4), higher_is_better=True,
                scaling="weak" if world == 1 else "strong", vs_baseline=None, dtype="f32", data="synthetic",
-               regime=dict(name=regime, frames_fused_before_timed=n_before, timed_frames=args.steps, max_weight=maxw,
-                           note="pre-saturation: every timed frame runs before any voxel weight can have reached max_weight (plain fusion kernels); "
-                                "saturated: the saturation-aware kernels run (free space at (tsdf 1, weight max) is counted, not touched); "
-                                "`steady_state` reports that regime separately on the N=1 line"),
+               value_resident=round(fps, 2),
+               deferral=dict(enabled=deferral_on, frames_fused_before_timed=n_before, timed_frames=args.steps, max_weight=maxw,
+                             note="deferred free-space weights (integrate.hip, DEFER): from the second fused frame on, a quarter brick whose 128 voxels hold tsdf 1 and are "
+                                  "all observed as free space again is counted, not read or written; bit-identical results (tests/test_gpu_saturation.py, "
+                                  "tools/sat_equivalence.py).  Default: on for volumes of 768^3 and finer (1024^3 +46 %, 2048^3 +86 % frames/s), off below (512^3 with "
+                                  "the stock 2 m gate: -1.5 %, the fusion pass is not memory-bound there); kf_set_defer / KF_INTEGRATE_SAT=0|2 override"),
                config=dict(workload=wl["desc"], volume="%d^3 @ %g m" % (res, size), image="%dx%d" % (cam[0], cam[1]),
                            tracker=("CameraPoseFinderSDF (max %d iterations, device-resident)" % int(P["sdf_max_iter_nums"])
                                     if (wl.get("tracker") == "sdf" or (slab and args.tracker == "sdf")) else "ICP 10/5/4 (device-resident Gauss-Newton)"),
@@ -653,7 +783,7 @@ def main():
         out["mesh_extraction"] = mesh
     if slab and dist is not None:
         # z-slab runs: per-rank statistics over 20 extra frames, then the lock-step check (all ranks fused / lost the same frames, same pose bits)
-        out["per_rank"] = per_rank_leg(pipe, run, barrier, dist, world, rank, base + args.warmup + args.steps, 20)
+        out["per_rank"] = per_rank_leg(pipe, run, barrier, dist, world, rank, after_roofline, 20)
         out["lockstep"] = pipe.verify_lockstep()
         if world > 1 and args.config == "auto" and not args.no_c5:
             # the north star quotes 1024^3 AND 2048^3 for 1/2/4/8 GPUs: a short C5 block (2048^3 @ 8 m, 1280x960 depth, mesh extraction) on the same ranks
@@ -663,7 +793,7 @@ def main():
     if extras:
         # per-stage device time (HIP events around every stage, 50 extra frames outside the timed region)
         pipe.stage_timers(0x1F | (1 << 5))
-        run(base + args.warmup + args.steps, 50)
+        run(after_roofline, 50)
         pipe.sync()
         sm, sc = pipe.read_stage_ms()
         out["stage_us"] = {STAGE_NAMES[i]: round(1000.0 * float(sm[i]) / max(int(sc[i]), 1), 2) for i in (1, 2, 3, 4, 5)}
@@ -672,7 +802,7 @@ def main():
             out["roofline"]["stage"] = stage_block(out["roofline"]["algorithmic_bytes_per_launch"], float(sm[3]) / max(int(sc[3]), 1),
                                                    "HIP events on the 50 frames after the timed region (inside it only the kernel is timed)")
         pipe.stage_timers(0)
-        out["roofline_extra"] = roofline_extra(pipe, run, base + args.warmup + args.steps + 50, res, size)
+        out["roofline_extra"] = roofline_extra(pipe, run, after_roofline + 50, res, size, wl_name=wl["name"])
     if world == 1 and args.config == "auto" and not args.force_slab and not args.no_scaling_reference:
         pipe.close()
         out["multi_gpu_workload_on_1_gpu"] = single_gpu_reference("c4")      # what --gpus 2/4/8 should be compared with
@@ -690,10 +820,17 @@ def main():
     if extras:
         pipe.close()
         out["pcie_inclusive"] = pcie_inclusive(wl, frames)
+        # the metric's own wording includes the upload ("upload + preprocess + track + integrate + raycast"): both rates side by side
+        out["value_pcie_inclusive"] = out["pcie_inclusive"]["value"]
+        out["value_note"] = ("value = value_resident: frames already in HBM when the timed region starts (the bench contract); value_pcie_inclusive: every frame "
+                             "crosses PCIe inside the timed region (kf_upload_depth_mm), the metric's literal wording")
         out["steady_state"] = {"C2": steady_state("c2"), "C4": steady_state("c4")}
+        if args.config == "auto":
+            out["scene_noise"] = scene_noise_block(wl)
     if world == 1 and not args.no_cpu_baseline and not wl.get("extract_mesh"):      # (the oracle's 2048^3 volume would need 103 GB of host memory)
         pipe.close()
-        out["cpu_baseline"] = cpu_baseline(wl, frames, n_sample=150 if wl["res"] <= 512 else 40)      # 10-20 s of CPU work either way
+        n_sample = 150 if wl["res"] <= 512 else 40                                    # 10-20 s of CPU work either way
+        out["cpu_baseline"], out["parity_witness"] = cpu_baseline(wl, frames, n_sample=n_sample, witness=gpu_witness_run(wl, frames, n_sample))
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

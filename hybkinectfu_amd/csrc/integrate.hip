@@ -187,6 +187,10 @@ __global__ void __launch_bounds__(CULL_WAVES * 64) __attribute__((amdgpu_waves_p
   // depth test against the tile max over the brick's pixel footprint (only when the brick is clear of the eye plane)
   const float zn = pz - ez, zf = pz + ez;
   bool noop = false;                                                       // a brick retired here: its 512 voxels are counted, not visited
+  // DEFER: the brick's four deferred-weight words, requested before the depth tests so that they travel together with the tile maxima
+  // (behind them they were one more dependent round trip at the end of every surviving lane's chain)
+  const unsigned cull_slot = keep ? kf_brick_slot(v, bx, by, bz) : 0u;
+  const unsigned long long pp = DEFER ? v.pend[kf_opaque(cull_slot)] : 0ull;
   if (keep && zn > 4.f * cell) {
     const float xl = px - ex, xr = px + ex, yl = py - ey, yr = py + ey;
     float u0 = (xl < 0.f ? xl / zn : xl / zf) * a.dcam.fx + a.dcam.cx, u1 = (xr > 0.f ? xr / zn : xr / zf) * a.dcam.fx + a.dcam.cx;
@@ -219,8 +223,7 @@ __global__ void __launch_bounds__(CULL_WAVES * 64) __attribute__((amdgpu_waves_p
           // brick's far side -> every voxel passes the reference's predicate (:39-67), observes tsdf min(1, sdf / trunc) = 1, and
           // (1 * w + 1) / (w + 1) = 1 leaves the tsdf as it is; the weight's min(w + 1, max) is one more pending step of each quarter
           // (nothing at all once a quarter is saturated).  The brick is counted, not queued: no other wave touches it in this frame.
-          const unsigned slot = kf_brick_slot(v, bx, by, bz);
-          const unsigned long long pp = v.pend[slot];
+          const unsigned slot = cull_slot;
           const unsigned q0 = (unsigned)(pp & 0xFFFFull), q1 = (unsigned)((pp >> 16) & 0xFFFFull), q2 = (unsigned)((pp >> 32) & 0xFFFFull), q3 = (unsigned)(pp >> 48);
           if (q0 && q1 && q2 && q3) {
             const float* tmn = tbl + a.n_tile_floats;
@@ -677,21 +680,14 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
       }
       const float nw0 = fminf(ow1.x, v.max_weight), nw1 = fminf(ow1.y, v.max_weight);
       unsigned flags = 0;
-      // DEFER: what this lane knows of its two voxels afterwards.  A lane that loads nothing knows them through the quarter's word alone
-      // (p >= 1: tsdf 1, weight >= 1; whether saturated is not known)
-      bool lane_unit = DEFER && pnd[b] != 0u, lane_sat = false;
+      float4 r = make_float4(ot.x, ow.x, ot.y, ow.y);                       // the stored pair (with the pending steps applied, if any)
+      if (upd0[b]) { r.x = nt.x; r.y = nw0; }
+      if (upd1[b]) { r.z = nt.y; r.w = nw1; }
       if (rw[b]) {
-        float4 r = make_float4(ot.x, ow.x, ot.y, ow.y);                     // the stored pair (with the pending steps applied, if any)
-        if (upd0[b]) { r.x = nt.x; r.y = nw0; }
-        if (upd1[b]) { r.z = nt.y; r.w = nw1; }
         if (KF_EXP_MODE(a) == 0 || KF_EXP_MODE(a) >= 8 || r.x == 123.456f) *p[b] = r;     // experiments 1 / 2: no store
         if (COLOR) {
           const kf_f2 nz = {nz0[b], nz1[b]};
           *pc[b] = integrate_color_update2(qc[b], rgb0[b], rgb1[b], ow, nz, upd0[b], upd1[b], a.color_angled, r075);
-        }
-        if (DEFER) {
-          lane_unit = __float_as_uint(r.x) == one_f && __float_as_uint(r.z) == one_f && r.y >= 1.f && r.w >= 1.f;
-          lane_sat = lane_unit && __float_as_uint(r.y) == sat_w && __float_as_uint(r.w) == sat_w;
         }
       }
       if (upd0[b] || upd1[b]) {
@@ -725,9 +721,16 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
           atomicOr(&v.negbits[slot[b] >> 5], 1u << (slot[b] & 31u));
         }
       }
-      if (DEFER && wrote) {
-        // the quarter's word follows what this wave left behind: all 128 voxels known (every lane loaded, or the word vouches for the rest)
-        // and nothing but (tsdf 1, weight >= 1) -> deferred with nothing pending (saturated when every weight is max_weight); else plain
+      if (DEFER && wrote && (pnd[b] != 0u || __ballot(rw[b]) == ~0ull)) {
+        // The quarter's word follows what this wave left behind -- when that can be known: every lane loaded its pair, or the word vouches
+        // for the lanes that did not (p >= 1: tsdf 1, weight >= 1; whether saturated is not known).  All 128 voxels (tsdf 1, weight >= 1) ->
+        // deferred with nothing pending (saturated when every weight is max_weight); else plain.  (A wave of a plain quarter that loads
+        // only some of its lanes -- most band and silhouette waves -- skips all of this.)
+        bool lane_unit = pnd[b] != 0u, lane_sat = false;
+        if (rw[b]) {
+          lane_unit = __float_as_uint(r.x) == one_f && __float_as_uint(r.z) == one_f && r.y >= 1.f && r.w >= 1.f;
+          lane_sat = lane_unit && __float_as_uint(r.y) == sat_w && __float_as_uint(r.w) == sat_w;
+        }
         const bool all_unit = __ballot(lane_unit) == ~0ull, all_sat = __ballot(lane_sat) == ~0ull;
         const unsigned np = all_unit ? (all_sat ? KF_PEND_SAT : 1u) : 0u;
         if (np != pnd[b] && (threadIdx.x & 63) == 0) pend16[slot[b] * 4u + quarter] = (unsigned short)np;
@@ -778,13 +781,18 @@ static inline KfCam to_cam(const kf_camera_params* p) {
   KfCam c; c.cols = (int)p->cols; c.rows = (int)p->rows; c.cx = p->cx; c.cy = p->cy; c.fx = p->fx; c.fy = p->fy; return c;
 }
 
-// KF_INTEGRATE_SAT=0: never defer (the plain fusion kernel on every frame: what the roofline line is measured on); default: deferral from the first frame
+// Does this context defer whole-quarter free-space weight updates?  kf_set_defer(ctx, 0 | 1) decides when called; otherwise KF_INTEGRATE_SAT
+// (0: never, 2: always) and, by default, the volume's resolution: 768^3 and finer.  Measured on Scene S (profiles/r04_deferred_weights.txt, same
+// box): 1024^3 @ 6 m 1.83 k -> 2.67 k frames/s, 2048^3 @ 8 m 356 -> 663, but 512^3 @ 4 m with the stock 2 m integration gate 4.98 k -> 4.89 k --
+// there the fusion pass is start-up + instruction issue, not memory, two thirds of its waves are silhouette / band waves that
+// cannot defer, and the deferred form's bookkeeping (+2 us kernel, +1.4 us cull) is all that shows.  Results are bit-identical either way.
 bool kf_defer_enabled(const kf_ctx* c) {
   static int sat_env = -1, pairs_env = -1;
   if (sat_env < 0) { const char* e = getenv("KF_INTEGRATE_SAT"); sat_env = e ? atoi(e) : 1; }
   if (pairs_env < 0) { const char* e = getenv("KF_INTEGRATE_PAIRS"); pairs_env = e ? atoi(e) : 1; }
-  if (c->defer_override >= 0) return c->defer_override != 0 && pairs_env && c->vol.pend && c->vol.max_weight >= 1.f && c->vol.max_weight <= KF_PEND_MAX_WEIGHT;
-  return sat_env != 0 && pairs_env != 0 && c->vol.pend && c->vol.max_weight >= 1.f && c->vol.max_weight <= KF_PEND_MAX_WEIGHT;
+  if (!pairs_env || !c->vol.pend || !(c->vol.max_weight >= 1.f && c->vol.max_weight <= KF_PEND_MAX_WEIGHT)) return false;
+  if (c->defer_override >= 0) return c->defer_override != 0;
+  return sat_env == 2 || (sat_env == 1 && c->vol.res >= 768);
 }
 
 // every pending count applied to its 128 voxels (one wave per brick); the words drop to "nothing pending" and stay valid
@@ -890,7 +898,10 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
     resident4 = cus * (unsigned)per_cu4;
   }
   const bool big = c->n_stored_bricks >= ((size_t)1 << 20);
-  const unsigned grid_cap = grid_env != 1u ? grid_env : (big && !has_color ? 8u * resident4 : (has_color ? 8192u : resident));
+  // DEFER: one brick in flight whatever the size -- most waves end without touching a voxel, so there is little memory latency to cover and
+  // the four-brick form's extra registers (85 VGPRs + scalar spills) only cost: 1024^3 181 -> 130 us, 2048^3 795 -> 577 us (BR 4 x 12288 vs
+  // BR 1 x 8192 workgroups; BR 1 x 2048 157, x 4096 135, x 16384 132 us at 1024^3: profiles/r04_deferred_weights.txt)
+  const unsigned grid_cap = grid_env != 1u ? grid_env : (defer ? (big ? 4u * resident : resident) : (big && !has_color ? 8u * resident4 : (has_color ? 8192u : resident)));
   unsigned grid = (unsigned)(c->n_stored_bricks < grid_cap ? c->n_stored_bricks : grid_cap);
   // the roofline kernel's live timer: the event pair rides on the dispatch itself (kf_evt_attach), so what is measured is the kernel, as rocprofv3 sees it
   hipEvent_t ke0 = nullptr, ke1 = nullptr;
@@ -911,7 +922,7 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
     // bricks in flight per workgroup (see the grid above): 1, or 4 for large volumes.  KF_INTEGRATE_BR overrides.
     static int br_env = -1;
     if (br_env < 0) { const char* e = getenv("KF_INTEGRATE_BR"); br_env = e ? atoi(e) : 0; if (br_env != 1 && br_env != 2 && br_env != 4) br_env = 0; }
-    const int br = br_env ? br_env : (big ? 4 : 1);
+    const int br = br_env ? br_env : ((big && !defer) ? 4 : 1);
     static int pairs = -1;                               // 1 (default): the packed-pair kernel; 0: the scalar one (A/B and colour path)
     if (pairs < 0) { const char* e = getenv("KF_INTEGRATE_PAIRS"); pairs = e ? atoi(e) : 1; }
 #ifdef KF_EXPERIMENTS

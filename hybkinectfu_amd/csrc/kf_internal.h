@@ -89,7 +89,9 @@ struct KfTrackState {
   int   iterations;
   int   converged;       // SDF tracker: |x| < 1e-3 reached
   unsigned arrive;       // arrival counter of the persistent ICP loop's grid barrier (monotonic within a frame)
-  unsigned pad_[3];
+  unsigned rescue_tag;   // persistent ICP loop: tag_base of the last launch that timed out waiting and was finished by ONE workgroup alone (track.hip)
+  int      rescued;      // the committed verdict of the last tracking call comes from that solo finish (kf_track_result::launch_form 3)
+  unsigned pad_[1];
   float pose_inv[16];    // pose.getInverse(), written wherever pose is committed: integrate reads it (integrateVolume.cu:84)
 };
 
@@ -168,6 +170,8 @@ struct kf_ctx {
   // the persistent ICP loop after a stall (KF_TRACK_STALLED: some of its workgroups were not resident -- a foreign process on the GPU):
   // `persistent_backoff` frames track with one launch per step, then the loop is tried again; every further stall doubles the wait
   int persistent_backoff, persistent_backoff_len;
+  int loop_clean_frames;              // loop launches since the last stall was noted (1024 in a row forget the back-off history)
+  int inject_stall;                   // kf_inject_track_stall: loop launches that still get a workgroup playing dead
   int loop_refused;                   // the device cannot hold the loop's workgroups at once (occupancy check / cooperative launch refused): never tried again
   int loop_occupancy;                 // workgroups of k_icp_loop one CU can hold (0: not asked yet)
   int last_track_form;                // kf_track_result::launch_form of the last tracking call

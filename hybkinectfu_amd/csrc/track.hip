@@ -519,9 +519,10 @@ __host__ __device__ static inline void icp_level_geometry(int npx, int loop_grid
 // index of this lane's j-th pixel: pixels are dealt to the grid_l workgroups in 64-pixel chunks, round robin -- every workgroup sees
 // the same mix of surface and background, so they all reach the exchange of partial sums at about the same time (contiguous blocks
 // did not)
-__device__ __forceinline__ int icp_dealt_pixel(int j, int grid_l) {
-  return (((int)(threadIdx.x >> 6) * grid_l + (int)blockIdx.x) + j * ((ICP_THREADS / 64) * grid_l)) * 64 + (int)(threadIdx.x & 63);
+__device__ __forceinline__ int icp_dealt_pixel_of(int j, int grid_l, int wg) {
+  return (((int)(threadIdx.x >> 6) * grid_l + wg) + j * ((ICP_THREADS / 64) * grid_l)) * 64 + (int)(threadIdx.x & 63);
 }
+__device__ __forceinline__ int icp_dealt_pixel(int j, int grid_l) { return icp_dealt_pixel_of(j, grid_l, (int)blockIdx.x); }
 // one Gauss-Newton step's pixel phase for this lane's (up to ICP_PX) pixels: correspondences + the 27 products, fused accumulation
 __device__ __forceinline__ void icp_accumulate(const TrackArgs& a, const float* s_cur, const float* s_linv, const float4 iv[ICP_PX], const float4 in_[ICP_PX],
                                                const float4* __restrict__ model_v, const float4* __restrict__ model_n, float acc[27]) {
@@ -615,6 +616,7 @@ struct IcpLoopArgs {
   KfTrackState* track;
   unsigned* stall_word;                          // pinned host word: set when the loop gives up waiting, polled by the next kf_icp_track
   int exp_mode;                                  // diagnostics only (KF_ICP_EXP): 1 = skip the solve (timing), 7 = shader-clock stamps per phase
+  int play_dead;                                 // fault injection (kf_inject_track_stall): this workgroup exits at once, as if it had never become resident
   // Riders: workgroups [n_loop, gridDim.x) do not take part in the loop -- they carry the NEXT frame's u16 -> f32 + gate + bilateral filter
   // (kf_prefetch_frame, requested before kf_icp_track).  The loop keeps one workgroup on each of ~200 CUs busy for ~0.14 ms at two waves per
   // SIMD and leaves the other CUs idle; the riders are dispatched behind the loop's workgroups (they cannot displace them), wait for
@@ -623,7 +625,10 @@ struct IcpLoopArgs {
   KfBilateralArgs bil; int bil_gx, bil_tiles, bil_fast;
 };
 
-#define ICP_SPIN_LIMIT 8192u            // polls (~1-1.5 us each: about 10 ms) before a workgroup gives up: a legitimate wait is tens of microseconds
+// A workgroup gives up waiting for the others' partial sums after ICP_WAIT_LIMIT ticks of the 100 MHz wall clock (s_memrealtime) = 20 ms -- a
+// legitimate wait is tens of microseconds; the clock is read every 64th poll (~1-1.5 us each).  Giving up costs latency, not the frame: one
+// workgroup then finishes the frame's Gauss-Newton loop alone (icp_solo_finish below), with the same bits.
+#define ICP_WAIT_LIMIT 2000000ull
 #define ICP_FOLD_BATCH 13
 #ifndef KF_ICP_POLL_PIPE
 #define KF_ICP_POLL_PIPE 2        // s_sleep between the two polls kept in flight (0 is not a value: -DKF_ICP_POLL_SINGLE selects the one-poll loop)
@@ -633,9 +638,11 @@ struct IcpLoopArgs {
 // reader needs no barrier and no flag: it polls the words it is about to add until their tags are current.  The adds run
 // in a fixed order (workgroup-major within a part, then the parts): every workgroup of the loop arrives at the same bits.  The
 // per-step launch form (k_icp_step) deals pixels to workgroups differently, so the two forms agree to tolerance, not bitwise.
-__device__ __forceinline__ void fold_partials_tagged(const unsigned long long* slots, int n_wg, unsigned tag, float* s_tot, int* s_abort, int exp_mode = 0) {
+__device__ __forceinline__ void fold_partials_tagged(const unsigned long long* slots, int n_wg, unsigned tag, float* s_tot, int* s_abort, int exp_mode = 0,
+                                                     const unsigned* rescue_tag = nullptr, unsigned tag_base = 0u) {
   const int k = threadIdx.x & 31, part = threadIdx.x >> 5, parts = blockDim.x >> 5;
   float s = 0.f;
+  unsigned long long t_wait0 = 0ull;
   if (k < 27) {
     for (int w0 = part; w0 < n_wg; w0 += ICP_FOLD_BATCH * parts) {
       float v[ICP_FOLD_BATCH];
@@ -665,7 +672,12 @@ __device__ __forceinline__ void fold_partials_tagged(const unsigned long long* s
 #pragma unroll
         for (int j = 0; j < ICP_FOLD_BATCH; ++j) stale |= (unsigned)(u[0][j] >> 32) ^ tag;
         if (stale == 0u) break;
-        if (++spins > ICP_SPIN_LIMIT) { *s_abort = 1; break; }
+        if ((++spins & 63u) == 0u) {
+          // (somebody else of this launch already gave up and one workgroup is finishing the frame alone: nothing more will be published)
+          if (rescue_tag && __hip_atomic_load(rescue_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag_base) { *s_abort = 1; break; }
+          const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+          if (t_wait0 == 0ull) t_wait0 = now; else if (now - t_wait0 > ICP_WAIT_LIMIT) { *s_abort = 1; break; }
+        }
 #pragma unroll
         for (int d = 0; d + 1 < KF_ICP_POLL_DEPTH; ++d)
 #pragma unroll
@@ -691,7 +703,10 @@ __device__ __forceinline__ void fold_partials_tagged(const unsigned long long* s
         }
         if (ok) break;
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > ICP_SPIN_LIMIT) { *s_abort = 1; break; }                   // never spin forever: report instead
+        if ((++spins & 63u) == 0u) {                                             // never spin forever
+          const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+          if (t_wait0 == 0ull) t_wait0 = now; else if (now - t_wait0 > ICP_WAIT_LIMIT) { *s_abort = 1; break; }
+        }
       }
 #endif
 #pragma unroll
@@ -701,6 +716,90 @@ __device__ __forceinline__ void fold_partials_tagged(const unsigned long long* s
   s_tot[part * 32 + k] = s;
   fold_combine_parts(s_tot, parts);       // the parts' sums, in the order the per-step fold uses too
 }
+
+
+// ---- a loop that timed out is finished by ONE workgroup ---------------------------------------------------------------------------------
+// The loop's workgroups wait for each other, so they must all be resident; when some are not (a foreign process holds CUs -- the cross-process
+// registry of ctx.hip only sees processes of this library) a fold times out.  The frame is NOT given up: the first workgroup to time out claims
+// the launch (rescue_tag), everybody else leaves (workgroups dispatched later see the claim and leave at once), and the claimant runs the whole
+// Gauss-Newton loop of this frame again by itself, playing every workgroup of the launch in turn: the same pixel dealing (icp_dealt_pixel_of),
+// the same pixel phase (icp_accumulate), the same workgroup reduction (icp_wg_reduce), its partial sums published into the same tagged slots and
+// folded by the same fold -- hence the SAME BITS as the loop or the per-step form would have produced (tests/test_gpu_track_forms.py injects the
+// fault).  It costs milliseconds (one CU walks all pixels 19 times), not the frame; the host backs off to per-step launches afterwards.
+// Not inlined: the hot kernel's register allocation stays what it was.
+__device__ __forceinline__ void icp_solo_finish(const IcpLoopArgs& L, float (*s_pose)[16], float* s_linv, float* s_wave, float* s_tot, int* s_abort) {
+  KfTrackState* st = L.track;
+  int cur_buf = 0;
+  float* s_cur = s_pose[0];
+  if (threadIdx.x < 16) s_cur[threadIdx.x] = st->pose[threadIdx.x];            // from the committed pose again (ICP.cpp:62): nothing of the attempt is kept
+  if (threadIdx.x == 0) *s_abort = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) kf_mat44_inverse(s_cur, s_linv);
+  __syncthreads();
+  TrackArgs a;
+  a.dist_thres = L.dist_thres; a.sin_thres = L.sin_thres; a.dist_shake = L.dist_shake; a.angle_shake = L.angle_shake; a.cos_shake = L.cos_shake; a.dist_shake2 = L.dist_shake2;
+  a.dist_thres2 = L.dist_thres2; a.sin_thres2 = L.sin_thres2; a.sdf = 0;
+#ifdef KF_EXPERIMENTS
+  a.dbg = nullptr; a.exp_nodet = false;
+#endif
+  int step = 0, n_prev = 0, applied = 0, code = STEP_APPLIED;
+  for (int l = L.levels - 1; l >= 0 && code == STEP_APPLIED; --l) {
+    a.cam = L.cam[l];
+    const float4* __restrict__ new_v = L.new_v[l]; const float4* __restrict__ new_n = L.new_n[l];
+    const int npx = a.cam.cols * a.cam.rows;
+    int px_l, grid_l;
+    icp_level_geometry(npx, L.n_loop, l, px_l, grid_l);
+    for (int it = 0; it < L.iters[l]; ++it, ++step) {
+      if (step > 0) {
+        fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, s_abort);
+        code = apply_step(a, s_tot, s_cur, nullptr, s_pose[cur_buf ^ 1]);
+        if (code != STEP_APPLIED) break;
+        cur_buf ^= 1; s_cur = s_pose[cur_buf];
+        ++applied;
+      }
+      for (int w = 0; w < grid_l; ++w) {                                       // every workgroup of the launch, one after the other
+        float4 iv[ICP_PX], in_[ICP_PX];
+#pragma unroll
+        for (int j = 0; j < ICP_PX; ++j) {
+          const int i = icp_dealt_pixel_of(j, grid_l, w);
+          iv[j] = make_float4(0.f, 0.f, 0.f, 0.f); in_[j] = iv[j];
+          if (j < px_l && i < npx) { iv[j] = new_v[i]; in_[j] = new_n[i]; }
+        }
+        float acc[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+        icp_accumulate(a, s_cur, s_linv, iv, in_, L.model_v[l], L.model_n[l], acc);
+        int k; float sw;
+        if (icp_wg_reduce(acc, s_wave, k, sw))
+          __hip_atomic_store(L.slots + (size_t)step * KF_ICP_LOOP_MAX_WG * 32 + w * 32 + k,
+                             ((unsigned long long)(L.tag_base + (unsigned)step) << 32) | (unsigned long long)__float_as_uint(sw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                                       // s_wave is reused by the next turn
+      }
+      n_prev = grid_l;
+    }
+  }
+  if (code == STEP_APPLIED) {                                                  // the last step's system, then commit _pose (ICP.cpp:84)
+    fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, s_abort);
+    code = apply_step(a, s_tot, s_cur, nullptr, s_pose[cur_buf ^ 1]);
+    if (code == STEP_APPLIED) { cur_buf ^= 1; s_cur = s_pose[cur_buf]; }
+    if (threadIdx.x < 27) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
+  }
+  if (code != STEP_APPLIED) { if (threadIdx.x == 0) { st->status = code; st->tracked = 0; st->iterations = applied; st->converged = 0; st->rescued = 1; } return; }
+  if (threadIdx.x < 16) st->pose[threadIdx.x] = s_cur[threadIdx.x];
+  if (threadIdx.x == 64) kf_mat44_inverse(s_cur, st->pose_inv);
+  if (threadIdx.x == 0) { st->status = KF_TRACK_OK; st->tracked = 1; st->iterations = applied + 1; st->converged = 0; st->rescued = 1; }
+}
+// a fold of the loop timed out (uniform: every lane of the workgroup is here): claim the launch or leave
+#define ICP_ON_ABORT() do { \
+    if (threadIdx.x == 0) { \
+      const unsigned old_ = atomicExch(&st->rescue_tag, L.tag_base); \
+      s_abort = (old_ != L.tag_base) ? 2 : 1;                      /* 2: this workgroup is the first to give up -> it finishes the frame alone */ \
+      if (s_abort == 2) __hip_atomic_store(L.stall_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+    } \
+    __syncthreads(); \
+    if (s_abort == 2) icp_solo_finish(L, s_pose, s_linv, s_wave, s_tot, &s_abort); \
+    return; \
+  } while (0)
 
 __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   if ((int)blockIdx.x >= L.n_loop) {                                           // a rider: two 64x4 filter tiles (bilateral_tile.h), then done
@@ -718,7 +817,13 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   int s_code = STEP_APPLIED, cur_buf = 0;
   float* s_cur = s_pose[0];
   KfTrackState* st = L.track;
-  if (threadIdx.x < 16) s_cur[threadIdx.x] = st->pose[threadIdx.x];            // ICP.cpp:62 cur_transform = _pose
+  // a workgroup that only becomes resident after the launch has been given up (icp_solo_finish above) has nothing to do; `play_dead`: fault
+  // injection (kf_inject_track_stall) -- the last workgroup behaves as if it never became resident
+  // (the pose and the claim word are requested together: one round trip)
+  const float pose_e = st->pose[threadIdx.x & 15];                             // ICP.cpp:62 cur_transform = _pose
+  if (__hip_atomic_load(&st->rescue_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == L.tag_base) return;
+  if (L.play_dead && (int)blockIdx.x == L.n_loop - 1) return;
+  if (threadIdx.x < 16) s_cur[threadIdx.x] = pose_e;
   if (threadIdx.x == 0) s_abort = 0;
   __syncthreads();
   if (threadIdx.x == 0) kf_mat44_inverse(s_cur, s_linv);                        // ICP.cpp:63 last_transform_inv
@@ -731,6 +836,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   a.exp_nodet = KF_EXP_MODE(L) == 12;
 #endif
   int step = 0, n_prev = 0, applied = 0;
+  bool timed_out = false;                        // a fold gave up waiting: leave both loops, see ICP_ON_ABORT (one copy of the solo finish)
   // diagnostic build path (KF_ICP_EXP=7): workgroup 0 accumulates shader-clock ticks per segment into track->reduced
   const bool stamp = KF_EXP_MODE(L) == 7 && blockIdx.x == 0 && threadIdx.x == 0;
   unsigned long long t_last = 0; float seg[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -758,8 +864,8 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     for (int it = 0; it < L.iters[l]; ++it, ++step) {
       KF_STAMP(0);
       if (step > 0) {
-        fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, (KF_EXP_MODE(L) == 2 && n_prev > 16) ? 16 : n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort, KF_EXP_MODE(L));
-        if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; __hip_atomic_store(L.stall_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } return; }
+        fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, (KF_EXP_MODE(L) == 2 && n_prev > 16) ? 16 : n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort, KF_EXP_MODE(L), &st->rescue_tag, L.tag_base);
+        if (s_abort) { timed_out = true; break; }
         KF_STAMP(1);
 #ifdef KF_EXPERIMENTS
         if (KF_EXP_MODE(L) == 9 && blockIdx.x == 5 && (threadIdx.x & 63) == 0)     // per-wave: fold of the previous step done
@@ -771,7 +877,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
         if (KF_EXP_MODE(L) == 1) { s_code = STEP_APPLIED; __syncthreads(); } else     // timing only: skip the 6x6 solve
         { s_code = apply_step(a, s_tot, s_cur, nullptr, s_pose[cur_buf ^ 1]); if (s_code == STEP_APPLIED) { cur_buf ^= 1; s_cur = s_pose[cur_buf]; } }
         if (s_code != STEP_APPLIED) {                                            // same verdict in every workgroup
-          if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; }
+          if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; st->converged = 0; st->rescued = 0; }
           return;
         }
         ++applied;
@@ -805,19 +911,20 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
 #endif
       n_prev = grid_l;
     }
+    if (timed_out) break;
   }
   if (stamp) { for (int i = 0; i < 6; ++i) st->reduced[20 + i] = seg[i]; }
   // the last step's system, then commit _pose (ICP.cpp:84)
-  fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort);
-  if (s_abort) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; __hip_atomic_store(L.stall_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } return; }
+  if (!timed_out) fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort, 0, &st->rescue_tag, L.tag_base);
+  if (timed_out || s_abort) ICP_ON_ABORT();
   s_code = apply_step(a, s_tot, s_cur, nullptr, s_pose[cur_buf ^ 1]);
   if (s_code == STEP_APPLIED) { cur_buf ^= 1; s_cur = s_pose[cur_buf]; }
   if (blockIdx.x != 0) return;
   if (threadIdx.x < 27 && KF_EXP_MODE(L) != 7) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
-  if (s_code != STEP_APPLIED) { if (threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; } return; }
+  if (s_code != STEP_APPLIED) { if (threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; st->converged = 0; st->rescued = 0; } return; }
   if (threadIdx.x < 16) st->pose[threadIdx.x] = s_cur[threadIdx.x];
   if (threadIdx.x == 64) kf_mat44_inverse(s_cur, st->pose_inv);               // a lane of another wave: the integrate pass reads it (integrateVolume.cu:84)
-  if (threadIdx.x == 0) { st->status = KF_TRACK_OK; st->tracked = 1; st->iterations = applied + 1; }    // (status: this launch may have run without k_track_begin's reset)
+  if (threadIdx.x == 0) { st->status = KF_TRACK_OK; st->tracked = 1; st->iterations = applied + 1; st->converged = 0; st->rescued = 0; }    // (the whole verdict: this launch may have run without k_track_begin's reset)
 }
 
 // ---- SDF tracker ------------------------------------------------------------------------------------------------------
@@ -899,7 +1006,7 @@ __global__ void __launch_bounds__(TRK_THREADS) k_sdf_step(TrackArgs a) {
 __global__ void k_track_begin(KfTrackState* st, int mode, KfGridBarrier* gb) {
   if (blockIdx.x == 0 && threadIdx.x < 10 && gb) reinterpret_cast<KfPaddedCounter*>(gb)[threadIdx.x].v = 0u;   // 8 groups + top + gen
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  st->status = KF_TRACK_OK; st->iterations = 0; st->converged = 0; st->arrive = 0u;
+  st->status = KF_TRACK_OK; st->iterations = 0; st->converged = 0; st->arrive = 0u; st->rescued = 0;
   if (mode == 0) { st->tracked = 1; return; }
   st->tracked = 0;
   for (int i = 0; i < 16; ++i) st->cur[0][i] = st->pose[i];                 // ICP.cpp:62
@@ -1003,10 +1110,14 @@ extern "C" int kf_read_solver_params(kf_ctx* c, float out27[27]) {
 #ifndef KF_ICP_COOPERATIVE_DEFAULT
 #define KF_ICP_COOPERATIVE_DEFAULT 0
 #endif
-// a persistent loop reported KF_TRACK_STALLED: back off to per-step launches for a while (64 frames, doubling up to 4096 on repeats)
+// a persistent loop timed out and was finished by one workgroup alone (icp_solo_finish: the frame is kept, milliseconds late): back off to
+// per-step launches for a while (64 frames, doubling up to 4096 on repeats; 1024 clean loop frames in a row forget the history).  One episode
+// is noted once: launches of the loop that were already enqueued when the word was seen raise it again while the back-off is running.
 static void kf_note_loop_stall(kf_ctx* c) {
+  if (c->persistent_backoff > 0) return;
   c->persistent_backoff_len = c->persistent_backoff_len ? (c->persistent_backoff_len >= 2048 ? 4096 : c->persistent_backoff_len * 2) : 64;
   c->persistent_backoff = c->persistent_backoff_len;
+  c->loop_clean_frames = 0;
 }
 
 extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* icp, const kf_camera_params* cam0) {
@@ -1035,6 +1146,7 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   // k_icp_step); after `persistent_backoff_len` of them the loop is tried again, and every further stall doubles that wait.
   unsigned* stall_word = (unsigned*)((char*)c->host_pinned + KF_PINNED_STALL_WORD);
   if (__atomic_load_n(stall_word, __ATOMIC_RELAXED)) { __atomic_store_n(stall_word, 0u, __ATOMIC_RELAXED); kf_note_loop_stall(c); }
+  else if (c->persistent_backoff == 0 && c->persistent_backoff_len && ++c->loop_clean_frames >= 1024) { c->persistent_backoff_len = 0; c->loop_clean_frames = 0; }
   bool use_loop = persistent_env && !c->loop_refused && grid0 <= KF_ICP_LOOP_MAX_WG && iters[0] + iters[1] + iters[2] <= KF_ICP_LOOP_STEPS &&
                   kf_live_contexts(c->cfg.device) == 1 && !kf_device_shared(c->cfg.device);
   if (use_loop && c->loop_occupancy == 0) {
@@ -1064,6 +1176,7 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
     c->icp_loop_seq += 64u;                                  // tags of one launch never collide with an earlier launch's slots
     L.slots = c->icp_loop_slots; L.tag_base = c->icp_loop_seq; L.track = c->track;
     L.stall_word = stall_word;
+    if (c->inject_stall > 0) { L.play_dead = 1; --c->inject_stall; }
     { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_ICP_EXP"); L.exp_mode = em; }
     L.n_loop = grid0;
     // a pending kf_prefetch_frame: the next frame's filter rides in this launch (see IcpLoopArgs) and leaves the gated + filtered image in
@@ -1277,8 +1390,8 @@ extern "C" int kf_wait_track_result(kf_ctx* c, kf_track_result* out) {
   c->track_requested = 0;
   const KfTrackState* h = (const KfTrackState*)((const char*)c->host_pinned + 1024);
   memcpy(out->pose.m, h->pose, 64);
-  out->tracked = h->tracked; out->status = h->status; out->iterations = h->iterations; out->launch_form = c->last_track_form;
-  if (h->status == KF_TRACK_STALLED && c->persistent_backoff == 0) kf_note_loop_stall(c);
+  out->tracked = h->tracked; out->status = h->status; out->iterations = h->iterations; out->launch_form = (h->rescued && c->last_track_form == 1) ? 3 : c->last_track_form;
+  if (h->rescued && c->last_track_form == 1) kf_note_loop_stall(c);
   return 0;
 }
 
@@ -1288,9 +1401,18 @@ extern "C" int kf_read_track_result(kf_ctx* c, kf_track_result* out) {
   KF_CHECK(hipMemcpyAsync(h, c->track, sizeof(KfTrackState), hipMemcpyDeviceToHost, c->stream));
   KF_CHECK(hipStreamSynchronize(c->stream));
   memcpy(out->pose.m, h->pose, 64);
-  out->tracked = h->tracked; out->status = h->status; out->iterations = h->iterations; out->launch_form = c->last_track_form;
-  // status 3: the persistent loop gave up waiting for a partial sum -- some of its workgroups were not resident (another
-  // process on the GPU?).  The frame counts as lost; the next frames track with one launch per step, then the loop is tried again.
-  if (h->status == KF_TRACK_STALLED && c->persistent_backoff == 0) kf_note_loop_stall(c);
+  // launch_form 3: the persistent loop timed out waiting for a partial sum -- some of its workgroups were not resident (another process on
+  // the GPU?) -- and one workgroup finished the frame alone (same bits, milliseconds late).  The next frames track with one launch per
+  // step, then the loop is tried again.
+  out->tracked = h->tracked; out->status = h->status; out->iterations = h->iterations; out->launch_form = (h->rescued && c->last_track_form == 1) ? 3 : c->last_track_form;
+  if (h->rescued && c->last_track_form == 1) kf_note_loop_stall(c);
+  return 0;
+}
+
+// Fault injection for tests and rehearsals: in each of the next `launches` launches of the persistent ICP loop one workgroup exits at once, as
+// if a foreign process had kept it off the chip -- the others time out (20 ms) and one of them finishes the frame alone.  Results are unchanged.
+extern "C" int kf_inject_track_stall(kf_ctx* c, int launches) {
+  if (!c || launches < 0) return KF_ERR_ARG;
+  c->inject_stall = launches;
   return 0;
 }

@@ -85,7 +85,7 @@ SYMBOLS = [
     "kf_upload_map", "kf_download_volume", "kf_upload_volume", "kf_get_volume_stats", "kf_stored_z_range",
     "kf_stage_timers", "kf_read_stage_ms", "kf_read_work_counters", "kf_set_stream", "kf_raycast_volume_slab", "kf_slab_mask_candidates", "kf_set_model_maps_device", "kf_raycast_volume_slab_rays", "kf_slab_mask_rays", "kf_set_model_maps_rays", "kf_selftest_div",
     "kf_icp_partition_begin", "kf_icp_partition_steps", "kf_icp_partition_step", "kf_icp_partition_finish",
-    "kf_sdf_partition_begin", "kf_sdf_partition_step", "kf_sdf_partition_finish", "kf_set_defer",
+    "kf_sdf_partition_begin", "kf_sdf_partition_step", "kf_sdf_partition_finish", "kf_set_defer", "kf_inject_track_stall",
 ]
 
 
@@ -293,10 +293,14 @@ class Context:
         p = SdfTrackerParams(max_iter, dist_shake, angle_shake)
         _chk(self.lib.kf_sdf_track(self.h, frame_id, C.byref(p), C.byref(self.cam)), "kf_sdf_track")
 
+    def inject_track_stall(self, launches=1):
+        """fault injection: the next `launches` persistent-loop launches run with one workgroup playing dead (the frame is finished solo)"""
+        _chk(self.lib.kf_inject_track_stall(self.h, int(launches)), "kf_inject_track_stall")
+
     def track_result(self):
         r = TrackResult()
         _chk(self.lib.kf_read_track_result(self.h, C.byref(r)), "kf_read_track_result")
-        self.last_form = r.launch_form       # 1: persistent device loop, 2: one launch per Gauss-Newton step (same pose bits), 0: none
+        self.last_form = r.launch_form       # 1: persistent device loop, 2: one launch per Gauss-Newton step, 3: loop finished by one workgroup after a time-out (same pose bits), 0: none
         return bool(r.tracked), r.pose.numpy(), r.status, r.iterations
 
     # ---- volume ----

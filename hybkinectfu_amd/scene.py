@@ -98,3 +98,36 @@ def make_stream(n_frames, cam, size, trunc_min=STOCK["depth_trunc_min"], start=0
         poses[i] = trajectory_pose(start + i, size, trunc_min)
         frames[i] = render_depth_mm(poses[i], cam, size)
     return frames, poses
+
+
+# ---- sensor noise ("no RNG needed unless noise is enabled -- then LCG seed 12345") -----------------------------
+LCG_A, LCG_C, LCG_SEED = 1664525, 1013904223, 12345
+
+
+def _lcg(state):
+    return (state * np.uint64(LCG_A) + np.uint64(LCG_C)) & np.uint64(0xFFFFFFFF)
+
+
+def add_sensor_noise(frames_mm, hole_fraction=0.02, seed=LCG_SEED, first_frame=0):
+    """Depth-sensor noise on u16-millimetre frames, deterministic: every pixel of every frame draws from the 32-bit LCG (1664525, 1013904223)
+    started at seed + its global index.  Axial noise with the Kinect's depth dependence, sigma(z) = 1.2 mm + 1.9 mm/m^2 (z - 0.4 m)^2 (sum of
+    four uniform draws ~ normal), re-quantised to whole millimetres; `hole_fraction` of the valid pixels drop out (0 = invalid,
+    src/FrameData.h:57).  The bilateral filter's early return (DataPreprocesser.cu:66-69), the ICP's rejection tests and the fusion pass's
+    partial waves all see different inputs than on the noise-free scene."""
+    f = np.ascontiguousarray(frames_mm, np.uint16)
+    shape = f.shape
+    n = f.size
+    idx = np.arange(n, dtype=np.uint64) + np.uint64(first_frame) * np.uint64(shape[-1] * shape[-2])
+    st = _lcg((np.uint64(seed) + idx * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF))
+    acc = np.zeros(n, np.float64)
+    for _ in range(4):
+        st = _lcg(st)
+        acc += (st >> np.uint64(8)).astype(np.float64) * (1.0 / 16777216.0)
+    g = (acc - 2.0) * math.sqrt(3.0)                                  # four uniforms: variance 4/12 -> unit variance
+    st = _lcg(st)
+    drop = (st >> np.uint64(8)).astype(np.float64) * (1.0 / 16777216.0) < hole_fraction
+    z = f.reshape(-1).astype(np.float64) * 1e-3
+    sigma = 0.0012 + 0.0019 * (z - 0.4) ** 2
+    out = np.floor((z + sigma * g) * 1000.0 + 0.5)
+    out = np.where((f.reshape(-1) == 0) | drop, 0.0, np.clip(out, 1, 65535))
+    return out.astype(np.uint16).reshape(shape)

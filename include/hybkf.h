@@ -66,7 +66,7 @@ enum {
 
 /* status of the device-side tracker after kf_icp_track / kf_sdf_track */
 enum { KF_TRACK_OK = 0, KF_TRACK_LOST_DET = 1, KF_TRACK_LOST_SHAKE = 2,
-       KF_TRACK_STALLED = 3 /* device-side wait timed out (GPU shared with another process); frame lost, pose unchanged */ };
+       KF_TRACK_STALLED = 3 /* (no longer produced: a device-side wait that times out is finished by one workgroup alone, see kf_track_result::launch_form) */ };
 
 typedef struct kf_track_result {
   kf_mat44 pose;            /* CameraPoseFinder::_pose after the call (unchanged when lost) */
@@ -74,7 +74,9 @@ typedef struct kf_track_result {
   int32_t  status;          /* KF_TRACK_* */
   int32_t  iterations;      /* Gauss-Newton iterations actually applied */
   int32_t  launch_form;     /* how the last ICP call was launched: 0 none (frame 0, SDF tracker), 1 persistent device loop, 2 one launch per
-                             * Gauss-Newton step (image too large for co-resident workgroups, GPU shared, after a stall); same pose bits either way */
+                             * Gauss-Newton step (image too large for co-resident workgroups, GPU shared, after a stall), 3 persistent loop that timed
+                             * out waiting for a workgroup that was not resident and was finished by one workgroup alone (the frame is kept,
+                             * milliseconds late); the same pose bits in every form */
 } kf_track_result;
 
 typedef struct kf_volume_stats {
@@ -156,6 +158,10 @@ int kf_read_track_result(kf_ctx* ctx, kf_track_result* out);          /* blockin
  * arrived -- work enqueued in between (integrate and raycast with transform == NULL) keeps the GPU busy meanwhile */
 int kf_request_track_result(kf_ctx* ctx);
 int kf_wait_track_result(kf_ctx* ctx, kf_track_result* out);
+/* Fault injection (tests, rehearsals; no reference counterpart): each of the next `launches` launches of the persistent ICP loop gets one
+ * workgroup that exits at once, as if a foreign process had kept it off the chip.  The others time out after 20 ms and one of them finishes
+ * the frame's Gauss-Newton loop alone: same pose bits, launch_form 3, no frame lost. */
+int kf_inject_track_stall(kf_ctx* ctx, int launches);
 
 /* cudaIntegrateVolume  src/cuda/integrateVolume.cu:78-96.  transform == NULL: use the device-resident pose and
  * integrate only if the last kf_*_track call tracked (src/HybKinectfu.cpp:123-140). */
@@ -166,8 +172,9 @@ int kf_integrate_volume(kf_ctx* ctx, int has_color, int use_angle_weight_color, 
  * src/cuda/integrateVolume.cu:15-77, src/cuda/tsdfVolume.h:57-75 -- results are bit-identical either way).  A wave of the fusion pass
  * whose 128 voxels all hold tsdf 1 and are all observed as free space again only counts the observation; the count is applied to the
  * weights (w <- fminf(w + k, max_weight)) when anything else writes into those voxels and by kf_download_volume.  mode 1: on, 0: off (the
- * plain read-modify-write kernel on every frame), -1: follow the environment (KF_INTEGRATE_SAT=0 turns it off; default on).  Needs
- * 1 <= max_weight <= 65000 and no colour; otherwise the plain kernel runs whatever the mode. */
+ * plain read-modify-write kernel on every frame), -1 (default): on for volumes of 768^3 voxels and finer, where the fusion pass is memory-bound
+ * (KF_INTEGRATE_SAT=0 / 2 in the environment: never / always).  Needs 1 <= max_weight <= 65000 and no colour; otherwise the plain kernel runs
+ * whatever the mode. */
 int kf_set_defer(kf_ctx* ctx, int mode);
 /* cudaRaycastingVolume  src/cuda/raycastingVolume.cu:158-176.  transform == NULL: device-resident pose. */
 int kf_raycast_volume(kf_ctx* ctx, int has_color, const kf_mat44* transform, const kf_raycast_params* raycast_params,

@@ -455,7 +455,7 @@ def test_maximum_configuration_2048_cubed():
         assert np.linalg.norm(pose[:3, 3] - S.trajectory_pose(k, size)[:3, 3]) < 2e-3
     st = pipe.stats()
     assert st["frames_fused"] == n and st["frames_lost"] == 0
-    assert st["updated_last"] > 4e8 and st["weight_gt0"] >= st["updated_last"] and st["bricks_active"] > 1_000_000
+    assert st["updated_last"] > 4e8 and st["weight_gt0"] >= st["updated_last"] and st["bricks_active"] > 300_000      # (whole free-space bricks are retired by the cull from the second frame on: counted, not queued)
     hit = pipe.ctx.download_map(K.MAP_MODEL_VERTICES)[..., 3] != 0
     assert hit.sum() > 0.9 * hit.size
     pipe.ctx.marching_cubes(300 * size / res)
@@ -629,4 +629,55 @@ def test_integrate_color_vga_color_camera_bit_exact(angled):
     ctx.raycast(pose, 0.7 * trunc, 0.3, 4.0, has_color=True)
     assert np.array_equal(bits(ctx.download_map(K.MAP_MODEL_VERTICES)), bits(ov))
     assert np.array_equal(ctx.download_map(K.MAP_RAYCAST_RGB), orgb) and int(np.count_nonzero(orgb)) > 1000
+    ctx.close()
+
+
+def test_noisy_scene_parity():
+    """The frames of bench.py's `scene_noise` block (Scene S + scene.add_sensor_noise: LCG seed 12345, depth-dependent axial noise, 2 % drop-outs)
+    at C2's image size: preprocess chain (bilateral early returns, DataPreprocesser.cu:66-69, now fire all over the image), three fused frames
+    (update counts and planes bit-exact: partial waves around every drop-out), the raycast maps bit-exact, and one ICP step sequence on identical
+    maps within the north star's 1e-4."""
+    cam, size, res, trunc = S.vga_camera(), 4.0, 256, 5 * 4.0 / 256
+    ocam, kcam = O.Cam.make(*cam), K.camera(*cam)
+    clean, poses = S.make_stream(4, cam, size)
+    noisy = S.add_sensor_noise(clean)
+    assert 0.015 < float((noisy == 0).mean()) < 0.03 and not np.array_equal(noisy[0], clean[0])
+    ctx = K.Context(kcam, res, size, P["volume_max_weight"], levels=3)
+    ovol = O.OVolume(res, size, P["volume_max_weight"])
+    early = 0
+    for k in range(3):
+        pose = poses[k].astype(np.float32)
+        d, tr, fl, v, n = oracle_preprocess(noisy[k], ocam)
+        early += int(((fl == tr) & (tr != 0)).sum())                    # pixels the filter returned unfiltered (or could not change)
+        ctx.upload_depth_mm(noisy[k])
+        ctx.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+        assert np.array_equal(bits(ctx.download_map(K.MAP_TRUNCED_DEPTH)), bits(tr))
+        g_fl = ctx.download_map(K.MAP_FILTERED_DEPTH)
+        assert np.allclose(g_fl, fl, rtol=2e-6, atol=0) and np.array_equal(g_fl == 0, fl == 0)
+        assert np.array_equal((g_fl == tr), (fl == tr))                  # the same pixels take the early return
+        n_o = O.integrate(ovol, tr, n, None, False, False, pose, trunc, 2.5, ocam, ocam)
+        ctx.integrate(pose, trunc, 2.5)
+        assert ctx.stats()["updated_last"] == n_o and n_o > 500_000
+    assert early > 1000
+    t, w = ctx.download_volume()
+    assert np.array_equal(bits(t), bits(ovol.tsdf)) and np.array_equal(bits(w), bits(ovol.weight))
+    inc = 0.7 * trunc
+    ov, on, _ = O.raycast(ovol, False, pose, inc, ocam, P["depth_trunc_min"], P["depth_trunc_max"])
+    ctx.raycast(pose, inc, P["depth_trunc_min"], P["depth_trunc_max"])
+    assert int((ov[..., 3] != 0).sum()) > 50_000
+    assert np.array_equal(bits(ctx.download_map(K.MAP_MODEL_VERTICES)), bits(ov)) and np.array_equal(bits(ctx.download_map(K.MAP_MODEL_NORMALS)), bits(on))
+    # the next noisy frame against that model: identical tracker inputs on both sides
+    d, tr, fl, v, n = oracle_preprocess(noisy[3], ocam)
+    ctx.upload_depth_mm(noisy[3])
+    ctx.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+    ctx.upload_map(K.MAP_NEW_VERTICES, 0, v)
+    ctx.upload_map(K.MAP_NEW_NORMALS, 0, n)
+    ok_o, pose_o = O.icp_estimate(O.pyramid(v, 3), O.pyramid(n, 3, normals=True), O.pyramid(ov, 3), O.pyramid(on, 3, normals=True), ocam,
+                                  P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"], pose)
+    ctx.set_pose(pose)
+    ctx.icp_track(1, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+    ok_g, pose_g, status, iters = ctx.track_result()
+    assert ok_o and ok_g and status == 0 and iters == 19
+    assert np.max(np.abs(pose_g[:3, 3] - pose_o[:3, 3])) < 1e-4 and np.max(np.abs(pose_g[:3, :3] - pose_o[:3, :3])) < 1e-4
+    assert np.linalg.norm(pose_g[:3, 3] - poses[3][:3, 3]) < 0.01
     ctx.close()

@@ -26,7 +26,7 @@ def bits(a):
 class Pair:
     """the same frames through the library and the oracle"""
 
-    def __init__(self, res, size, color=False, cam=CAM, maxw=3.0, defer=None):
+    def __init__(self, res, size, color=False, cam=CAM, maxw=3.0, defer=1):      # (volumes below 768^3 do not defer unless asked to)
         self.res, self.size, self.color, self.cam, self.maxw = res, size, color, cam, maxw
         self.ocam = O.Cam.make(*cam)
         self.ovol = O.OVolume(res, size, maxw)

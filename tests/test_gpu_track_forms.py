@@ -122,3 +122,60 @@ def test_negative_thresholds_reject_like_the_reference(icp):
     assert not ok_o and not ok and status in (1, 2) and np.array_equal(p, pose)
     assert status == (1 if (icp[0] < 0 or icp[1] < 0) else 2)
     ctx.close()
+
+
+@pytest.mark.parametrize("res,cam", [(128, S.vga_camera()), (96, ragged_cam())])
+def test_a_loop_that_times_out_is_finished_by_one_workgroup_with_the_same_bits(res, cam):
+    """kf_inject_track_stall: one workgroup of the persistent loop plays dead (as if a foreign process had kept it off the chip).  The others
+    time out, one of them claims the launch and runs the frame's whole Gauss-Newton loop alone, playing every workgroup in turn: the same pose
+    bits and final 27 sums as the undisturbed loop, launch_form 3, tracked -- the frame is not lost; the context then backs off to per-step
+    launches (form 2) for a while.  Also the lost verdict through the solo path."""
+    size, trunc = 3.0, 5 * 3.0 / res
+    ctx, ovol, pose, nxt, ocam, maps = _tracking_case(res, size, cam, trunc)
+    ok1, p1, st1, it1, form1, sums1 = _track(ctx, pose)
+    assert form1 == 1 and ok1 and st1 == 0 and it1 == 19
+    ctx.inject_track_stall(1)
+    ok2, p2, st2, it2, form2, sums2 = _track(ctx, pose)
+    assert form2 == 3, form2                                  # timed out, finished solo
+    assert ok2 and st2 == 0 and it2 == 19
+    assert np.array_equal(p1.view(np.uint32), p2.view(np.uint32)) and np.array_equal(sums1.view(np.uint32), sums2.view(np.uint32))
+    ok3, p3, st3, it3, form3, _ = _track(ctx, pose)          # back-off: one launch per step now, same bits again
+    assert form3 == 2 and np.array_equal(p3.view(np.uint32), p1.view(np.uint32))
+    ctx.close()
+    # the lost verdict on the solo path: shake threshold 0 rejects the first step, pose unchanged, iterations 0 (not a stale count)
+    ctx, ovol, pose, nxt, ocam, maps = _tracking_case(res, size, cam, trunc)
+    _track(ctx, pose)
+    ctx.inject_track_stall(1)
+    ok_l, p_l, st_l, it_l, form_l, _ = _track(ctx, pose, (ICP[0], ICP[1], 0.0, 0.0))
+    assert not ok_l and st_l == 2 and it_l == 0 and np.array_equal(p_l, pose)
+    ctx.close()
+
+
+def test_a_timed_out_loop_in_the_streamed_pipeline_loses_no_frame():
+    """The asynchronous pipeline (no host synchronisation per frame, next frame's front end riding in the launches): a loop launch that times out
+    in the middle of the stream costs milliseconds, not the frame -- frames_lost stays 0 and every pose equals the undisturbed run's bit for bit."""
+    import torch
+    from hybkinectfu_amd.pipeline import SingleGpuPipeline
+    cam, res, size = S.vga_camera(), 384, 3.0                    # stock truncation (0.05 m) = 6.4 voxels, as at C2
+    n = 8
+    frames, _ = S.make_stream(n, cam, size)
+    dev = torch.from_numpy(frames.astype(np.int16)).cuda()
+    fb = cam[0] * cam[1] * 2
+    poses, forms = [], []
+    for inject_at in (None, 4):
+        pipe = SingleGpuPipeline(K.camera(*cam), res, size, dict(trunc_max=P["depth_trunc_max"], integ_dist=P["integrate_depth_trunc"]))
+        out, fo = [], []
+        for k in range(n):
+            if inject_at == k:
+                pipe.ctx.inject_track_stall(1)
+            pipe.process_frame_device(dev.data_ptr() + k * fb, k, dev.data_ptr() + ((k + 1) % n) * fb)
+            ok, pose, status, iters = pipe.track_result()
+            assert ok and status == 0, (inject_at, k)
+            out.append(pose); fo.append(pipe.ctx.last_form)
+        st = pipe.stats()
+        assert st["frames_lost"] == 0 and st["frames_fused"] == n
+        poses.append(out); forms.append(fo)
+        pipe.close()
+    assert forms[1][4] == 3 and forms[1][5] == 2 and forms[0][4] == 1
+    for a, b in zip(*poses):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

@@ -23,13 +23,14 @@ for lo, hi in zip(edges, edges[1:]):
     if lo >= n:
         break
     hi = min(hi, n)
-    c.stage_timers(1 << 16)
+    a0, b0, m0, _ = c.work_counters()          # (the counters are never reset here: kf_stage_timers(1 << 16) would also let the raycast count into them)
     for k in range(lo, hi):
         pipe.process_frame_device(dev.data_ptr() + (k % nf) * fb, k)
     pipe.sync()
     a, b, m, _ = c.work_counters()
+    a, b, m = a - a0, b - b0, m - m0
     f = float(hi - lo)
     st = c.stats()
-    lo32, hi32 = (lambda x: (x & 0xFFFFFFFF) / f), (lambda x: (x >> 32) / f)
+    lo32, hi32 = (lambda x: (x & 0xFFFFFFFF) / f), (lambda x: (x >> 32) / f)      # (differences of packed counts: each half stays below 2^32 over a run)
     print("%s frames %3d..%3d: queued %7d bricks (last frame) | waves/frame: skipped sat %8.0f def %8.0f | flush %7.0f | written band %8.0f whole-free %8.0f partial-free %8.0f" % (
         cfg, lo, hi, st["bricks_active"], lo32(a), hi32(a), lo32(b), hi32(b), lo32(m), hi32(m)))

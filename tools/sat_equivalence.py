@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The fusion pass with deferred free-space weights (KF_INTEGRATE_SAT=1, default: from the first frame) against the plain kernels
+"""The fusion pass with deferred free-space weights (KF_INTEGRATE_SAT=2: from the first frame, whatever the volume size) against the plain kernels
 (KF_INTEGRATE_SAT=0) on the benchmark stream at full size: same update counts and the same voxel bits after n frames.  The switch is
 read once per process, so the parent runs one child per setting (one after the other; the parent itself touches no GPU) and compares
 what they print.  max_weight 128 (stock) stays in the pending-count state for 127 frames, max_weight 3 saturates after three.
@@ -43,7 +43,7 @@ if __name__ == "__main__":
     n = sys.argv[2] if len(sys.argv) > 2 else "200"
     maxw = sys.argv[3] if len(sys.argv) > 3 else "128"
     out = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "2"):          # 0: never defer, 2: defer whatever the volume size (the default, 1, defers from 768^3 on)
         env = dict(os.environ, KF_INTEGRATE_SAT=mode)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", cfg, n, maxw], env=env, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
@@ -51,7 +51,7 @@ if __name__ == "__main__":
             print(r.stdout, r.stderr); sys.exit(1)
         out[mode] = line[0]
         print("KF_INTEGRATE_SAT=%s %s" % (mode, line[0]))
-    a, b = out["0"].split(), out["1"].split()
+    a, b = out["0"].split(), out["2"].split()
     same = [x for x in a if not x.startswith("bricks_active_last")] == [x for x in b if not x.startswith("bricks_active_last")]
     print("EQUIVALENT" if same else "DIFFERENT", "(%s, %s frames, max_weight %s; the queue of the last frame differs by design: retired bricks are counted, not queued)" % (cfg, n, maxw))
     sys.exit(0 if same else 2)
