@@ -546,6 +546,10 @@ def main():
     ap.add_argument("--slab-balance", default="probe", choices=["probe", "equal"],
                     help="N > 1: slab boundaries from a one-frame low-resolution probe of the work per z-layer (default: the busiest rank sets the frame time, "
                          "and equal z-slabs are unequally busy) or equal thickness")
+    ap.add_argument("--rebalance-every", type=int, default=0,
+                    help="N > 1: every K frames the ranks pool the work per brick layer counted by the fusion pass, re-run the boundary optimisation and move the layers "
+                         "that change owner rank to rank (SlabPipeline.rebalance); 0 (default): the boundaries of the start-up probe stay -- the benchmark trajectory is a "
+                         "2 cm circle, its work does not move along z")
     ap.add_argument("--no-c5", action="store_true", help="N > 1: skip the short C5 block (2048^3 @ 8 m, 1280x960) that follows the C4 measurement")
     ap.add_argument("--config", default="auto", choices=["auto", "c1", "c2", "c3", "c4", "c5"],
                     help="auto: C2 (512^3 @ 4 m) on 1 GPU, C4 (1024^3 @ 6 m, z-slabs) on N > 1, as BASELINE.json's metric states; "
@@ -619,7 +623,7 @@ def main():
         from hybkinectfu_amd.pipeline import SlabPipeline as Pipe
         pipe = Pipe(kcam, res, size, wl, rank=rank, world=world, device=device, icp_mode=args.icp_mode, tracker=args.tracker,
                     max_triangles=(16_000_000 // world + 1_000_000 if wl.get("extract_mesh") else 0),
-                    ranges=balanced_ranges(args, kcam, res, size, wl, world, device, dev_frames.data_ptr()))
+                    ranges=balanced_ranges(args, kcam, res, size, wl, world, device, dev_frames.data_ptr()), rebalance_every=args.rebalance_every)
 
     def run(first, count):
         # --prefetch: frame k+1 is preprocessed on the context's side stream while frame k is tracked (kf_prefetch_frame)
@@ -773,7 +777,8 @@ def main():
                            world_size=(dist.get_world_size() if dist is not None else 1),
                            backend=("none" if dist is None else ("rccl" if args.backend == "nccl" else "gloo (rehearsal: host-staged collectives, ranks may share a GPU)")),
                            partition="none" if not slab else
-                           "z-slab x%d (boundaries: %s); %d halo layers per side RE-INTEGRATED by both neighbours (recomputed, not exchanged over xGMI); "
+                           "z-slab x%d (boundaries: %s); %d halo layers per side RE-INTEGRATED by both neighbours (recomputed, not exchanged per frame; when the boundaries move -- "
+                           "--rebalance-every -- whole brick layers travel rank to rank: SlabMigrator); "
                            "raycast merge = MIN all-reduce (t, 1.2 MB) + integer SUM all-reduce (vertex ray parameter + normal, 4.9 MB); ICP %s"
                            % (world, "balanced from a one-frame 256^3 probe of the work per z-layer" if (world > 1 and args.slab_balance == "probe") else "equal thickness",
                               pipe.halo, args.icp_mode),
@@ -785,6 +790,7 @@ def main():
         # z-slab runs: per-rank statistics over 20 extra frames, then the lock-step check (all ranks fused / lost the same frames, same pose bits)
         out["per_rank"] = per_rank_leg(pipe, run, barrier, dist, world, rank, after_roofline, 20)
         out["lockstep"] = pipe.verify_lockstep()
+        out["slab_migrations"] = [dict(frame=f, old=[list(r) for r in o], new=[list(r) for r in n], voxel_layers_moved_by_rank0=m) for f, o, n, m in pipe.migrations]
         if world > 1 and args.config == "auto" and not args.no_c5:
             # the north star quotes 1024^3 AND 2048^3 for 1/2/4/8 GPUs: a short C5 block (2048^3 @ 8 m, 1280x960 depth, mesh extraction) on the same ranks
             pipe.close()

@@ -110,7 +110,7 @@ extern "C" int kf_destroy(kf_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->own_stream) hipStreamSynchronize(c->own_stream);
   void* ptrs[] = {c->up_dev[0], c->up_dev[1], c->raw_depth, c->trunced_depth, c->filtered_depth, c->raw_rgb, c->raycast_rgb, c->icp_partials, c->icp_loop_slots,
-                  c->track, c->counters, c->grid_barrier, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macrobits, c->vol.negbits, c->vol.pend, c->active_bricks,
+                  c->track, c->counters, c->grid_barrier, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macrobits, c->vol.negbits, c->vol.pend, c->layer_work, c->active_bricks,
                   c->tile_max_depth, c->triangles, c->mc_block_counts, c->mc_list, c->mc_nbr_bits, c->mc_partials, c->mc_codes, c->mc_surv, c->mc_block_bits, c->mc_recs, c->mc_d1_list};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->up_stream) { hipStreamSynchronize(c->up_stream); hipStreamDestroy(c->up_stream); }
@@ -498,6 +498,118 @@ extern "C" int kf_upload_volume(kf_ctx* c, uint32_t z0, uint32_t z1, const float
   { const int fs = kf_flush_pending(c); if (fs) return fs; }
   KF_CHECK(hipMemsetAsync(c->vol.pend, 0, c->n_stored_bricks * sizeof(unsigned long long), c->stream)); c->pend_live = 0;
   return volume_xfer(c, z0, z1, (float*)tsdf, (float*)weight, (uint8_t*)color, false);
+}
+
+// ---- the same import / export with CALLER-OWNED DEVICE buffers, asynchronous on the context's stream --------------------------------
+// What z-slab ranks move between GPUs when slab boundaries change (pipeline.SlabPipeline.rebalance: torch tensors sent with
+// torch.distributed send / recv -- RCCL point-to-point over xGMI): planes in the reference's linear order, pending weight steps applied.
+extern "C" int kf_download_volume_device(kf_ctx* c, uint32_t z0, uint32_t z1, float* dev_tsdf, float* dev_weight, uint8_t* dev_color) {
+  if (!c || !dev_tsdf || !dev_weight) return KF_ERR_ARG;
+  if (z0 >= z1 || (int)z0 < c->vol.bz0 * KF_BRICK || (int)z1 > c->vol.bz1 * KF_BRICK) return KF_ERR_ARG;
+  const size_t n = (size_t)(z1 - z0) * c->vol.res * c->vol.res;
+  const int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  hipLaunchKernelGGL(k_volume_export, dim3(grid), dim3(256), 0, c->stream, c->vol, (int)z0, (int)z1, dev_tsdf, dev_weight, (unsigned char*)dev_color);
+  return (int)hipGetLastError();
+}
+extern "C" int kf_upload_volume_device(kf_ctx* c, uint32_t z0, uint32_t z1, const float* dev_tsdf, const float* dev_weight, const uint8_t* dev_color) {
+  if (!c || !dev_tsdf || !dev_weight) return KF_ERR_ARG;
+  if (z0 >= z1 || (int)z0 < c->vol.bz0 * KF_BRICK || (int)z1 > c->vol.bz1 * KF_BRICK) return KF_ERR_ARG;
+  ++c->vol_flags_serial;
+  { const int fs = kf_flush_pending(c); if (fs) return fs; }
+  KF_CHECK(hipMemsetAsync(c->vol.pend, 0, c->n_stored_bricks * sizeof(unsigned long long), c->stream)); c->pend_live = 0;
+  const size_t n = (size_t)(z1 - z0) * c->vol.res * c->vol.res;
+  const int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  hipLaunchKernelGGL(k_volume_import, dim3(grid), dim3(256), 0, c->stream, c->vol, (int)z0, (int)z1, dev_tsdf, dev_weight, (const unsigned char*)dev_color);
+  const int fg = (int)(c->n_stored_bricks > 4096 ? 4096 : c->n_stored_bricks);
+  KF_CHECK(hipMemsetAsync(c->vol.macrobits, 0, (size_t)(c->vol.macro_words + c->vol.super_words) * sizeof(unsigned), c->stream));   // rebuilt with the flags
+  hipLaunchKernelGGL(k_rebuild_flags, dim3(fg), dim3(256), 0, c->stream, c->vol, c->n_stored_bricks);
+  return (int)hipGetLastError();
+}
+
+// ---- a z-slab context changes the layers it owns (dynamic re-balancing of the slab boundaries) -----------------------------------------------
+// New owned range [z_begin, z_end) + halo -> new stored brick layers.  The layers stored before AND after keep their voxels (a brick layer is
+// one contiguous run of bricks: device-to-device copies); layers that are new read as never observed until the caller fills them
+// (kf_upload_volume_device with what their previous owner sent); layers no longer stored are dropped.  Everything else of the context --
+// device-resident pose and tracker state, frame maps, counters, streams -- stays.  Blocking (allocations).
+extern "C" int kf_resize_slab(kf_ctx* c, uint32_t z_begin, uint32_t z_end, uint32_t halo) {
+  if (!c) return KF_ERR_ARG;
+  KfVolume& v = c->vol;
+  const uint32_t R = (uint32_t)v.res;
+  if (z_begin >= z_end || z_end > R || (z_begin % KF_BRICK) || (z_end % KF_BRICK)) return KF_ERR_ARG;
+  KF_CHECK(hipSetDevice(c->cfg.device));
+  const int halo_b = (int)((halo + KF_BRICK - 1) / KF_BRICK);
+  int nb0 = (int)(z_begin / KF_BRICK) - halo_b, nb1 = (int)(z_end / KF_BRICK) + halo_b;
+  nb0 = nb0 < 0 ? 0 : nb0; nb1 = nb1 > v.nb ? v.nb : nb1;
+  { const int fs = kf_flush_pending(c); if (fs) return fs; }                        // the stored weights become authoritative: no word moves
+  const size_t per_layer = (size_t)v.nb * v.nb;                                      // bricks of one brick layer
+  const size_t n_new = (size_t)(nb1 - nb0) * per_layer;
+  float2* tw = nullptr; uchar4* color = nullptr; uint8_t* flags = nullptr; unsigned* negbits = nullptr; unsigned long long* pend = nullptr;
+  unsigned* queue = nullptr; unsigned* mc_counts = nullptr;
+  int st = 0;
+  if (!st) st = dev_alloc(&tw, n_new * KF_BRICK_VOX);
+  if (!st && v.color) st = dev_alloc(&color, n_new * KF_BRICK_VOX);
+  if (!st) st = dev_alloc(&flags, n_new + 4);
+  if (!st) st = dev_alloc(&negbits, kf_negbit_words(n_new));
+  if (!st) st = dev_alloc(&pend, n_new);
+  if (!st) st = dev_alloc(&queue, n_new + 8);
+  if (!st) st = dev_alloc(&mc_counts, (n_new * KF_BRICK_VOX + 255) / 256 + 1);
+  hipError_t e = hipSuccess;
+  if (!st) {
+    e = hipMemsetAsync(tw, 0, n_new * KF_BRICK_VOX * sizeof(float2), c->stream);
+    if (e == hipSuccess && color) e = hipMemsetAsync(color, 0, n_new * KF_BRICK_VOX * sizeof(uchar4), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(flags, 0, n_new + 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(negbits, 0, kf_negbit_words(n_new) * sizeof(unsigned), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(pend, 0, n_new * sizeof(unsigned long long), c->stream);
+    const int lo = nb0 > v.bz0 ? nb0 : v.bz0, hi = nb1 < v.bz1 ? nb1 : v.bz1;       // brick layers stored before and after
+    if (e == hipSuccess && hi > lo) {
+      const size_t src = (size_t)(lo - v.bz0) * per_layer * KF_BRICK_VOX, dst = (size_t)(lo - nb0) * per_layer * KF_BRICK_VOX, cnt = (size_t)(hi - lo) * per_layer * KF_BRICK_VOX;
+      e = hipMemcpyAsync(tw + dst, v.tw + src, cnt * sizeof(float2), hipMemcpyDeviceToDevice, c->stream);
+      if (e == hipSuccess && color) e = hipMemcpyAsync(color + dst, v.color + src, cnt * sizeof(uchar4), hipMemcpyDeviceToDevice, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    st = (int)e;
+  }
+  if (st) {
+    void* fresh[] = {tw, color, flags, negbits, pend, queue, mc_counts};
+    for (void* p : fresh) if (p) hipFree(p);
+    return st;
+  }
+  void* old[] = {v.tw, v.color, v.flags, v.negbits, v.pend, c->active_bricks, c->mc_block_counts,
+                 c->mc_list, c->mc_nbr_bits, c->mc_partials, c->mc_codes, c->mc_surv, c->mc_block_bits, c->mc_recs, c->mc_d1_list};
+  for (void* p : old) if (p) hipFree(p);
+  v.tw = tw; v.color = color; v.flags = flags; v.negbits = negbits; v.pend = pend; c->active_bricks = queue; c->mc_block_counts = mc_counts;
+  c->mc_list = nullptr; c->mc_nbr_bits = nullptr; c->mc_partials = nullptr; c->mc_codes = nullptr; c->mc_surv = nullptr; c->mc_block_bits = nullptr; c->mc_recs = nullptr; c->mc_d1_list = nullptr;
+  v.bz0 = nb0; v.bz1 = nb1; v.own_z0 = (int)z_begin; v.own_z1 = (int)z_end;
+  c->cfg.slab_z_begin = z_begin; c->cfg.slab_z_end = z_end; c->cfg.slab_halo = halo;
+  c->n_stored_bricks = n_new; c->n_stored_vox = n_new * KF_BRICK_VOX; c->mc_blocks_cap = (c->n_stored_vox + 255) / 256;
+  ++c->vol_flags_serial; c->pend_live = 0;
+  // brick flags, has-negative bits and the macro / super cell tables of what is stored now
+  KF_CHECK(hipMemsetAsync(v.macrobits, 0, (size_t)(v.macro_words + v.super_words) * sizeof(unsigned), c->stream));
+  hipLaunchKernelGGL(k_rebuild_flags, dim3((unsigned)(n_new > 4096 ? 4096 : n_new)), dim3(256), 0, c->stream, v, n_new);
+  KF_CHECK(hipStreamSynchronize(c->stream));
+  return (int)hipGetLastError();
+}
+
+// ---- work per brick layer (what the slab boundaries are balanced on) --------------------------------------------------------------------------
+// kf_count_layer_work: the next `frames` kf_integrate_volume calls add, per brick layer of the WHOLE volume, the voxels of queued bricks that passed
+// the update predicate (bricks the cull retires as whole free space cost nothing and are not counted).  kf_read_layer_work: blocking; out has
+// resolution / 8 entries (zeros for layers this context does not store); reset != 0 clears the counts afterwards.
+extern "C" int kf_count_layer_work(kf_ctx* c, int frames) {
+  if (!c || frames < 0) return KF_ERR_ARG;
+  if (!c->layer_work) {
+    KF_CHECK(hipMalloc((void**)&c->layer_work, (size_t)c->vol.nb * sizeof(unsigned long long)));
+    KF_CHECK(hipMemsetAsync(c->layer_work, 0, (size_t)c->vol.nb * sizeof(unsigned long long), c->stream));
+  }
+  c->layer_work_frames = frames;
+  return 0;
+}
+extern "C" int kf_read_layer_work(kf_ctx* c, uint64_t* out, int reset) {
+  if (!c || !out) return KF_ERR_ARG;
+  if (!c->layer_work) { memset(out, 0, (size_t)c->vol.nb * sizeof(uint64_t)); return 0; }
+  KF_CHECK(hipMemcpyAsync(out, c->layer_work, (size_t)c->vol.nb * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  if (reset) KF_CHECK(hipMemsetAsync(c->layer_work, 0, (size_t)c->vol.nb * sizeof(unsigned long long), c->stream));
+  KF_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
 }
 
 // ---- statistics ----------------------------------------------------------------------------------------------------

@@ -41,6 +41,8 @@ struct IntegrateArgs {
   int defer_cull;                // deferred-weight words are in use (k_integrate_pairs<.., DEFER>) and the tile minima describe this depth map: the cull may
                                  // retire whole free-space bricks (counted, their pending counts bumped, never queued)
   int free_ok;                   // sdf_trunc > 0 (and the shortcut not disabled): free-space waves skip the quotients (k_integrate_pairs)
+  unsigned long long* layer_work;   // non-null on sampled frames (kf_count_layer_work): voxels updated per BRICK LAYER of the whole volume, queued bricks only --
+                                    // what z-slab ranks balance their boundaries on (pipeline.SlabPipeline.rebalance)
 };
 
 // Retire the OTHER parity's counters (nobody touches them during this launch) and clear the tile tables for the next frame's fused
@@ -485,8 +487,10 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   unsigned short* const pend16 = reinterpret_cast<unsigned short*>(v.pend);      // quarter q of brick slot s: pend16[4 s + q]
   const KfRecip2 r075 = kf_recip2(f2_splat(0.75f));                     // COLOR: the angle weight's |nz| / 0.75
   __shared__ unsigned s_upd;
+  __shared__ unsigned s_layer[1024];                                     // sampled frames only: this workgroup's update counts per brick layer (kf_create: <= 1024 brick layers)
   unsigned upd_total = 0;
   if (threadIdx.x == 0) s_upd = 0;
+  if (a.layer_work) for (int i = threadIdx.x; i < v.nb; i += 256) s_layer[i] = 0u;       // uniform
   __syncthreads();
   // The queue entries of an iteration are requested one iteration ahead.  On gfx9-family hardware loads and stores share one in-order
   // counter (vmcnt): a queue load issued AFTER the previous iteration's voxel stores can only be waited for together with them, which
@@ -585,6 +589,13 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
       upd0[b] = ok0[b] && d[b].x != 0.f && d[b].x < a.max_dist && sdf[b].x > -a.sdf_trunc;
       upd1[b] = ok1[b] && d[b].y != 0.f && d[b].y < a.max_dist && sdf[b].y > -a.sdf_trunc;
       if (COLOR) { upd0[b] = upd0[b] && okc0[b]; upd1[b] = upd1[b] && okc1[b]; }              // :59-62 `continue` when the colour pixel is outside
+    }
+    if (a.layer_work) {                                                    // uniform; a sampled frame: every wave adds its quarter's updates to the brick layer's count
+#pragma unroll
+      for (int b = 0; b < BR; ++b) {
+        const unsigned n = (unsigned)__popcll(__ballot(upd0[b])) + (unsigned)__popcll(__ballot(upd1[b]));
+        if (n && (threadIdx.x & 63) == 0) atomicAdd(&s_layer[(ent[b] >> 20) + (unsigned)v.bz0], n);
+      }
     }
     // Free space, decided per wave before the voxels are even requested: when no updating voxel of the wave lies inside the truncation
     // band (sdf >= trunc for all of them) every one observes tsdf = fminf(1, sdf / trunc) = 1 EXACTLY -- x >= t > 0 implies RN(x / t) >= 1
@@ -741,6 +752,7 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   if ((threadIdx.x & 63) == 0 && s > 0.f) atomicAdd(&s_upd, (unsigned)s);
   __syncthreads();
   if (threadIdx.x == 0 && s_upd) atomicAdd(&a.cnt->upd_shard[a.parity][(blockIdx.x & 63) * 16], (unsigned long long)s_upd);
+  if (a.layer_work) for (int i = threadIdx.x; i < v.nb; i += 256) { const unsigned n = s_layer[i]; if (n) atomicAdd(&a.layer_work[i], (unsigned long long)n); }
 }
 
 #ifdef KF_EXPERIMENTS
@@ -858,6 +870,8 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   } else {
     a.tinv = c->track->pose_inv; a.track = c->track;     // kept current by whoever commits the device-resident pose
   }
+  a.layer_work = nullptr;
+  if (c->layer_work_frames > 0 && c->layer_work) { a.layer_work = c->layer_work; --c->layer_work_frames; }
   a.parity = c->int_parity; c->last_parity = c->int_parity; c->int_parity ^= 1;
   a.clear_tiles = 1; a.n_tile_floats = c->n_tile_floats;
   // deferred free-space weights (k_integrate_pairs<.., DEFER>): the packed-pair kernel without colour.  Any other fusion kernel knows nothing of

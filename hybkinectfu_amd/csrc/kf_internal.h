@@ -195,6 +195,7 @@ struct kf_ctx {
   unsigned* mc_block_counts; size_t mc_blocks_cap;
   unsigned* mc_list; unsigned* mc_nbr_bits; unsigned* mc_partials;   // extraction scratch, allocated by the first kf_marching_cubes
   unsigned short* mc_codes; unsigned char* mc_surv; unsigned* mc_block_bits; uint2* mc_recs; unsigned* mc_d1_list;   // voxel classes, sieve bits, cell records, brick list (mcubes.hip), same scratch
+  unsigned long long* layer_work; int layer_work_frames;   // per-brick-layer update counts of the next `layer_work_frames` integrate calls (kf_count_layer_work)
   int defer_override;            // kf_set_defer: -1 follow the environment (default), 0 never defer, 1 defer
   int pend_live;                 // a DEFER fusion pass has run since the volume was last reset / uploaded / flushed: deferred-weight words may be set
   unsigned vol_flags_serial, mc_zero_serial;   // bumped when brick flags may have been CLEARED (reset, upload) / the serial the class tables were last zeroed for

@@ -86,6 +86,7 @@ SYMBOLS = [
     "kf_stage_timers", "kf_read_stage_ms", "kf_read_work_counters", "kf_set_stream", "kf_raycast_volume_slab", "kf_slab_mask_candidates", "kf_set_model_maps_device", "kf_raycast_volume_slab_rays", "kf_slab_mask_rays", "kf_set_model_maps_rays", "kf_selftest_div",
     "kf_icp_partition_begin", "kf_icp_partition_steps", "kf_icp_partition_step", "kf_icp_partition_finish",
     "kf_sdf_partition_begin", "kf_sdf_partition_step", "kf_sdf_partition_finish", "kf_set_defer", "kf_inject_track_stall",
+    "kf_download_volume_device", "kf_upload_volume_device", "kf_resize_slab", "kf_count_layer_work", "kf_read_layer_work",
 ]
 
 
@@ -378,6 +379,27 @@ class Context:
         z1 = z0 + tsdf.shape[0]
         cc = np.ascontiguousarray(color, np.uint8) if color is not None else None
         _chk(self.lib.kf_upload_volume(self.h, z0, z1, _p(tsdf), _p(weight), _p(cc) if cc is not None else None), "kf_upload_volume")
+
+    def download_volume_device(self, z0, z1, dev_tsdf, dev_weight):
+        _chk(self.lib.kf_download_volume_device(self.h, z0, z1, C.c_void_p(dev_tsdf), C.c_void_p(dev_weight), None), "kf_download_volume_device")
+
+    def upload_volume_device(self, z0, z1, dev_tsdf, dev_weight):
+        _chk(self.lib.kf_upload_volume_device(self.h, z0, z1, C.c_void_p(dev_tsdf), C.c_void_p(dev_weight), None), "kf_upload_volume_device")
+
+    def resize_slab(self, z0, z1, halo):
+        """own [z0, z1) (+ halo) from now on: layers stored before and after keep their voxels, new ones read as never observed"""
+        _chk(self.lib.kf_resize_slab(self.h, z0, z1, halo), "kf_resize_slab")
+        z0s, z1s = C.c_uint32(), C.c_uint32()
+        _chk(self.lib.kf_stored_z_range(self.h, C.byref(z0s), C.byref(z1s)), "kf_stored_z_range")
+        self.stored, self.owned = (z0s.value, z1s.value), (z0, z1)
+
+    def count_layer_work(self, frames):
+        _chk(self.lib.kf_count_layer_work(self.h, int(frames)), "kf_count_layer_work")
+
+    def read_layer_work(self, reset=True):
+        out = np.zeros(self.res // 8, np.uint64)
+        _chk(self.lib.kf_read_layer_work(self.h, _p(out), int(reset)), "kf_read_layer_work")
+        return out
 
     def reset_volume(self):
         _chk(self.lib.kf_reset_volume(self.h), "kf_reset_volume")

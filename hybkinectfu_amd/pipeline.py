@@ -201,6 +201,83 @@ def slab_halo_layers(res, size, ray_increment):
     return ((need + 7) // 8) * 8
 
 
+def stored_range(owned, halo, res):
+    """brick-aligned layers a rank with owned range `owned` stores: own + halo per side, clipped to the volume (kf_create / kf_resize_slab)"""
+    hb = (int(halo) + 7) // 8
+    return (max(0, owned[0] - 8 * hb), min(res, owned[1] + 8 * hb))
+
+
+def busiest_rank_work(ranges, layer_work, halo):
+    """work (own + halo brick layers) of the busiest rank under `ranges` -- what slab_ranges minimises"""
+    hb = (int(halo) + 7) // 8
+    nb = len(layer_work)
+    return max(sum(layer_work[max(0, a // 8 - hb):min(nb, b // 8 + hb)]) for a, b in ranges)
+
+
+def plan_migration(old_ranges, new_ranges, halo, res):
+    """Which voxel layers move between which ranks when the owned ranges change from old_ranges to new_ranges: a list of (src, dst, z0, z1),
+    brick aligned, in ONE canonical order every rank derives for itself (no negotiation).  A rank needs every layer of its NEW stored range
+    (own + halo) that it did not store before; the source of a layer is the rank that OWNED it before (its halo copies on the neighbours are
+    bit-identical -- both re-integrate them -- but the owner is the one deterministic choice).  Consecutive layers with the same source travel
+    as one piece."""
+    world = len(old_ranges)
+    owner_of = {}
+    for r, (a, b) in enumerate(old_ranges):
+        for L in range(a // 8, b // 8):
+            owner_of[L] = r
+    plan = []
+    for d in range(world):
+        o0, o1 = stored_range(old_ranges[d], halo, res)
+        n0, n1 = stored_range(new_ranges[d], halo, res)
+        run = None                                              # (src, first layer, one past the last)
+        for L in range(n0 // 8, n1 // 8):
+            src = None if o0 // 8 <= L < o1 // 8 else owner_of[L]
+            if run is not None and (src != run[0] or src is None):
+                plan.append((run[0], d, run[1] * 8, run[2] * 8)); run = None
+            if src is not None:
+                run = (src, L, L + 1) if run is None else (run[0], run[1], L + 1)
+        if run is not None:
+            plan.append((run[0], d, run[1] * 8, run[2] * 8))
+    return sorted(plan, key=lambda t: (t[2], t[1], t[0]))
+
+
+class SlabMigrator:
+    """Moves voxel layers between ranks when the slab boundaries change (the xGMI exchange of boundary slabs the design needs: a long sequence
+    that turns the camera shifts the work along z, and a frame lasts as long as the busiest rank needs).
+
+        plan = plan_migration(old, new)            the same list on every rank
+        senders export their pieces                BEFORE their own resize may drop them
+        resize(new owned range)                    layers stored before and after keep their voxels, new ones start unobserved
+        for every piece, in plan order:            dist.send on the source, dist.recv + import on the destination
+
+    export(z0, z1) -> tensor, import_(z0, z1, tensor), resize(z0, z1) and alloc(z0, z1) -> empty tensor are the rank's volume operations
+    (SlabPipeline: kf_download_volume_device / kf_upload_volume_device / kf_resize_slab on torch CUDA tensors; the CPU-only tests: a numpy
+    stand-in), wire / unwire convert a piece to and from what the process group can carry (gloo: CPU tensors).  Blocking sends and receives
+    in one global order cannot deadlock: the earliest unfinished piece always has both its ends free."""
+
+    def __init__(self, dist, rank, world, res, halo, export, import_, resize, alloc, wire=None, unwire=None):
+        self.dist, self.rank, self.world, self.res, self.halo = dist, rank, world, res, halo
+        self.export, self.import_, self.resize, self.alloc = export, import_, resize, alloc
+        self.wire = wire or (lambda t: t)
+        self.unwire = unwire or (lambda t: t)
+
+    def migrate(self, old_ranges, new_ranges):
+        plan = plan_migration(old_ranges, new_ranges, self.halo, self.res)
+        outgoing = {i: self.wire(self.export(z0, z1)) for i, (s, d, z0, z1) in enumerate(plan) if s == self.rank}
+        self.resize(*new_ranges[self.rank])
+        moved = 0
+        for i, (s, d, z0, z1) in enumerate(plan):
+            if s == self.rank:
+                self.dist.send(outgoing.pop(i), dst=d)
+                moved += z1 - z0
+            elif d == self.rank:
+                buf = self.wire(self.alloc(z0, z1))
+                self.dist.recv(buf, src=s)
+                self.import_(z0, z1, self.unwire(buf))
+                moved += z1 - z0
+        return plan, moved
+
+
 class SlabPipeline:
     """One rank of the z-slab partitioned pipeline.
 
@@ -210,7 +287,8 @@ class SlabPipeline:
     by SlabExchange's two all-reduces.
     """
 
-    def __init__(self, kcam, res, size, wl=None, rank=0, world=1, device=0, max_triangles=0, icp_mode="replicated", tracker="icp", ranges=None):
+    def __init__(self, kcam, res, size, wl=None, rank=0, world=1, device=0, max_triangles=0, icp_mode="replicated", tracker="icp", ranges=None,
+                 rebalance_every=0, rebalance_gain=0.10, rebalance_sample=4):
         import torch
         import torch.distributed as dist
         self.icp_mode = icp_mode            # "replicated" (default, faster at VGA) or "allreduce" (pixels split over the ranks)
@@ -240,6 +318,17 @@ class SlabPipeline:
                                unpack=lambda cand: c.set_model_maps_rays(None, cand.data_ptr()))
         self.sums = torch.zeros(32, dtype=torch.float32, device=dev)
         self._merge_events = None           # time_merge(True): (start, end) torch event pairs around every frame's merge
+        # dynamic re-balancing of the slab boundaries: every `rebalance_every` frames the ranks pool the work per brick layer that the fusion pass
+        # counted over the last `rebalance_sample` frames, re-run slab_ranges (deterministic: every rank computes the same boundaries) and, when the
+        # busiest rank's work drops by more than `rebalance_gain`, move the layers that change owner (SlabMigrator).  0: boundaries stay as given.
+        self.res, self.size, self.dev = int(res), float(size), dev
+        self.rebalance_every, self.rebalance_gain, self.rebalance_sample = int(rebalance_every), float(rebalance_gain), max(1, int(rebalance_sample))
+        self.migrations = []                # [(frame, old ranges, new ranges, voxel layers this rank sent or received)]
+        cpu_wire = world > 1 and dist.is_initialized() and dist.get_backend() == "gloo"       # rehearsals: gloo carries CPU tensors only
+        self.migrator = SlabMigrator(dist, rank, world, self.res, self.halo, export=self._export_layers, import_=self._import_layers,
+                                     resize=lambda z0, z1: c.resize_slab(z0, z1, self.halo),
+                                     alloc=lambda z0, z1: torch.empty((2, z1 - z0, self.res, self.res), dtype=torch.float32, device=dev),
+                                     wire=(lambda t: t.cpu()) if cpu_wire else None, unwire=(lambda t: t.to(dev)) if cpu_wire else None)
 
     def process_frame_device(self, dev_mm_ptr, frame_id, next_mm_ptr=None):
         with self.torch.cuda.stream(self.stream):
@@ -250,8 +339,63 @@ class SlabPipeline:
         c.set_depth_mm_device(dev_mm_ptr)
         c.preprocess(P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
 
+    # ---- slab boundaries that follow the work ----
+    def _export_layers(self, z0, z1):
+        t = self.torch.empty((2, z1 - z0, self.res, self.res), dtype=self.torch.float32, device=self.dev)
+        self.ctx.download_volume_device(z0, z1, t[0].data_ptr(), t[1].data_ptr())
+        self.stream.synchronize()
+        return t
+
+    def _import_layers(self, z0, z1, t):
+        t = t.contiguous()
+        self.ctx.upload_volume_device(z0, z1, t[0].data_ptr(), t[1].data_ptr())
+        self.stream.synchronize()             # (t may be freed by the caller)
+
+    def pooled_layer_work(self):
+        """work per brick layer of the WHOLE volume: every layer's count comes from the rank that owns it (a collective)"""
+        import numpy as np
+        torch, dist = self.torch, self.dist
+        mine = torch.from_numpy(self.ctx.read_layer_work(reset=True).astype(np.int64))
+        if self.world == 1:
+            return mine.numpy().astype(np.float64)
+        on_dev = dist.get_backend() != "gloo"
+        mine = mine.to(self.dev) if on_dev else mine
+        every = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(every, mine)
+        work = np.zeros(self.res // 8, np.float64)
+        for r, (a, b) in enumerate(self.ranges):
+            work[a // 8:b // 8] = every[r].cpu().numpy()[a // 8:b // 8]
+        return work
+
+    def rebalance(self, frame_id=-1, force_ranges=None):
+        """A collective: pool the sampled work per brick layer, compute the boundaries that minimise the busiest rank and migrate when that
+        pays (or to `force_ranges`, tests).  Returns the new ranges when layers moved, else None."""
+        with self.torch.cuda.stream(self.stream):
+            work = self.pooled_layer_work()
+            old = list(self.ranges)
+            if force_ranges is not None:
+                new = [tuple(r) for r in force_ranges]
+            else:
+                if work.sum() <= 0:
+                    return None
+                new = slab_ranges(self.res, self.world, work.tolist(), halo=self.halo)
+                if busiest_rank_work(new, work.tolist(), self.halo) > (1.0 - self.rebalance_gain) * busiest_rank_work(old, work.tolist(), self.halo):
+                    return None
+            if new == old:
+                return None
+            self.sync()
+            plan, moved = self.migrator.migrate(old, new)
+            self.ranges, self.slab = new, new[self.rank]
+            self.migrations.append((frame_id, old, new, moved))
+            return new
+
     def _process_frame_device(self, dev_mm_ptr, frame_id, next_mm_ptr):
         c, dist, ex = self.ctx, self.dist, self.ex
+        if self.rebalance_every and frame_id > 0:
+            if frame_id % self.rebalance_every == 0:
+                self.rebalance(frame_id)
+            elif (frame_id + self.rebalance_sample) % self.rebalance_every == 0:
+                c.count_layer_work(self.rebalance_sample)             # the frames right before the next check are the sample
         self._preprocess(dev_mm_ptr)                                      # (adopts the set the previous frame's launches prepared, if they did)
         if next_mm_ptr is not None:
             # the next frame's front end rides in this frame's launches (kf_prefetch_frame): gate + bilateral in the tracking launch when the persistent

@@ -238,6 +238,20 @@ int kf_upload_volume(kf_ctx* ctx, uint32_t z_begin, uint32_t z_end, const float*
 int kf_get_volume_stats(kf_ctx* ctx, kf_volume_stats* out);                /* blocking */
 int kf_stored_z_range(kf_ctx* ctx, uint32_t* z_begin, uint32_t* z_end);
 
+/* z-slab re-balancing (BASELINE.json north_star "xGMI ... exchange of boundary slabs").  No reference counterpart: the reference
+ * holds one whole volume (src/cuda/tsdfVolume.h:29-37).
+ * kf_download_volume_device / kf_upload_volume_device: kf_download_volume / kf_upload_volume with caller-owned DEVICE buffers, asynchronous on the
+ *   context's stream -- the planes two ranks exchange (torch.distributed send / recv: RCCL point-to-point) when a brick layer changes its owner.
+ * kf_resize_slab: the context now owns [z_begin, z_end) (+ halo): layers stored before and after keep their voxels, new layers read as never observed
+ *   until uploaded, the rest is dropped; pose, tracker state, frame maps and counters stay.  Blocking.
+ * kf_count_layer_work / kf_read_layer_work: per brick layer (resolution / 8 entries) the voxels of queued bricks the next `frames` integrate calls update:
+ *   the work measure the boundaries are balanced on. */
+int kf_download_volume_device(kf_ctx* ctx, uint32_t z_begin, uint32_t z_end, float* dev_tsdf, float* dev_weight, uint8_t* dev_color);
+int kf_upload_volume_device(kf_ctx* ctx, uint32_t z_begin, uint32_t z_end, const float* dev_tsdf, const float* dev_weight, const uint8_t* dev_color);
+int kf_resize_slab(kf_ctx* ctx, uint32_t z_begin, uint32_t z_end, uint32_t halo);
+int kf_count_layer_work(kf_ctx* ctx, int frames);
+int kf_read_layer_work(kf_ctx* ctx, uint64_t* out, int reset);                /* blocking */
+
 /* test hook: counts fp32 quotients where the kernels' split exact-division helper differs from the compiler's `/` (must be 0) */
 int kf_selftest_div(kf_ctx* ctx, unsigned n, unsigned seed, int mode, unsigned* mismatches);
 

@@ -73,3 +73,47 @@ def synthetic_candidates(rows, cols, rank, world, seed):
     has = (owner < world).unsqueeze(-1)
     want_v, want_n = unpack(torch.where(has, c_true, zero).contiguous())
     return t.contiguous(), cand.contiguous(), want_v, want_n
+
+
+# ---- a numpy stand-in for one rank's slab of the volume: what SlabMigrator moves, without a GPU ---------------------------------------------------
+class FakeSlab:
+    """The volume operations SlabMigrator needs, with kf_resize_slab's semantics, on a numpy array: layers stored before and after a resize keep
+    their content, new layers read as zeros (never observed) until imported."""
+
+    def __init__(self, res, owned, halo, xy=4):
+        from hybkinectfu_amd import pipeline as PL
+        self.PL, self.res, self.halo, self.xy = PL, res, halo, xy
+        self.owned = tuple(owned)
+        self.stored = PL.stored_range(self.owned, halo, res)
+        self.data = np.zeros((2, self.stored[1] - self.stored[0], xy, xy), np.float32)
+
+    @staticmethod
+    def truth(z0, z1, xy, frame=0):
+        """what layers [z0, z1) hold after `frame` fused frames: a function of (plane, z, y, x) -- any rank that integrates a layer arrives at it"""
+        z = np.arange(z0, z1, dtype=np.float32).reshape(1, -1, 1, 1)
+        y = np.arange(xy, dtype=np.float32).reshape(1, 1, -1, 1)
+        x = np.arange(xy, dtype=np.float32).reshape(1, 1, 1, -1)
+        p = np.arange(2, dtype=np.float32).reshape(-1, 1, 1, 1)
+        return (np.sin(z * 0.37 + y * 1.3 + x * 2.1 + p) + np.float32(frame) * (z + 1.0)).astype(np.float32)
+
+    def integrate(self, frame):
+        self.data[...] = self.truth(self.stored[0], self.stored[1], self.xy, frame)      # own AND halo layers, as the real slab re-integrates both
+
+    def export(self, z0, z1):
+        assert self.stored[0] <= z0 < z1 <= self.stored[1]
+        return torch.from_numpy(self.data[:, z0 - self.stored[0]:z1 - self.stored[0]].copy())
+
+    def import_(self, z0, z1, t):
+        assert self.stored[0] <= z0 < z1 <= self.stored[1]
+        self.data[:, z0 - self.stored[0]:z1 - self.stored[0]] = t.numpy()
+
+    def resize(self, z0, z1):
+        new_stored = self.PL.stored_range((z0, z1), self.halo, self.res)
+        fresh = np.zeros((2, new_stored[1] - new_stored[0], self.xy, self.xy), np.float32)
+        lo, hi = max(new_stored[0], self.stored[0]), min(new_stored[1], self.stored[1])
+        if hi > lo:
+            fresh[:, lo - new_stored[0]:hi - new_stored[0]] = self.data[:, lo - self.stored[0]:hi - self.stored[0]]
+        self.data, self.stored, self.owned = fresh, new_stored, (z0, z1)
+
+    def alloc(self, z0, z1):
+        return torch.empty((2, z1 - z0, self.xy, self.xy), dtype=torch.float32)

@@ -350,3 +350,108 @@ def test_sdf_tracker_on_slabs_matches_whole_volume_and_oracle(world):
     thin.close()
     for c in [whole] + slabs:
         c.close()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("world,new_cuts", [(2, [0, 40, 128]), (3, [0, 88, 96, 128]), (3, [0, 16, 40, 128])])
+def test_layers_change_owner_between_slab_contexts(world, new_cuts):
+    """Dynamic slab boundaries on the device side: pipeline.plan_migration's pieces leave their old owner through kf_download_volume_device (pending
+    deferred weights applied on the way), every context takes its new range with kf_resize_slab (layers stored before and after keep their voxels),
+    the pieces arrive through kf_upload_volume_device -- and the slabs go on fusing.  Before and after, every stored layer (own + halo) equals the
+    whole-volume context bit for bit; so do the concatenated marching-cubes extractions and the per-slab update counts' sum."""
+    cam, size, res = S.vga_camera(), 3.0, 128
+    kcam = K.camera(*cam)
+    trunc = 5 * size / res
+    halo = PL.slab_halo_layers(res, size, 0.7 * trunc)
+    old = PL.slab_ranges(res, world)
+    new = [(new_cuts[i], new_cuts[i + 1]) for i in range(world)]
+    whole = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=600000)
+    slabs = [K.Context(kcam, res, size, P["volume_max_weight"], levels=3, max_triangles=600000, slab=r, halo=halo) for r in old]
+    for c in [whole] + slabs:
+        c.set_defer(1)                                            # pending counts exist when the layers leave (frames 1, 2 defer whole free-space quarters)
+
+    def fuse(k):
+        pose = S.trajectory_pose(k, size).astype(np.float32)
+        mm = S.render_depth_mm(pose, cam, size)
+        for c in [whole] + slabs:
+            c.upload_depth_mm(mm)
+            c.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+            c.integrate(pose, trunc, 2.5)
+
+    def check():
+        for c in slabs:
+            z0, z1 = c.stored
+            tw, ww = whole.download_volume(z0, z1)
+            t, w = c.download_volume(z0, z1)
+            assert np.array_equal(bits(t), bits(tw)) and np.array_equal(bits(w), bits(ww)), (c.owned, c.stored)
+        assert sum(c.stats()["weight_gt0"] for c in slabs) == whole.stats()["weight_gt0"]
+
+    for k in range(3):
+        fuse(k)
+    check()
+    plan = PL.plan_migration(old, new, halo, res)
+    assert plan
+    dev = torch.device("cuda", 0)
+    pieces = []
+    for s, d, z0, z1 in plan:                                      # every piece leaves its old owner before anybody resizes
+        t = torch.empty((2, z1 - z0, res, res), dtype=torch.float32, device=dev)
+        slabs[s].download_volume_device(z0, z1, t[0].data_ptr(), t[1].data_ptr())
+        slabs[s].sync()
+        pieces.append(t)
+    for c, r in zip(slabs, new):
+        c.resize_slab(r[0], r[1], halo)
+        assert c.owned == tuple(r) and c.stored == PL.stored_range(r, halo, res)
+    for (s, d, z0, z1), t in zip(plan, pieces):
+        slabs[d].upload_volume_device(z0, z1, t[0].data_ptr(), t[1].data_ptr())
+        slabs[d].sync()
+    check()                                                        # nothing lost, nothing invented
+    for k in range(3, 6):
+        fuse(k)
+    check()
+    thr = 300 * size / res
+    whole.marching_cubes(thr)
+    wt = whole.triangles()
+    parts = []
+    for c in slabs:
+        c.marching_cubes(thr)
+        parts.append(c.triangles())
+    cat = np.concatenate(parts)
+    assert len(wt) > 1000 and np.array_equal(cat.view(np.uint32), wt.view(np.uint32))
+    for c in [whole] + slabs:
+        c.close()
+
+
+def test_layer_work_counts_the_updates_per_brick_layer():
+    """kf_count_layer_work / kf_read_layer_work: the work measure the slab boundaries are balanced on.  With deferral off nothing is retired by the
+    cull, so a sampled frame's counts are its update counts per brick layer -- compared with the oracle's (first frame into an empty volume: the
+    updated voxels are the ones whose weight became 1); a slab context reports its stored layers only; unsampled frames add nothing."""
+    cam, size, res = S.vga_camera(), 3.0, 128
+    kcam, ocam = K.camera(*cam), O.Cam.make(*cam)
+    trunc = 5 * size / res
+    pose = S.trajectory_pose(0, size).astype(np.float32)
+    mm = S.render_depth_mm(pose, cam, size)
+    tr = O.trunc_depth(O.depth_mm_to_m(mm), P["depth_trunc_min"], P["depth_trunc_max"])
+    nrm = O.vertices_to_normals(O.depth_to_vertices(O.bilateral(tr, P["filter_sigma_pixel"], P["filter_sigma_depth"]), ocam))
+    ovol = O.OVolume(res, size, P["volume_max_weight"])
+    n_o = O.integrate(ovol, tr, nrm, None, False, False, pose, trunc, 2.5, ocam, ocam)
+    want = (ovol.weight > 0).reshape(res // 8, -1).sum(axis=1).astype(np.uint64)
+    assert int(want.sum()) == n_o
+    whole = K.Context(kcam, res, size, P["volume_max_weight"], levels=3)
+    slab = K.Context(kcam, res, size, P["volume_max_weight"], levels=3, slab=(48, 88), halo=8)
+    for c in (whole, slab):
+        c.set_defer(0)
+        c.count_layer_work(1)
+        for _ in range(2):                                        # the second frame is not sampled
+            c.upload_depth_mm(mm)
+            c.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+            c.integrate(pose, trunc, 2.5)
+    got = whole.read_layer_work()
+    assert np.array_equal(got, want), (got, want)
+    gs = slab.read_layer_work()
+    lo, hi = slab.stored[0] // 8, slab.stored[1] // 8
+    assert np.array_equal(gs[lo:hi], want[lo:hi]) and not gs[:lo].any() and not gs[hi:].any()
+    assert not whole.read_layer_work().any()                       # read with reset: cleared
+    whole.close(); slab.close()

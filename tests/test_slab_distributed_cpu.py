@@ -172,3 +172,71 @@ def test_balanced_slab_ranges_minimise_the_busiest_rank():
     assert got <= best * (1 + 1e-6)
     with pytest.raises(ValueError):
         PL.slab_ranges(64, 9)
+
+
+# ---- dynamic slab boundaries: layers change their owner over the wire ---------------------------------------------------------------------------
+def test_migration_plan_covers_exactly_what_a_rank_lacks():
+    """plan_migration: every layer of a rank's NEW stored range (own + halo) that it did not store before arrives exactly once, from the rank that
+    owned it; nothing else moves; the plan is the same whoever computes it."""
+    rng = np.random.default_rng(5)
+    for res, world, halo in ((128, 2, 8), (128, 3, 8), (256, 4, 16), (512, 8, 8), (64, 2, 0)):
+        nb = res // 8
+        for _ in range(40):
+            cuts = lambda: [0] + sorted(rng.choice(np.arange(1, nb), world - 1, replace=False).tolist()) + [nb]
+            a, b = cuts(), cuts()
+            old = [(a[i] * 8, a[i + 1] * 8) for i in range(world)]
+            new = [(b[i] * 8, b[i + 1] * 8) for i in range(world)]
+            plan = PL.plan_migration(old, new, halo, res)
+            assert plan == PL.plan_migration(list(old), list(new), halo, res)
+            got = {d: set() for d in range(world)}
+            for s, d, z0, z1 in plan:
+                assert s != d and z0 % 8 == 0 and z1 % 8 == 0 and z0 < z1
+                assert old[s][0] <= z0 and z1 <= old[s][1]                      # the source owned every layer of the piece
+                layers = set(range(z0, z1))
+                assert not (layers & got[d])
+                got[d] |= layers
+            for d in range(world):
+                o, n = PL.stored_range(old[d], halo, res), PL.stored_range(new[d], halo, res)
+                assert got[d] == set(range(n[0], n[1])) - set(range(o[0], o[1]))
+
+
+def _migration_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import slab_cpu_ops as ops
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res, halo = 192, 8
+    ranges = PL.slab_ranges(res, world)
+    slab = ops.FakeSlab(res, ranges[rank], halo)
+    mig = PL.SlabMigrator(dist, rank, world, res, halo, slab.export, slab.import_, slab.resize, slab.alloc)
+    rng = np.random.default_rng(11)                                             # identical on every rank
+    ok, moved_total = True, 0
+    nb = res // 8
+    for step in range(6):
+        slab.integrate(step)                                                     # every rank fuses the frame into what it stores
+        if step == 3:                                                            # the boundaries the balancer itself would pick for a far-heavy workload
+            work = np.where(np.arange(nb) > nb // 2, 5.0, 0.2)
+            new = PL.slab_ranges(res, world, work.tolist(), halo=halo)
+        else:
+            cuts = [0] + sorted(rng.choice(np.arange(1, nb), world - 1, replace=False).tolist()) + [nb]
+            new = [(cuts[i] * 8, cuts[i + 1] * 8) for i in range(world)]
+        plan, moved = mig.migrate(ranges, new)
+        moved_total += moved
+        ranges = new
+        ok = ok and slab.owned == tuple(new[rank]) and slab.stored == PL.stored_range(new[rank], halo, res)
+        ok = ok and np.array_equal(slab.data.view(np.uint32), ops.FakeSlab.truth(slab.stored[0], slab.stored[1], slab.xy, step).view(np.uint32))
+    flag = torch.tensor([1 if ok else 0, moved_total], dtype=torch.int64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    open(os.path.join(out_dir, "mig%d.txt" % rank), "w").write("ok %d" % flag[1].item() if flag[0].item() else "mismatch")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_layers_migrate_between_ranks_gloo(tmp_path, world):
+    """SlabMigrator over a gloo group: after every change of the boundaries (random ones, and the balancer's own) each rank holds, bit for bit, what
+    it would hold had it integrated its new stored range from the start -- own layers and halo, whichever rank they came from."""
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_migration_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        txt = open(os.path.join(str(tmp_path), "mig%d.txt" % r)).read()
+        assert txt.startswith("ok"), (r, txt)

@@ -4,7 +4,11 @@
 The parent touches no GPU; it starts N rank processes (torch.distributed.run).  The ranks share GPU 0 and form a gloo group
 (RCCL refuses two ranks on one device), run SlabPipeline -- real kernels, real collectives, the launcher path bench.py uses --
 for a few frames, and every rank compares against SingleGpuPipeline run in the same process: tracked poses and merged model
-maps bit for bit, its owned volume layers bit for bit.  Prints `REHEARSAL OK ranks=N` from rank 0 on success."""
+maps bit for bit, its owned volume layers bit for bit.  Prints `REHEARSAL OK ranks=N` from rank 0 on success.
+
+--rebalance-every K: the slab boundaries follow the work (SlabPipeline.rebalance: work per brick layer counted by the fusion pass, pooled, slab_ranges
+re-run, layers that change owner sent rank to rank) -- with --yaw D / --dolly M the camera turns by D degrees and moves M metres into the scene over
+the sequence, so the work shifts along z and migrations happen; the comparison with the single-GPU pipeline then covers frames before and after them."""
 import argparse
 import os
 import subprocess
@@ -28,12 +32,19 @@ def worker(a):
     res, size, cam = a.res, a.size, S.vga_camera()
     wl = dict(trunc_max=P["depth_trunc_max"], integ_dist=P["integrate_depth_trunc"])
     n = a.frames
-    frames = np.stack([S.render_depth_mm(S.trajectory_pose(k, size), cam, size) for k in range(n)])
+    def pose_of(k):                                       # the stock circle, plus a slow turn and a dolly into the scene (the work moves along z)
+        p = S.trajectory_pose(k, size)
+        f = k / max(n - 1, 1)
+        yaw = np.radians(a.yaw) * f
+        turn = np.array([[np.cos(yaw), 0, np.sin(yaw), 0], [0, 1, 0, 0], [-np.sin(yaw), 0, np.cos(yaw), a.dolly * f], [0, 0, 0, 1.0]])
+        return p @ turn
+    frames = np.stack([S.render_depth_mm(pose_of(k), cam, size) for k in range(n)])
     dev = torch.from_numpy(frames.astype(np.int16)).cuda()
     fb = cam[0] * cam[1] * 2
     outs = []
     for cls in (PL.SingleGpuPipeline, PL.SlabPipeline):
-        pipe = cls(K.camera(*cam), res, size, wl) if cls is PL.SingleGpuPipeline else cls(K.camera(*cam), res, size, wl, rank=rank, world=world)
+        pipe = (cls(K.camera(*cam), res, size, wl) if cls is PL.SingleGpuPipeline else
+                cls(K.camera(*cam), res, size, wl, rank=rank, world=world, rebalance_every=a.rebalance_every, rebalance_sample=2))
         poses = []
         for k in range(n):
             nxt = dev.data_ptr() + (k + 1) * fb if (k % 2 == 0 and k + 1 < n) else None
@@ -46,12 +57,19 @@ def worker(a):
         z0, z1 = pipe.ctx.owned
         vol = pipe.ctx.download_volume(z0, z1)
         outs.append((poses, maps, vol, (z0, z1), pipe.stats()["updated_total"]))
+        if cls is PL.SlabPipeline:
+            for (f, old, new, moved) in pipe.migrations:
+                print("rank %d: frame %d boundaries %s -> %s, %d voxel layers sent / received here" % (rank, f, old, new, moved), flush=True)
+            n_mig = len(pipe.migrations)
         pipe.close()
     (p1, m1, v1, _, _), (p2, m2, v2, (z0, z1), upd) = outs
     ok = all(np.array_equal(a_, b_) for a_, b_ in zip(p1, p2))
     ok = ok and all(np.array_equal(a_.view(np.uint32), b_.view(np.uint32)) for a_, b_ in zip(m1, m2))
     ok = ok and np.array_equal(v1[0][z0:z1].view(np.uint32), v2[0].view(np.uint32)) and np.array_equal(v1[1][z0:z1], v2[1])
     valid = int((m2[0][..., 3] != 0).sum())
+    if a.rebalance_every and a.expect_migration and n_mig == 0:
+        ok = False
+        print("rank %d: no migration happened" % rank, flush=True)
     flag = torch.tensor([1 if ok else 0, valid], dtype=torch.int64)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     print("rank %d: slab z[%d,%d) poses/maps/volume %s, %d valid model pixels, %d voxel updates" % (rank, z0, z1, "bit-exact" if ok else "MISMATCH", valid, upd), flush=True)
@@ -67,6 +85,10 @@ def main():
     ap.add_argument("--res", type=int, default=384)
     ap.add_argument("--size", type=float, default=3.0)
     ap.add_argument("--frames", type=int, default=6)
+    ap.add_argument("--rebalance-every", type=int, default=0)
+    ap.add_argument("--yaw", type=float, default=0.0, help="degrees the camera turns over the sequence")
+    ap.add_argument("--dolly", type=float, default=0.0, help="metres the camera moves into the scene over the sequence")
+    ap.add_argument("--expect-migration", action="store_true", help="fail when the run ends without a single migration")
     a = ap.parse_args()
     if "WORLD_SIZE" in os.environ:
         sys.exit(worker(a))
