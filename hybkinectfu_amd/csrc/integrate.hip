@@ -153,8 +153,11 @@ __global__ void __launch_bounds__(CULL_WAVES * 64) __attribute__((amdgpu_waves_p
   const int nmxy = (v.nb + 3) >> 2;                          // macro cells per x / y
   const int mz0 = v.bz0 >> 2, mz1 = (v.bz1 + 3) >> 2;        // macro layers touching the stored bricks
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * CULL_WAVES + wid;
   const int n_macro = nmxy * nmxy * (mz1 - mz0);
+  // (Several groups of cells per workgroup -- fewer, longer waves for the 262 144 macro cells of 2048^3 -- were measured and lost: the walking form needs
+  // 112 registers, one workgroup per CU, and a block barrier pair per group: integrate stage 767 -> 801 / 817 / 889 us at 2, 4, 8 groups, 159 -> 177 us at
+  // 1024^3, profiles/r04_deferred_weights.txt.)
+  const int wave = blockIdx.x * CULL_WAVES + wid;
   const int mx = wave % nmxy, my = (wave / nmxy) % nmxy, mz = wave / (nmxy * nmxy) + mz0;
   const float* m = a.tinv ? a.tinv : a.tinv_val.m;
   const float cell = v.cell;
@@ -469,7 +472,7 @@ __device__ __forceinline__ uint2 integrate_color_update2(uint2 oc, unsigned col0
 // the running average of tsdfVolume.h:68-70 keeps the reference's double-precision weight expression and its IEEE quotients.  Colour
 // changes even where (tsdf, weight) no longer do and blends with the weight, so COLOR excludes DEFER (pending counts are flushed before a
 // colour frame and the words cleared behind it: kf_integrate_volume).
-template <int BR, bool DEFER, bool COLOR = false>
+template <int BR, bool DEFER, bool COLOR = false, bool LAYERS = false>
 __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   static_assert(!(DEFER && COLOR), "colour changes where (tsdf, weight) do not, and blends with the weight: no deferral");
   const KfVolume& v = a.vol;
@@ -487,10 +490,10 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   unsigned short* const pend16 = reinterpret_cast<unsigned short*>(v.pend);      // quarter q of brick slot s: pend16[4 s + q]
   const KfRecip2 r075 = kf_recip2(f2_splat(0.75f));                     // COLOR: the angle weight's |nz| / 0.75
   __shared__ unsigned s_upd;
-  __shared__ unsigned s_layer[1024];                                     // sampled frames only: this workgroup's update counts per brick layer (kf_create: <= 1024 brick layers)
+  __shared__ unsigned s_layer[LAYERS ? 1024 : 1];                        // LAYERS (sampled frames: a launch of its own instantiation): this workgroup's update counts per brick layer (kf_create: <= 1024 brick layers)
   unsigned upd_total = 0;
   if (threadIdx.x == 0) s_upd = 0;
-  if (a.layer_work) for (int i = threadIdx.x; i < v.nb; i += 256) s_layer[i] = 0u;       // uniform
+  if (LAYERS) for (int i = threadIdx.x; i < v.nb; i += 256) s_layer[i] = 0u;
   __syncthreads();
   // The queue entries of an iteration are requested one iteration ahead.  On gfx9-family hardware loads and stores share one in-order
   // counter (vmcnt): a queue load issued AFTER the previous iteration's voxel stores can only be waited for together with them, which
@@ -590,7 +593,7 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
       upd1[b] = ok1[b] && d[b].y != 0.f && d[b].y < a.max_dist && sdf[b].y > -a.sdf_trunc;
       if (COLOR) { upd0[b] = upd0[b] && okc0[b]; upd1[b] = upd1[b] && okc1[b]; }              // :59-62 `continue` when the colour pixel is outside
     }
-    if (a.layer_work) {                                                    // uniform; a sampled frame: every wave adds its quarter's updates to the brick layer's count
+    if (LAYERS) {                                                          // a sampled frame: every wave adds its quarter's updates to the brick layer's count
 #pragma unroll
       for (int b = 0; b < BR; ++b) {
         const unsigned n = (unsigned)__popcll(__ballot(upd0[b])) + (unsigned)__popcll(__ballot(upd1[b]));
@@ -752,7 +755,7 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   if ((threadIdx.x & 63) == 0 && s > 0.f) atomicAdd(&s_upd, (unsigned)s);
   __syncthreads();
   if (threadIdx.x == 0 && s_upd) atomicAdd(&a.cnt->upd_shard[a.parity][(blockIdx.x & 63) * 16], (unsigned long long)s_upd);
-  if (a.layer_work) for (int i = threadIdx.x; i < v.nb; i += 256) { const unsigned n = s_layer[i]; if (n) atomicAdd(&a.layer_work[i], (unsigned long long)n); }
+  if (LAYERS) for (int i = threadIdx.x; i < v.nb; i += 256) { const unsigned n = s_layer[i]; if (n) atomicAdd(&a.layer_work[i], (unsigned long long)n); }
 }
 
 #ifdef KF_EXPERIMENTS
@@ -891,8 +894,9 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   {
     const int nmxy = (c->vol.nb + 3) >> 2, nmz = ((c->vol.bz1 + 3) >> 2) - (c->vol.bz0 >> 2);
     const unsigned n_macro = (unsigned)nmxy * nmxy * nmz;                      // one wave per macro cell, sixteen per workgroup
-    if (a.defer_cull) hipLaunchKernelGGL(k_integrate_cull<true>, dim3((n_macro + CULL_WAVES - 1) / CULL_WAVES), dim3(CULL_WAVES * 64), 0, c->stream, a);
-    else hipLaunchKernelGGL(k_integrate_cull<false>, dim3((n_macro + CULL_WAVES - 1) / CULL_WAVES), dim3(CULL_WAVES * 64), 0, c->stream, a);
+    const unsigned cgrid = (n_macro + CULL_WAVES - 1) / CULL_WAVES;
+    if (a.defer_cull) hipLaunchKernelGGL(k_integrate_cull<true>, dim3(cgrid), dim3(CULL_WAVES * 64), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_integrate_cull<false>, dim3(cgrid), dim3(CULL_WAVES * 64), 0, c->stream, a);
   }
   // Workgroups walking the queue.  Large volumes (>= 2^20 stored bricks: the queue holds >~100k bricks): four bricks in flight per workgroup and
   // EIGHT TIMES as many workgroups as the chip holds at once (6 per CU x 256 = 1536 -> 12288: whole rounds; 8192 = 5.33 rounds ended on a third
@@ -947,7 +951,10 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
     else if (a.exp_mode == 12) FUSE_LAUNCH((k_exp_brick_rmw<4, 4>));
     else
 #endif
-    if (pairs) {
+    if (pairs && a.layer_work) {                           // a sampled frame (kf_count_layer_work): the one-brick form that also counts per brick layer
+      if (defer) FUSE_LAUNCH((k_integrate_pairs<1, true, false, true>));
+      else FUSE_LAUNCH((k_integrate_pairs<1, false, false, true>));
+    } else if (pairs) {
       if (defer) {
         if (br == 1) FUSE_LAUNCH((k_integrate_pairs<1, true>));
         else if (br == 2) FUSE_LAUNCH((k_integrate_pairs<2, true>));

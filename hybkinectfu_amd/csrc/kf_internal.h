@@ -26,7 +26,8 @@
 #endif
 #define KF_MAX_LEVELS 3
 #define KF_ICP_MAX_WG 2048             // workgroups of one ICP / SDF step launch (1536 pixels each: up to 3.1 M pixels)
-#define KF_ICP_LOOP_MAX_WG 512         // workgroups of the persistent ICP loop (bounded by the CU count anyway)
+#define KF_ICP_LOOP_MAX_WG 1024        // publishers of one step of the persistent ICP loops (k_icp_loop: its workgroups, bounded by the CU count; k_icp_loop_batched: the
+                                       // workgroups of the dealing, 800 at 1280x960)
 #define KF_ICP_LOOP_STEPS 32           // Gauss-Newton steps of one persistent ICP launch (stock: 4 + 5 + 10)
 
 // Result-changing timing experiments (KF_INTEGRATE_EXP / KF_ICP_EXP / KF_RAYCAST_EXP: skipped stores, partial queues, clock
@@ -174,6 +175,7 @@ struct kf_ctx {
   int inject_stall;                   // kf_inject_track_stall: loop launches that still get a workgroup playing dead
   int loop_refused;                   // the device cannot hold the loop's workgroups at once (occupancy check / cooperative launch refused): never tried again
   int loop_occupancy;                 // workgroups of k_icp_loop one CU can hold (0: not asked yet)
+  int loop_occupancy_batched;         // the same for k_icp_loop_batched
   int last_track_form;                // kf_track_result::launch_form of the last tracking call
   KfTrackState* track;                // device
   KfCounters* counters;               // device

@@ -622,6 +622,8 @@ struct IcpLoopArgs {
   // SIMD and leaves the other CUs idle; the riders are dispatched behind the loop's workgroups (they cannot displace them), wait for
   // nobody, and are long done when the loop ends.  gridDim.x == n_loop: none.
   int n_loop;
+  int n_virtual;                                 // workgroups the pixel dealing is defined for (= the workgroups level 0 needs at ICP_PX pixels per lane, what the per-step form
+                                                 // launches): n_loop in k_icp_loop; larger in k_icp_loop_batched, whose n_loop resident workgroups each play several of them
   KfBilateralArgs bil; int bil_gx, bil_tiles, bil_fast;
 };
 
@@ -748,7 +750,7 @@ __device__ __forceinline__ void icp_solo_finish(const IcpLoopArgs& L, float (*s_
     const float4* __restrict__ new_v = L.new_v[l]; const float4* __restrict__ new_n = L.new_n[l];
     const int npx = a.cam.cols * a.cam.rows;
     int px_l, grid_l;
-    icp_level_geometry(npx, L.n_loop, l, px_l, grid_l);
+    icp_level_geometry(npx, L.n_virtual, l, px_l, grid_l);
     for (int it = 0; it < L.iters[l]; ++it, ++step) {
       if (step > 0) {
         fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, s_abort);
@@ -801,16 +803,18 @@ __device__ __forceinline__ void icp_solo_finish(const IcpLoopArgs& L, float (*s_
     return; \
   } while (0)
 
+// a rider workgroup of a tracking launch: two 64x4 tiles of the NEXT frame's gate + bilateral filter (IcpLoopArgs::bil)
+__device__ __forceinline__ void icp_rider(const IcpLoopArgs& L) {
+  __shared__ float s_bil[2 * (BIL_TX + 8) * (BIL_TY + 8)];
+  const int half = (int)(threadIdx.x >> 8), t = ((int)blockIdx.x - L.n_loop) * 2 + half;
+  const int tt = t < L.bil_tiles ? t : L.bil_tiles;                          // past the last tile: a row below the image, nothing is touched
+  float* tile = s_bil + half * ((BIL_TX + 8) * (BIL_TY + 8));
+  if (L.bil_fast) kf_bilateral_tile<4, true>(L.bil, tt % L.bil_gx, tt / L.bil_gx, (int)(threadIdx.x & 255), tile);
+  else kf_bilateral_tile<4, false>(L.bil, tt % L.bil_gx, tt / L.bil_gx, (int)(threadIdx.x & 255), tile);
+}
+
 __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
-  if ((int)blockIdx.x >= L.n_loop) {                                           // a rider: two 64x4 filter tiles (bilateral_tile.h), then done
-    __shared__ float s_bil[2 * (BIL_TX + 8) * (BIL_TY + 8)];
-    const int half = (int)(threadIdx.x >> 8), t = ((int)blockIdx.x - L.n_loop) * 2 + half;
-    const int tt = t < L.bil_tiles ? t : L.bil_tiles;                          // past the last tile: a row below the image, nothing is touched
-    float* tile = s_bil + half * ((BIL_TX + 8) * (BIL_TY + 8));
-    if (L.bil_fast) kf_bilateral_tile<4, true>(L.bil, tt % L.bil_gx, tt / L.bil_gx, (int)(threadIdx.x & 255), tile);
-    else kf_bilateral_tile<4, false>(L.bil, tt % L.bil_gx, tt / L.bil_gx, (int)(threadIdx.x & 255), tile);
-    return;
-  }
+  if ((int)blockIdx.x >= L.n_loop) { icp_rider(L); return; }                   // a rider: two 64x4 filter tiles (bilateral_tile.h), then done
   __shared__ float s_pose[2][16], s_linv[16];                                  // the running transform lives in one of two buffers: a step writes the other one
   __shared__ float s_wave[27 * (ICP_THREADS / 16)], s_tot[(ICP_THREADS / 32) * 32];
   __shared__ int s_abort;
@@ -848,7 +852,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     const float4* __restrict__ model_v = L.model_v[l]; const float4* __restrict__ model_n = L.model_n[l];
     const int npx = a.cam.cols * a.cam.rows;
     int px_l, grid_l;
-    icp_level_geometry(npx, L.n_loop, l, px_l, grid_l);
+    icp_level_geometry(npx, L.n_virtual, l, px_l, grid_l);
     const bool has_px = (int)blockIdx.x < grid_l;
     // this lane's own vertices / normals depend neither on the running transform nor on the iteration: they are loaded once
     // per pyramid level and stay in registers for all of its iterations (the reference re-reads them 4 / 5 / 10 times)
@@ -925,6 +929,89 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   if (threadIdx.x < 16) st->pose[threadIdx.x] = s_cur[threadIdx.x];
   if (threadIdx.x == 64) kf_mat44_inverse(s_cur, st->pose_inv);               // a lane of another wave: the integrate pass reads it (integrateVolume.cu:84)
   if (threadIdx.x == 0) { st->status = KF_TRACK_OK; st->tracked = 1; st->iterations = applied + 1; st->converged = 0; st->rescued = 0; }    // (the whole verdict: this launch may have run without k_track_begin's reset)
+}
+
+
+// ---- the same loop for images whose level 0 needs more workgroups than the chip holds at once (1280x960: 800) ------------------------------------------
+// The per-step form pays a kernel boundary per Gauss-Newton step and folds 800 x 27 partials from a cold start each time (24 us per step at 1280x960:
+// 0.46 ms of BASELINE config C5's frame).  Here n_loop resident workgroups play the n_virtual workgroups of the dealing in turn -- workgroup p plays p,
+// p + n_loop, ... -- each turn exactly a workgroup's pixel phase, reduction and publication in the per-step form's dealing, so the tagged slots hold the
+// same partial sums and the same fold arrives at the SAME BITS as k_icp_step (tests/test_gpu_track_forms.py).  A lane's pixels cannot stay in registers
+// across steps (several turns share them): they are re-read every step, from L2 / the Infinity Cache (78 MB per step at 1280x960 fit the 256 MiB cache).
+__global__ void __launch_bounds__(ICP_THREADS) k_icp_loop_batched(IcpLoopArgs L) {
+  if ((int)blockIdx.x >= L.n_loop) { icp_rider(L); return; }
+  __shared__ float s_pose[2][16], s_linv[16];
+  __shared__ float s_wave[27 * (ICP_THREADS / 16)], s_tot[(ICP_THREADS / 32) * 32];
+  __shared__ int s_abort;
+  int s_code = STEP_APPLIED, cur_buf = 0;
+  float* s_cur = s_pose[0];
+  KfTrackState* st = L.track;
+  const float pose_e = st->pose[threadIdx.x & 15];                             // ICP.cpp:62 cur_transform = _pose
+  if (__hip_atomic_load(&st->rescue_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == L.tag_base) return;
+  if (L.play_dead && (int)blockIdx.x == L.n_loop - 1) return;
+  if (threadIdx.x < 16) s_cur[threadIdx.x] = pose_e;
+  if (threadIdx.x == 0) s_abort = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) kf_mat44_inverse(s_cur, s_linv);                        // ICP.cpp:63 last_transform_inv
+  __syncthreads();
+  TrackArgs a;
+  a.dist_thres = L.dist_thres; a.sin_thres = L.sin_thres; a.dist_shake = L.dist_shake; a.angle_shake = L.angle_shake; a.cos_shake = L.cos_shake; a.dist_shake2 = L.dist_shake2;
+  a.dist_thres2 = L.dist_thres2; a.sin_thres2 = L.sin_thres2; a.sdf = 0;
+#ifdef KF_EXPERIMENTS
+  a.dbg = nullptr; a.exp_nodet = false;
+#endif
+  int step = 0, n_prev = 0, applied = 0;
+  bool timed_out = false;
+  for (int l = L.levels - 1; l >= 0; --l) {                                      // coarse -> fine, ICP.cpp:65
+    a.cam = L.cam[l];
+    const float4* __restrict__ new_v = L.new_v[l]; const float4* __restrict__ new_n = L.new_n[l];
+    const int npx = a.cam.cols * a.cam.rows;
+    int px_l, grid_l;
+    icp_level_geometry(npx, L.n_virtual, l, px_l, grid_l);
+    for (int it = 0; it < L.iters[l]; ++it, ++step) {
+      if (step > 0) {
+        fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort, 0, &st->rescue_tag, L.tag_base);
+        if (s_abort) { timed_out = true; break; }
+        s_code = apply_step(a, s_tot, s_cur, nullptr, s_pose[cur_buf ^ 1]);
+        if (s_code != STEP_APPLIED) {                                            // same verdict in every workgroup
+          if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; st->converged = 0; st->rescued = 0; }
+          return;
+        }
+        cur_buf ^= 1; s_cur = s_pose[cur_buf];
+        ++applied;
+      }
+      for (int w = (int)blockIdx.x; w < grid_l; w += L.n_loop) {                 // this workgroup's turns
+        float4 iv[ICP_PX], in_[ICP_PX];
+#pragma unroll
+        for (int j = 0; j < ICP_PX; ++j) {
+          const int i = icp_dealt_pixel_of(j, grid_l, w);
+          iv[j] = make_float4(0.f, 0.f, 0.f, 0.f); in_[j] = iv[j];
+          if (j < px_l && i < npx) { iv[j] = new_v[i]; in_[j] = new_n[i]; }
+        }
+        float acc[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+        icp_accumulate(a, s_cur, s_linv, iv, in_, L.model_v[l], L.model_n[l], acc);
+        int k; float sw;
+        if (icp_wg_reduce(acc, s_wave, k, sw))
+          __hip_atomic_store(L.slots + (size_t)step * KF_ICP_LOOP_MAX_WG * 32 + w * 32 + k,
+                             ((unsigned long long)(L.tag_base + (unsigned)step) << 32) | (unsigned long long)__float_as_uint(sw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                                         // s_wave is reused by the next turn
+      }
+      n_prev = grid_l;
+    }
+    if (timed_out) break;
+  }
+  if (!timed_out) fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort, 0, &st->rescue_tag, L.tag_base);
+  if (timed_out || s_abort) ICP_ON_ABORT();
+  s_code = apply_step(a, s_tot, s_cur, nullptr, s_pose[cur_buf ^ 1]);
+  if (s_code == STEP_APPLIED) { cur_buf ^= 1; s_cur = s_pose[cur_buf]; }
+  if (blockIdx.x != 0) return;
+  if (threadIdx.x < 27) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
+  if (s_code != STEP_APPLIED) { if (threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; st->converged = 0; st->rescued = 0; } return; }
+  if (threadIdx.x < 16) st->pose[threadIdx.x] = s_cur[threadIdx.x];
+  if (threadIdx.x == 64) kf_mat44_inverse(s_cur, st->pose_inv);
+  if (threadIdx.x == 0) { st->status = KF_TRACK_OK; st->tracked = 1; st->iterations = applied + 1; st->converged = 0; st->rescued = 0; }
 }
 
 // ---- SDF tracker ------------------------------------------------------------------------------------------------------
@@ -1151,12 +1238,23 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
                   kf_live_contexts(c->cfg.device) == 1 && !kf_device_shared(c->cfg.device);
   if (use_loop && c->loop_occupancy == 0) {
     // every workgroup must be resident at once (they wait for each other's tagged partial sums): ask the runtime how many 512-lane
-    // workgroups of THIS kernel a CU holds (registers, LDS) instead of assuming one
-    int per_cu = 0;
+    // workgroups of THESE kernels a CU holds (registers, LDS) instead of assuming one
+    int per_cu = 0, per_cu_b = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_icp_loop, ICP_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = -1;
-    c->loop_occupancy = per_cu;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, k_icp_loop_batched, ICP_THREADS, 0) != hipSuccess || per_cu_b < 1) per_cu_b = -1;
+    c->loop_occupancy = per_cu; c->loop_occupancy_batched = per_cu_b;
   }
-  if (use_loop && (c->loop_occupancy < 1 || (long long)grid0 > (long long)c->loop_occupancy * c->num_cus)) use_loop = false;     // e.g. 1280x960: 800 workgroups
+  // Images whose level 0 needs more workgroups than the chip holds at once (1280x960: 800): the batched loop -- as many resident workgroups as the
+  // VGA loop uses (the CU count less a share for the riders), each playing several workgroups of the dealing in turn.  KF_ICP_BATCHED=0: per step.
+  static int batched_env = -1;
+  if (batched_env < 0) { const char* e = getenv("KF_ICP_BATCHED"); batched_env = e ? atoi(e) : 1; }
+  int n_resident = grid0;                                    // workgroups of the loop launch
+  bool batched = false;
+  if (use_loop && (c->loop_occupancy < 1 || (long long)grid0 > (long long)c->loop_occupancy * c->num_cus)) {
+    const int room = c->loop_occupancy_batched >= 1 ? c->num_cus - c->num_cus / 5 : 0;      // 256 CUs: 205 resident workgroups, 51 CUs left to the riders
+    if (batched_env && !coop_env && room >= 16) { batched = true; n_resident = room; }
+    else use_loop = false;
+  }
   if (use_loop && c->persistent_backoff > 0) { --c->persistent_backoff; use_loop = false; }
   // ICP.cpp:57-63: the four pyramids + the loop's set-up, one launch -- unless every pyramid describes its level 0 already (the raycast launch
   // left the model maps' behind, its riders the prefetched frame's: raycast.hip) AND the persistent loop runs, which reads nothing of that
@@ -1178,7 +1276,7 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
     L.stall_word = stall_word;
     if (c->inject_stall > 0) { L.play_dead = 1; --c->inject_stall; }
     { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_ICP_EXP"); L.exp_mode = em; }
-    L.n_loop = grid0;
+    L.n_loop = n_resident; L.n_virtual = grid0;
     // a pending kf_prefetch_frame: the next frame's filter rides in this launch (see IcpLoopArgs) and leaves the gated + filtered image in
     // the alternate buffers; the raycast launch that follows carries its tile tables (the fusion pass in between clears them) and its
     // vertices / normals.  Not under a cooperative launch, whose whole grid would have to be resident.
@@ -1202,7 +1300,8 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
       (void)hipGetLastError();                               // refused: this device / configuration cannot hold the loop -- per-step from now on
       c->loop_refused = 1;
     } else {
-      hipLaunchKernelGGL(k_icp_loop, dim3((unsigned)grid0 + n_riders), dim3(ICP_THREADS), 0, c->stream, L);
+      if (batched) hipLaunchKernelGGL(k_icp_loop_batched, dim3((unsigned)n_resident + n_riders), dim3(ICP_THREADS), 0, c->stream, L);
+      else hipLaunchKernelGGL(k_icp_loop, dim3((unsigned)grid0 + n_riders), dim3(ICP_THREADS), 0, c->stream, L);
       c->last_track_form = 1;
       kf_evt_end(c, KF_STAGE_TRACK);
       return (int)hipGetLastError();

@@ -1,8 +1,9 @@
 """GPU: every launch form of the device ICP against the oracle's CameraPoseFinderICP loop (src/CameraPoseFinderICP.cpp:50-145).
 
 kf_icp_track runs either ONE persistent launch (k_icp_loop) or one launch per Gauss-Newton step (k_icp_step + k_track_finish): the
-latter whenever the image needs more workgroups than the chip holds at once (1280x960, BASELINE config C5), a second context lives
-on the device, the GPU is shared with another process, or after a stall.  Both forms deal the pixels, reduce and fold in the same
+latter whenever a second context lives
+on the device, the GPU is shared with another process, or after a time-out.  An image that needs more workgroups than the chip holds at
+once (1280x960, BASELINE config C5) takes the BATCHED persistent loop (k_icp_loop_batched).  All forms deal the pixels, reduce and fold in the same
 order, so they must agree BITWISE; each is compared with the oracle at the north star's 1e-4 m / 1e-4 rad on identical maps.
 The pixel-partitioned form (kf_icp_partition_*, the multi-GPU all-reduce of the 27-float system) is compared with the oracle too.
 """
@@ -54,19 +55,33 @@ def test_persistent_loop_and_per_step_launches_agree_bitwise(res, cam):
     ctx.close()
 
 
-def test_per_step_form_at_1280x960_against_the_oracle():
-    """BASELINE config C5's image: 800 workgroups at level 0 do not fit the chip at once -> one launch per step."""
+def test_forms_at_1280x960_against_the_oracle_and_each_other():
+    """BASELINE config C5's image: level 0 needs 800 workgroups, more than the chip holds at once.  Alone on the device the BATCHED persistent loop runs
+    (k_icp_loop_batched: ~200 resident workgroups each play several workgroups of the dealing per step); with a second live context one launch per
+    step.  Same dealing, reduction and fold -> the same pose bits and final sums; each within 1e-4 of the oracle; the lost verdict through both;
+    a time-out of the batched loop is finished by one workgroup, same bits again."""
     cam, res, size = S.vga_camera(2), 128, 3.0
     trunc = 5 * size / res
     ctx, ovol, pose, nxt, ocam, maps = _tracking_case(res, size, cam, trunc)
     ok_o, pose_o = _oracle_pose(maps, ocam, pose)
-    ok, p, status, iters, form, _ = _track(ctx, pose)
-    assert form == 2 and ok and ok_o and status == 0 and iters == 19
+    ok, p, status, iters, form, sums = _track(ctx, pose)
+    assert form == 1 and ok and ok_o and status == 0 and iters == 19
     assert np.max(np.abs(p[:3, 3] - pose_o[:3, 3])) < 1e-4 and np.max(np.abs(p[:3, :3] - pose_o[:3, :3])) < 1e-4
     assert np.linalg.norm(p[:3, 3] - nxt[:3, 3]) < np.linalg.norm(pose[:3, 3] - nxt[:3, 3]) + 1e-3
-    # lost verdict through the same form: shake threshold 0 rejects the first step, pose unchanged
+    other = K.Context(K.camera(*mid_cam()), 32, 3.0, levels=3)      # a second live context: one launch per step
+    ok2, p2, st2, it2, form2, sums2 = _track(ctx, pose)
+    assert form2 == 2 and ok2 and st2 == 0 and it2 == 19
+    assert np.array_equal(p.view(np.uint32), p2.view(np.uint32)) and np.array_equal(sums.view(np.uint32), sums2.view(np.uint32))
+    # lost verdict through both forms: shake threshold 0 rejects the first step, pose unchanged
     ok_l, p_l, st_l, it_l, form_l, _ = _track(ctx, pose, (ICP[0], ICP[1], 0.0, 0.0))
     assert form_l == 2 and not ok_l and st_l == 2 and it_l == 0 and np.array_equal(p_l, pose)
+    other.close()
+    ok_l, p_l, st_l, it_l, form_l, _ = _track(ctx, pose, (ICP[0], ICP[1], 0.0, 0.0))
+    assert form_l == 1 and not ok_l and st_l == 2 and it_l == 0 and np.array_equal(p_l, pose)
+    ctx.inject_track_stall(1)                                       # one resident workgroup plays dead: the others time out, one finishes alone
+    ok3, p3, st3, it3, form3, sums3 = _track(ctx, pose)
+    assert form3 == 3 and ok3 and st3 == 0 and it3 == 19
+    assert np.array_equal(p.view(np.uint32), p3.view(np.uint32)) and np.array_equal(sums.view(np.uint32), sums3.view(np.uint32))
     ctx.close()
 
 

@@ -42,6 +42,7 @@ def worker(a):
     dev = torch.from_numpy(frames.astype(np.int16)).cuda()
     fb = cam[0] * cam[1] * 2
     outs = []
+    trace = {}
     for cls in (PL.SingleGpuPipeline, PL.SlabPipeline):
         pipe = (cls(K.camera(*cam), res, size, wl) if cls is PL.SingleGpuPipeline else
                 cls(K.camera(*cam), res, size, wl, rank=rank, world=world, rebalance_every=a.rebalance_every, rebalance_sample=2))
@@ -52,6 +53,10 @@ def worker(a):
             ok, pose, _, _ = pipe.track_result()
             assert ok, "rank %d lost frame %d" % (rank, k)
             poses.append(pose.copy())
+            if a.trace:                                   # per-frame fingerprints of the merged model maps and of the stored volume layers' update count
+                import hashlib
+                hm = hashlib.sha1(pipe.ctx.download_map(K.MAP_MODEL_VERTICES).tobytes() + pipe.ctx.download_map(K.MAP_MODEL_NORMALS).tobytes()).hexdigest()[:12]
+                trace.setdefault(cls.__name__, []).append((hm, int(pipe.stats()["updated_last"])))
         pipe.sync()
         maps = [pipe.ctx.download_map(m) for m in (K.MAP_MODEL_VERTICES, K.MAP_MODEL_NORMALS)]
         z0, z1 = pipe.ctx.owned
@@ -63,9 +68,24 @@ def worker(a):
             n_mig = len(pipe.migrations)
         pipe.close()
     (p1, m1, v1, _, _), (p2, m2, v2, (z0, z1), upd) = outs
-    ok = all(np.array_equal(a_, b_) for a_, b_ in zip(p1, p2))
-    ok = ok and all(np.array_equal(a_.view(np.uint32), b_.view(np.uint32)) for a_, b_ in zip(m1, m2))
-    ok = ok and np.array_equal(v1[0][z0:z1].view(np.uint32), v2[0].view(np.uint32)) and np.array_equal(v1[1][z0:z1], v2[1])
+    pose_ok = [bool(np.array_equal(a_, b_)) for a_, b_ in zip(p1, p2)]
+    maps_ok = all(np.array_equal(a_.view(np.uint32), b_.view(np.uint32)) for a_, b_ in zip(m1, m2))
+    vol_ok = np.array_equal(v1[0][z0:z1].view(np.uint32), v2[0].view(np.uint32)) and np.array_equal(v1[1][z0:z1], v2[1])
+    ok = all(pose_ok) and maps_ok and vol_ok
+    if not ok:
+        bad_layers = [z0 + int(i) for i in np.nonzero((v1[0][z0:z1].view(np.uint32) != v2[0].view(np.uint32)).reshape(z1 - z0, -1).any(axis=1) |
+                                                      (v1[1][z0:z1] != v2[1]).reshape(z1 - z0, -1).any(axis=1))[0]]
+        print("rank %d: first pose mismatch at frame %s, maps %s, volume %s (layers %s)" % (
+            rank, pose_ok.index(False) if False in pose_ok else None, "ok" if maps_ok else "MISMATCH", "ok" if vol_ok else "MISMATCH",
+            (bad_layers[:4] + ["..."] + bad_layers[-2:]) if len(bad_layers) > 6 else bad_layers), flush=True)
+    if a.trace:
+        ta, tb = trace["SingleGpuPipeline"], trace["SlabPipeline"]
+        first_map = next((k for k in range(n) if ta[k][0] != tb[k][0]), None)
+        upd = torch.tensor([t[1] for t in tb], dtype=torch.int64)
+        dist.all_reduce(upd, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            print("trace: first frame whose merged model maps differ from the single-GPU pipeline's: %s; first frame whose pose differs: %s" % (
+                first_map, pose_ok.index(False) if False in pose_ok else None), flush=True)
     valid = int((m2[0][..., 3] != 0).sum())
     if a.rebalance_every and a.expect_migration and n_mig == 0:
         ok = False
@@ -88,6 +108,7 @@ def main():
     ap.add_argument("--rebalance-every", type=int, default=0)
     ap.add_argument("--yaw", type=float, default=0.0, help="degrees the camera turns over the sequence")
     ap.add_argument("--dolly", type=float, default=0.0, help="metres the camera moves into the scene over the sequence")
+    ap.add_argument("--trace", action="store_true", help="per-frame fingerprints of the merged model maps: where does a mismatch start?")
     ap.add_argument("--expect-migration", action="store_true", help="fail when the run ends without a single migration")
     a = ap.parse_args()
     if "WORLD_SIZE" in os.environ:
