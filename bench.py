@@ -312,8 +312,8 @@ def launch_ranks(n, argv):
 
 def collective_selftest(args):
     """No GPU needed: the ranks form a gloo group and run SlabExchange -- the very sequence of collectives SlabPipeline issues per
-    frame (async MIN all-reduce, overlap hook, mask, integer SUM all-reduce, unpack) -- on CPU tensors, with plain-torch
-    restatements of the mask / unpack kernels (tests/slab_cpu_ops.py), and check the merged maps against the first-crossing rule.
+    frame (async MIN all-reduce of the 64-bit crossing words, overlap hook, normals by the vertex's owner, integer SUM all-reduce, unpack) -- on CPU tensors, with plain-torch
+    restatements of the device launches (tests/slab_cpu_ops.py), and check the merged maps against the first-crossing rule.
     Used by tests/test_slab_distributed_cpu.py to cover the launcher path end to end at world_size 2."""
     import torch
     import torch.distributed as dist
@@ -323,12 +323,14 @@ def collective_selftest(args):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo")
     rows, cols = 48, 64
-    model = {}
-    ex = SlabExchange(rows, cols, torch.device("cpu"), dist, mask=ops.mask, unpack=lambda cand: model.update(zip("vn", ops.unpack(cand))))
+    model, step = {}, {}
+    ex = SlabExchange(rows, cols, torch.device("cpu"), dist, normals=lambda ta, cand: step["normals"](ta, cand),
+                      unpack=lambda ta, cand: model.update(zip("vn", ops.unpack(ta, cand))))
     ok, overlapped = True, 0
     for frame in range(3):
-        t, cand, want_v, want_n = ops.synthetic_candidates(rows, cols, rank, world, seed=100 + frame)
-        ex.t.copy_(t); ex.cand.copy_(cand)
+        ta, normals, want_ta, want_cand, want_v, want_n = ops.synthetic_crossings(rows, cols, rank, world, seed=100 + frame)
+        step["normals"] = normals
+        ex.ta.copy_(ta)
 
         def overlap():
             nonlocal overlapped
@@ -779,7 +781,7 @@ def main():
                            partition="none" if not slab else
                            "z-slab x%d (boundaries: %s); %d halo layers per side RE-INTEGRATED by both neighbours (recomputed, not exchanged per frame; when the boundaries move -- "
                            "--rebalance-every -- whole brick layers travel rank to rank: SlabMigrator); "
-                           "raycast merge = MIN all-reduce (t, 1.2 MB) + integer SUM all-reduce (vertex ray parameter + normal, 4.9 MB); ICP %s"
+                           "raycast merge = MIN all-reduce (crossing parameter + vertex parameter as one 64-bit word, 2.5 MB at VGA) + integer SUM all-reduce (normal from the vertex's owner, 4.9 MB); ICP %s"
                            % (world, "balanced from a one-frame 256^3 probe of the work per z-layer" if (world > 1 and args.slab_balance == "probe") else "equal thickness",
                               pipe.halo, args.icp_mode),
                            slab_ranges=([list(r) for r in pipe.ranges] if slab else None)),

@@ -24,8 +24,9 @@ struct RaycastArgs {
   KfMat pose_val;
   float4* out_v; float4* out_n; uchar4* out_rgb;
   float* out_t;                  // optional: ray parameter of the first crossing this context detected (+inf: none) -- z-slab merge
-  float* out_t2;                 // optional second copy of out_t (the buffer the caller's MIN all-reduce works in place on)
-  float4* out_cand;              // optional (z-slab merge, ray form): (vertex's ray parameter, normal xyz) instead of the two maps
+  unsigned long long* out_ta;    // z-slab merge (what SlabPipeline runs): per pixel (bits of the crossing's ray parameter) << 32 | bits of the VERTEX's ray parameter
+                                 // alpha -- +inf / 0 without a crossing, alpha 0 where the reference gives up at the crossing (raycastingVolume.cu:87-88).  Only the two
+                                 // interpolations at the crossing are evaluated here; the gradient around the vertex is the job of whoever owns the vertex (k_slab_ray_normals)
   KfPyrOut pyr;                  // v1 non-null: the workgroups also leave levels 1 and 2 of the two maps' pyramids (bilateral_tile.h: kf_tile_pyramid)
   float inc, near_plane, far_plane;
   int has_color;
@@ -176,6 +177,14 @@ __device__ __forceinline__ void rc_pixel_ray(const KfCam& cam, const float* T, i
   dir.z = (dir.z == 0.f) ? (float)1e-15 : dir.z;
 }
 
+// [t_min, t_max) of a ray: getMinTime / getMaxTime (raycastingVolume.cu:44-63) clipped by the near / far planes (:152-153)
+__device__ __forceinline__ void rc_ray_interval(float S, float near_plane, float far_plane, float3 org, float3 dir, float3 cam_dir, float& tmin, float& tmax) {
+  tmin = fmaxf(fmaxf(((dir.x > 0 ? 0.f : S) - org.x) / dir.x, ((dir.y > 0 ? 0.f : S) - org.y) / dir.y), ((dir.z > 0 ? 0.f : S) - org.z) / dir.z);
+  tmax = fminf(fminf(((dir.x > 0 ? S : 0.f) - org.x) / dir.x, ((dir.y > 0 ? S : 0.f) - org.y) / dir.y), ((dir.z > 0 ? S : 0.f) - org.z) / dir.z);
+  tmin = fmaxf(tmin, near_plane / cam_dir.z);
+  tmax = fminf(tmax, far_plane / cam_dir.z);
+}
+
 // one 32x16 pixel tile (tile_x, tile_y) by the 512 threads of a workgroup; s_tables: the workgroup's dynamic LDS
 __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, int tile_y, unsigned* s_tables) {
   const KfVolume& v = a.vol;
@@ -216,10 +225,8 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
   float3 org, dir, cam_dir;
   rc_pixel_ray(a.cam, T, x, y, org, dir, cam_dir);
   const float S = v.size;
-  float tmin = fmaxf(fmaxf(((dir.x > 0 ? 0.f : S) - org.x) / dir.x, ((dir.y > 0 ? 0.f : S) - org.y) / dir.y), ((dir.z > 0 ? 0.f : S) - org.z) / dir.z);
-  float tmax = fminf(fminf(((dir.x > 0 ? S : 0.f) - org.x) / dir.x, ((dir.y > 0 ? S : 0.f) - org.y) / dir.y), ((dir.z > 0 ? S : 0.f) - org.z) / dir.z);
-  tmin = fmaxf(tmin, a.near_plane / cam_dir.z);
-  tmax = fminf(tmax, a.far_plane / cam_dir.z);
+  float tmin, tmax;
+  rc_ray_interval(S, a.near_plane, a.far_plane, org, dir, cam_dir, tmin, tmax);
   const float ref_tmin = tmin, ref_tmax = tmax;
 #ifdef KF_EXPERIMENTS
   unsigned long long st1 = __builtin_amdgcn_s_memtime(), st2 = st1;
@@ -255,6 +262,11 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
       const float3 pos = kf_add(org, kf_scale(dir, t_cross)), last_pos = kf_add(org, kf_scale(dir, t_cross_prev));
       float ftdt, ft; bool ok_cur, ok_last;
       kf_interpolate_sdf_pair(v, pos, last_pos, rS, rcell, ok_cur, ftdt, ok_last, ft);
+      if (a.out_ta) {
+        // z-slabs: the vertex org + dir * alpha may lie ANYWHERE along the ray -- alpha = t - inc * f(t) / (f(t) - f(t - inc)) extrapolates without bound when the
+        // two interpolated values nearly agree (an isolated negative voxel at a silhouette) -- so its gradient taps are not this slab's to read: only alpha leaves
+        if (ok_cur && ok_last) out_alpha = t_cross - a.inc * ftdt / (ftdt - ft);
+      } else
       if (ok_cur && ok_last) {                                              // :87-88 `break` on either failure
         const float alpha = t_cross - a.inc * ftdt / (ftdt - ft);
         const float3 vtx = kf_add(org, kf_scale(dir, alpha));
@@ -275,7 +287,7 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
     out_n = make_float4((float)n_samp, (float)(n_macro & 0xFFFF), (float)(n_macro >> 16), 0.f);
   }
 #endif
-  if (a.out_cand) a.out_cand[pix] = make_float4(out_alpha, out_n.x, out_n.y, out_n.z);      // vertex = org + dir * alpha, rebuilt by k_slab_rays_unpack
+  if (a.out_ta) a.out_ta[pix] = ((unsigned long long)__float_as_uint(t_cross) << 32) | (unsigned long long)(t_cross < inf ? __float_as_uint(out_alpha) : 0u);
   else { a.out_v[pix] = out_v; a.out_n[pix] = out_n; }
   if (a.work) {
     // what the REFERENCE's march reads for this ray (raycastingVolume.cu:65-119): one voxel per sample from t_min up to the
@@ -290,7 +302,6 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
     }
   }
   if (a.out_t) a.out_t[pix] = t_cross;
-  if (a.out_t2) a.out_t2[pix] = t_cross;
   if (a.has_color) a.out_rgb[pix] = out_c;
   };
   if (live) march_pixel();
@@ -351,7 +362,7 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) __attribute__((amdgpu_waves_p
 }
 
 static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, const kf_raycast_params* rp, const kf_camera_params* cam,
-                          float near_plane, float far_plane, float* out_t, float4* out_v, float4* out_n, float4* out_cand = nullptr, float* out_t2 = nullptr) {
+                          float near_plane, float far_plane, float* out_t, float4* out_v, float4* out_n, unsigned long long* out_ta = nullptr) {
   if (!c || !rp || !cam) return KF_ERR_ARG;
   if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
   if (has_color && (!c->vol.color || !c->raycast_rgb)) return KF_ERR_STATE;
@@ -360,16 +371,16 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
   a.cam.cols = (int)cam->cols; a.cam.rows = (int)cam->rows; a.cam.cx = cam->cx; a.cam.cy = cam->cy; a.cam.fx = cam->fx; a.cam.fy = cam->fy;
   if (transform) { for (int i = 0; i < 16; ++i) a.pose_val.m[i] = transform->m[i]; a.pose = nullptr; }
   else a.pose = c->track->pose;
-  if (!out_cand && (!out_v || !out_n)) c->model_pyr_ok = 0;             // the model maps' level 0 is rewritten
+  if (!out_ta && (!out_v || !out_n)) c->model_pyr_ok = 0;             // the model maps' level 0 is rewritten
   memset(&a.pyr, 0, sizeof(a.pyr));
   static int pyr_env = -1;
   if (pyr_env < 0) { const char* e = getenv("KF_RAYCAST_PYRAMID"); pyr_env = e ? atoi(e) : 1; }
-  const bool model_pyr = pyr_env && !out_cand && !out_v && !out_n && c->levels == 3;      // the model maps themselves, stock pyramid depth
+  const bool model_pyr = pyr_env && !out_ta && !out_v && !out_n && c->levels == 3;      // the model maps themselves, stock pyramid depth
   if (model_pyr) {
     a.pyr.v1 = c->model_v[1]; a.pyr.n1 = c->model_n[1]; a.pyr.v2 = c->model_v[2]; a.pyr.n2 = c->model_n[2];
     a.pyr.c1 = c->cols >> 1; a.pyr.r1 = c->rows >> 1; a.pyr.c2 = a.pyr.c1 >> 1; a.pyr.r2 = a.pyr.r1 >> 1;
   }
-  a.out_v = out_v ? out_v : c->model_v[0]; a.out_n = out_n ? out_n : c->model_n[0]; a.out_rgb = c->raycast_rgb; a.out_t = out_t; a.out_t2 = out_t2; a.out_cand = out_cand;
+  a.out_v = out_v ? out_v : c->model_v[0]; a.out_n = out_n ? out_n : c->model_n[0]; a.out_rgb = c->raycast_rgb; a.out_t = out_t; a.out_ta = out_ta;
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
   { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_RAYCAST_EXP"); a.exp_mode = em; }
   a.work = c->count_work ? c->counters : nullptr;
@@ -440,8 +451,9 @@ extern "C" int kf_raycast_volume(kf_ctx* c, int has_color, const kf_mat44* trans
   return raycast_launch(c, has_color, transform, rp, cam, near_plane, far_plane, nullptr, nullptr, nullptr);
 }
 
-// z-slab variant: this context marches every ray but reports only crossings whose negative sample lies in the voxel layers it
-// owns.  dev_t[pixel] = ray parameter of that crossing (+inf if none), dev_v / dev_n = the vertex / normal it produced
+// z-slab variant, MAP FORM (the earlier protocol, kept for per-kernel tests: it evaluates the gradient in the slab that met the crossing and therefore
+// drops the rare pixel whose extrapolated vertex leaves that slab's halo -- see kf_raycast_volume_slab_cross below, which SlabPipeline uses):
+// this context marches every ray but reports only crossings whose negative sample lies in the voxel layers it owns.  dev_t[pixel] = ray parameter of that crossing (+inf if none), dev_v / dev_n = the vertex / normal it produced
 // (zeros when the reference would have given up at that crossing).  The caller reduces over the slabs -- first crossing
 // along the ray wins, exactly the reference's sequential march -- and hands the result back with kf_set_model_maps_device.
 // The previous sample of the first owned one lies up to x = inc/cell layers outside the owned range and the trilinear +
@@ -476,27 +488,72 @@ extern "C" int kf_slab_mask_candidates(kf_ctx* c, const float* dev_t, const floa
   return (int)hipGetLastError();
 }
 
-// The same merge with a smaller exchange (what SlabPipeline runs): a candidate travels in RAY FORM -- the vertex's ray parameter and the
-// normal, 16 bytes per pixel instead of two 16-byte maps.  A vertex is `org + dir * alpha` (raycastingVolume.cu:98-99) and the pixel's ray
-// is a pure function of the pose and the camera, which every rank holds bit for bit: k_slab_rays_unpack repeats those operations
-// (rc_pixel_ray) and arrives at the owner's vertex bits.  kf_raycast_volume_slab_rays writes the candidates (zeros when the reference would
-// have given up at the crossing), kf_slab_mask_rays zeroes them where another slab's crossing comes first, the caller's integer SUM
-// all-reduce returns the winner's bits and kf_set_model_maps_rays turns them into the model maps (a unit normal is never all-zero,
-// which is what marks a valid pixel).
-extern "C" int kf_raycast_volume_slab_rays(kf_ctx* c, int has_color, const kf_mat44* transform, const kf_raycast_params* rp,
-                                           const kf_camera_params* cam, float near_plane, float far_plane, float* dev_t, float* dev_t_copy, float* dev_cand) {
-  if (!c || !rp || !dev_t || !dev_cand) return KF_ERR_ARG;
+// ---- the merge SlabPipeline runs: crossings first, normals by the vertex's owner -----------------------------------------------------------------------
+// A crossing's vertex is org + dir * alpha with alpha = t - inc * f(t) / (f(t) - f(t - inc)) (raycastingVolume.cu:89-90): an EXTRAPOLATION whenever the two
+// interpolated values have the same sign -- an isolated negative voxel at a silhouette does that -- and then the vertex lies anywhere along the ray, far
+// outside the halo of the slab that met the crossing (found in round 4: one pixel every few frames on a moving camera; the slab could not read the
+// gradient taps and dropped a pixel the single-GPU march keeps).  So the work is split where the data is:
+//   1. kf_raycast_volume_slab_cross: every slab marches every ray and reports, per pixel, ONE 64-bit word (crossing parameter << 32 | alpha), what it can
+//      decide alone (the two interpolations at the crossing lie within its halo);
+//   2. the caller's MIN all-reduce over those words: positive floats order like their bit patterns, so the first crossing along the ray wins and brings its
+//      alpha along (alpha 0: the reference gave up at that crossing -- the pixel stays empty, as in the sequential march);
+//   3. kf_slab_ray_normals: every rank rebuilds the winners' vertices from the rays (a pure function of pose and camera, which all ranks hold bit for bit);
+//      the rank that OWNS the vertex's voxel layer evaluates gradientForPoint (:16-42) -- its taps reach two layers, inside any halo -- and contributes
+//      (normal, 1), everybody else zeros; the previous sample's position, whose voxel the function bounds-tests, is found by replaying the chain of additions
+//      from t_min (:116), exactly as the march walked it;
+//   4. the caller's integer SUM all-reduce (exactly one contributor per pixel: the winner's bits, -0.0 included) and kf_set_model_maps_rays, which writes
+//      the model maps and levels 1 and 2 of their pyramids.
+// Two collectives and three launches per frame, as before; 8 + 16 bytes per pixel on the wire (was 4 + 16).
+extern "C" int kf_raycast_volume_slab_cross(kf_ctx* c, const kf_mat44* transform, const kf_raycast_params* rp, const kf_camera_params* cam,
+                                            float near_plane, float far_plane, uint64_t* dev_ta) {
+  if (!c || !rp || !dev_ta) return KF_ERR_ARG;
   const int st = slab_halo_check(c, rp);
   if (st) return st;
-  return raycast_launch(c, has_color, transform, rp, cam, near_plane, far_plane, dev_t, nullptr, nullptr, (float4*)dev_cand, dev_t_copy);
+  return raycast_launch(c, 0, transform, rp, cam, near_plane, far_plane, nullptr, nullptr, nullptr, (unsigned long long*)dev_ta);
 }
-__global__ void __launch_bounds__(256) k_slab_rays_mask(const float* __restrict__ t, const float* __restrict__ tmin, float4* __restrict__ cand, int npx) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= npx) return;
-  const float ti = t[i];
-  if (!(ti == tmin[i] && ti < __builtin_huge_valf())) cand[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+struct SlabNormalArgs { KfVolume vol; KfCam cam; const float* pose; KfMat pose_val; const unsigned long long* ta; float4* cand; float inc, near_plane, far_plane; };
+__global__ void __launch_bounds__(256) k_slab_ray_normals(SlabNormalArgs a) {
+  const int x = (int)blockIdx.x * 32 + (int)(threadIdx.x & 31), y = (int)blockIdx.y * 8 + (int)(threadIdx.x >> 5);
+  if (x >= a.cam.cols || y >= a.cam.rows) return;
+  const KfVolume& v = a.vol;
+  const int i = y * a.cam.cols + x;
+  const unsigned long long w = a.ta[i];
+  const float t_cross = __uint_as_float((unsigned)(w >> 32));
+  const unsigned alpha_bits = (unsigned)w;
+  float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t_cross < __builtin_huge_valf() && alpha_bits != 0u) {
+    float3 org, dir, cam_dir;
+    rc_pixel_ray(a.cam, a.pose ? a.pose : a.pose_val.m, x, y, org, dir, cam_dir);
+    const float3 vtx = kf_add(org, kf_scale(dir, __uint_as_float(alpha_bits)));
+    const KfRecip rS = kf_recip(v.size), rcell = kf_recip(v.cell);
+    int gz = kf_f2i(kf_div(vtx.z * (float)v.res, rS));                       // the vertex's voxel layer (tsdfVolume.h:50-56), clamped: exactly one owner
+    gz = max(0, min(gz, v.res - 1));
+    if (gz >= v.own_z0 && gz < v.own_z1) {
+      float tmin, tmax;
+      rc_ray_interval(v.size, a.near_plane, a.far_plane, org, dir, cam_dir, tmin, tmax);
+      float t = tmin, t_prev = tmin;
+      while (t < t_cross) { t_prev = t; t += a.inc; }                        // the march's own chain of additions: t ends ON t_cross, t_prev on the sample before it
+      const float3 last_pos = kf_add(org, kf_scale(dir, t_prev));
+      float3 grad;
+      if (gradient_for_point(v, last_pos, vtx, rS, rcell, grad)) out = make_float4(grad.x, grad.y, grad.z, 1.0f);
+    }
+  }
+  a.cand[i] = out;
 }
-struct SlabUnpackArgs { const float4* cand; float4* v; float4* n; KfCam cam; const float* pose; KfMat pose_val; KfPyrOut pyr; };
+extern "C" int kf_slab_ray_normals(kf_ctx* c, const kf_mat44* transform, const kf_raycast_params* rp, const kf_camera_params* cam,
+                                   float near_plane, float far_plane, const uint64_t* dev_ta_min, float* dev_cand) {
+  if (!c || !rp || !cam || !dev_ta_min || !dev_cand) return KF_ERR_ARG;
+  if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
+  SlabNormalArgs a;
+  a.vol = c->vol; a.ta = (const unsigned long long*)dev_ta_min; a.cand = (float4*)dev_cand;
+  a.cam.cols = (int)cam->cols; a.cam.rows = (int)cam->rows; a.cam.cx = cam->cx; a.cam.cy = cam->cy; a.cam.fx = cam->fx; a.cam.fy = cam->fy;
+  a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane;
+  if (transform) { for (int k = 0; k < 16; ++k) a.pose_val.m[k] = transform->m[k]; a.pose = nullptr; }
+  else a.pose = c->track->pose;
+  hipLaunchKernelGGL(k_slab_ray_normals, dim3(kf_div_up(c->cols, 32), kf_div_up(c->rows, 8)), dim3(256), 0, c->stream, a);
+  return (int)hipGetLastError();
+}
+struct SlabUnpackArgs { const unsigned long long* ta; const float4* cand; float4* v; float4* n; KfCam cam; const float* pose; KfMat pose_val; KfPyrOut pyr; };
 // one 32x8 pixel tile per workgroup: the tile's whole 2x2 and 4x4 blocks also give levels 1 and 2 of the model maps' pyramids (kf_tile_pyramid),
 // so the tracker that follows finds them done, as after a single-GPU raycast
 __global__ void __launch_bounds__(256) k_slab_rays_unpack(SlabUnpackArgs a) {
@@ -506,14 +563,13 @@ __global__ void __launch_bounds__(256) k_slab_rays_unpack(SlabUnpackArgs a) {
   if (x < a.cam.cols && y < a.cam.rows) {
     const int i = y * a.cam.cols + x;
     const float4 cd = a.cand[i];
-    const bool valid = cd.y != 0.f || cd.z != 0.f || cd.w != 0.f;
-    if (valid) {
+    if (cd.w != 0.f) {                                                       // the vertex's owner found a gradient: vertex = org + dir * alpha (raycastingVolume.cu:90), w = 1
       float3 org, dir, cam_dir;
       rc_pixel_ray(a.cam, a.pose ? a.pose : a.pose_val.m, x, y, org, dir, cam_dir);
-      const float3 vtx = kf_add(org, kf_scale(dir, cd.x));
+      const float3 vtx = kf_add(org, kf_scale(dir, __uint_as_float((unsigned)a.ta[i])));
       v = make_float4(vtx.x, vtx.y, vtx.z, 1.0f);
+      n = make_float4(cd.x, cd.y, cd.z, 0.f);
     }
-    n = make_float4(cd.y, cd.z, cd.w, 0.f);
     a.v[i] = v; a.n[i] = n;
   }
   if (a.pyr.v1) {                                                            // uniform
@@ -521,14 +577,8 @@ __global__ void __launch_bounds__(256) k_slab_rays_unpack(SlabUnpackArgs a) {
     kf_tile_pyramid<32, 8>(a.pyr, (int)blockIdx.x * 32, (int)blockIdx.y * 8, (int)threadIdx.x, s_v, s_n, s1_v, s1_n, [] { __syncthreads(); });
   }
 }
-extern "C" int kf_slab_mask_rays(kf_ctx* c, const float* dev_t, const float* dev_tmin, float* dev_cand) {
-  if (!c || !dev_t || !dev_tmin || !dev_cand) return KF_ERR_ARG;
-  const int npx = c->cols * c->rows;
-  hipLaunchKernelGGL(k_slab_rays_mask, dim3(kf_div_up(npx, 256)), dim3(256), 0, c->stream, dev_t, dev_tmin, (float4*)dev_cand, npx);
-  return (int)hipGetLastError();
-}
-extern "C" int kf_set_model_maps_rays(kf_ctx* c, const kf_mat44* transform, const kf_camera_params* cam, const float* dev_cand) {
-  if (!c || !cam || !dev_cand) return KF_ERR_ARG;
+extern "C" int kf_set_model_maps_rays(kf_ctx* c, const kf_mat44* transform, const kf_camera_params* cam, const uint64_t* dev_ta_min, const float* dev_cand) {
+  if (!c || !cam || !dev_ta_min || !dev_cand) return KF_ERR_ARG;
   if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
   SlabUnpackArgs a;
   c->model_pyr_ok = 0;
@@ -537,7 +587,7 @@ extern "C" int kf_set_model_maps_rays(kf_ctx* c, const kf_mat44* transform, cons
     a.pyr.v1 = c->model_v[1]; a.pyr.n1 = c->model_n[1]; a.pyr.v2 = c->model_v[2]; a.pyr.n2 = c->model_n[2];
     a.pyr.c1 = c->cols >> 1; a.pyr.r1 = c->rows >> 1; a.pyr.c2 = a.pyr.c1 >> 1; a.pyr.r2 = a.pyr.r1 >> 1;
   }
-  a.cand = (const float4*)dev_cand; a.v = c->model_v[0]; a.n = c->model_n[0];
+  a.ta = (const unsigned long long*)dev_ta_min; a.cand = (const float4*)dev_cand; a.v = c->model_v[0]; a.n = c->model_n[0];
   a.cam.cols = (int)cam->cols; a.cam.rows = (int)cam->rows; a.cam.cx = cam->cx; a.cam.cy = cam->cy; a.cam.fx = cam->fx; a.cam.fy = cam->fy;
   if (transform) { for (int k = 0; k < 16; ++k) a.pose_val.m[k] = transform->m[k]; a.pose = nullptr; }
   else a.pose = c->track->pose;                       // the pose the raycast used: nothing moves it between the raycast and this call

@@ -83,7 +83,7 @@ SYMBOLS = [
     "kf_icp_track", "kf_sdf_track", "kf_read_track_result", "kf_request_track_result", "kf_wait_track_result", "kf_integrate_volume", "kf_raycast_volume",
     "kf_marching_cubes", "kf_clear_triangles", "kf_triangle_count", "kf_read_triangles", "kf_download_map",
     "kf_upload_map", "kf_download_volume", "kf_upload_volume", "kf_get_volume_stats", "kf_stored_z_range",
-    "kf_stage_timers", "kf_read_stage_ms", "kf_read_work_counters", "kf_set_stream", "kf_raycast_volume_slab", "kf_slab_mask_candidates", "kf_set_model_maps_device", "kf_raycast_volume_slab_rays", "kf_slab_mask_rays", "kf_set_model_maps_rays", "kf_selftest_div",
+    "kf_stage_timers", "kf_read_stage_ms", "kf_read_work_counters", "kf_set_stream", "kf_raycast_volume_slab", "kf_slab_mask_candidates", "kf_set_model_maps_device", "kf_raycast_volume_slab_cross", "kf_slab_ray_normals", "kf_set_model_maps_rays", "kf_selftest_div",
     "kf_icp_partition_begin", "kf_icp_partition_steps", "kf_icp_partition_step", "kf_icp_partition_finish",
     "kf_sdf_partition_begin", "kf_sdf_partition_step", "kf_sdf_partition_finish", "kf_set_defer", "kf_inject_track_stall",
     "kf_download_volume_device", "kf_upload_volume_device", "kf_resize_slab", "kf_count_layer_work", "kf_read_layer_work",
@@ -331,18 +331,23 @@ class Context:
         _chk(self.lib.kf_slab_mask_candidates(self.h, C.c_void_p(dev_t), C.c_void_p(dev_tmin), C.c_void_p(dev_v), C.c_void_p(dev_n)),
              "kf_slab_mask_candidates")
 
-    def raycast_slab_rays(self, pose, inc, near, far, dev_t, dev_cand, dev_t_copy=None):
+    def raycast_slab_cross(self, pose, inc, near, far, dev_ta):
+        """every ray's first crossing in the owned layers as one 64-bit word per pixel (crossing parameter << 32 | vertex parameter alpha)"""
         rp = RaycastParams(inc)
         tp = C.byref(Mat44.of(pose)) if pose is not None else None
-        _chk(self.lib.kf_raycast_volume_slab_rays(self.h, 0, tp, C.byref(rp), C.byref(self.cam), C.c_float(near), C.c_float(far),
-                                                  C.c_void_p(dev_t), C.c_void_p(dev_t_copy), C.c_void_p(dev_cand)), "kf_raycast_volume_slab_rays")
+        _chk(self.lib.kf_raycast_volume_slab_cross(self.h, tp, C.byref(rp), C.byref(self.cam), C.c_float(near), C.c_float(far), C.c_void_p(dev_ta)),
+             "kf_raycast_volume_slab_cross")
 
-    def slab_mask_rays(self, dev_t, dev_tmin, dev_cand):
-        _chk(self.lib.kf_slab_mask_rays(self.h, C.c_void_p(dev_t), C.c_void_p(dev_tmin), C.c_void_p(dev_cand)), "kf_slab_mask_rays")
-
-    def set_model_maps_rays(self, pose, dev_cand):
+    def slab_ray_normals(self, pose, inc, near, far, dev_ta_min, dev_cand):
+        """after the MIN all-reduce of the words: (normal, 1) for the winners whose vertex this context owns, zeros elsewhere"""
+        rp = RaycastParams(inc)
         tp = C.byref(Mat44.of(pose)) if pose is not None else None
-        _chk(self.lib.kf_set_model_maps_rays(self.h, tp, C.byref(self.cam), C.c_void_p(dev_cand)), "kf_set_model_maps_rays")
+        _chk(self.lib.kf_slab_ray_normals(self.h, tp, C.byref(rp), C.byref(self.cam), C.c_float(near), C.c_float(far), C.c_void_p(dev_ta_min),
+                                          C.c_void_p(dev_cand)), "kf_slab_ray_normals")
+
+    def set_model_maps_rays(self, pose, dev_ta_min, dev_cand):
+        tp = C.byref(Mat44.of(pose)) if pose is not None else None
+        _chk(self.lib.kf_set_model_maps_rays(self.h, tp, C.byref(self.cam), C.c_void_p(dev_ta_min), C.c_void_p(dev_cand)), "kf_set_model_maps_rays")
 
     def set_model_maps_device(self, dev_v, dev_n):
         _chk(self.lib.kf_set_model_maps_device(self.h, C.c_void_p(dev_v), C.c_void_p(dev_n)), "kf_set_model_maps_device")

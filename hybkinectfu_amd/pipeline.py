@@ -155,40 +155,37 @@ def merge_candidates(t, v, n, all_reduce_min, all_reduce_sum_i32):
 
 
 class SlabExchange:
-    """The collective sequence that merges one frame's per-slab raycast candidates (first crossing along each ray wins):
+    """The collective sequence that merges one frame's per-slab raycast results (first crossing along each ray wins):
 
-        tmin <- t;  MIN all-reduce(tmin), asynchronous  ->  [overlap(): independent work]  ->  wait
-        mask(t, tmin, cand)                    losers zeroed in place
+        MIN all-reduce(ta), asynchronous       ta[px] = (crossing parameter << 32 | vertex parameter alpha) as int64: positive floats order like their bits,
+          -> [overlap(): independent work]     so the first crossing along the ray wins and brings its alpha along
+          -> wait
+        normals(ta, cand)                      every rank rebuilds the winners' vertices from the rays; the OWNER of a vertex's layer writes (normal, 1)
         integer SUM all-reduce(cand bits)      exactly one rank contributes non-zero bits per pixel; integer sums keep -0.0
-        unpack(cand)                           -> model maps of every rank
+        unpack(ta, cand)                       -> model maps (+ pyramids) of every rank
 
-    A candidate is in RAY FORM: (ray parameter of the vertex, normal xyz), 16 bytes per pixel -- the vertex is rebuilt from the pixel's
-    ray, which every rank derives from the same pose bits.  `mask` / `unpack` are the device launches (kf_slab_mask_rays /
-    kf_set_model_maps_rays) in SlabPipeline; the CPU-only tests and `bench.py --collective-selftest` pass restatements of the two
-    kernels and a gloo group, so the SAME sequence of collectives runs at world_size 2 without a GPU.
+    The gradient is the vertex owner's job, not the crossing owner's: the reference's vertex is an extrapolation (raycastingVolume.cu:89-90) that can land
+    far from the crossing, outside that slab's halo.  `normals` / `unpack` are device launches (kf_slab_ray_normals / kf_set_model_maps_rays) in
+    SlabPipeline; the CPU-only tests and `bench.py --collective-selftest` pass restatements and a gloo group, so the SAME sequence of collectives runs
+    at world_size 2 / 3 without a GPU.  8 + 16 bytes per pixel on the wire.
     """
 
-    def __init__(self, rows, cols, device, dist, mask, unpack):
+    def __init__(self, rows, cols, device, dist, normals, unpack):
         import torch
-        self.dist, self.mask, self.unpack = dist, mask, unpack
-        self.t = torch.empty((rows, cols), dtype=torch.float32, device=device)
-        self.tmin = torch.empty_like(self.t)
-        # what crosses xGMI besides the 4-byte crossing parameter: ray parameter + normal xyz of the winner, 16 bytes per pixel (4.9 MB at VGA)
-        self.cand = torch.empty((rows, cols, 4), dtype=torch.float32, device=device)
+        self.dist, self.normals, self.unpack = dist, normals, unpack
+        self.ta = torch.empty((rows, cols), dtype=torch.int64, device=device)              # this rank's crossings, then (in place) the winners
+        self.cand = torch.empty((rows, cols, 4), dtype=torch.float32, device=device)       # (normal xyz, 1) where this rank owns the winner's vertex
         self.cand_bits = self.cand.view(torch.int32)
 
-    def merge(self, overlap=None, tmin_ready=False):
-        """tmin_ready: the caller has filled self.tmin with a copy of self.t already (the raycast launch writes both)."""
+    def merge(self, overlap=None):
         dist = self.dist
-        if not tmin_ready:
-            self.tmin.copy_(self.t)
-        pending = dist.all_reduce(self.tmin, op=dist.ReduceOp.MIN, async_op=True)
+        pending = dist.all_reduce(self.ta, op=dist.ReduceOp.MIN, async_op=True)
         if overlap is not None:
             overlap()             # runs while the collective is in flight (RCCL's own stream until wait() joins it)
         pending.wait()
-        self.mask(self.t, self.tmin, self.cand)
+        self.normals(self.ta, self.cand)
         dist.all_reduce(self.cand_bits, op=dist.ReduceOp.SUM)
-        self.unpack(self.cand)
+        self.unpack(self.ta, self.cand)
 
 
 def slab_halo_layers(res, size, ray_increment):
@@ -314,8 +311,8 @@ class SlabPipeline:
         self.ctx.set_stream(self.stream.cuda_stream)
         c = self.ctx
         self.ex = SlabExchange(kcam.rows, kcam.cols, dev, dist,
-                               mask=lambda t, tmin, cand: c.slab_mask_rays(t.data_ptr(), tmin.data_ptr(), cand.data_ptr()),
-                               unpack=lambda cand: c.set_model_maps_rays(None, cand.data_ptr()))
+                               normals=lambda ta, cand: c.slab_ray_normals(None, self.inc, P["depth_trunc_min"], self.trunc_max, ta.data_ptr(), cand.data_ptr()),
+                               unpack=lambda ta, cand: c.set_model_maps_rays(None, ta.data_ptr(), cand.data_ptr()))
         self.sums = torch.zeros(32, dtype=torch.float32, device=dev)
         self._merge_events = None           # time_merge(True): (start, end) torch event pairs around every frame's merge
         # dynamic re-balancing of the slab boundaries: every `rebalance_every` frames the ranks pool the work per brick layer that the fusion pass
@@ -410,16 +407,16 @@ class SlabPipeline:
         else:
             c.icp_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
         c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist)
-        c.raycast_slab_rays(None, self.inc, P["depth_trunc_min"], self.trunc_max, ex.t.data_ptr(), ex.cand.data_ptr(), ex.tmin.data_ptr())
+        c.raycast_slab_cross(None, self.inc, P["depth_trunc_min"], self.trunc_max, ex.ta.data_ptr())
 
         if self._merge_events is not None:
             e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
             e0.record(self.stream)
-            ex.merge(tmin_ready=True)
+            ex.merge()
             e1.record(self.stream)
             self._merge_events.append((e0, e1))
         else:
-            ex.merge(tmin_ready=True)
+            ex.merge()
 
     def time_merge(self, on=True):
         """Measurement legs only: time every frame's merge (both all-reduces, mask, unpack)
@@ -442,7 +439,7 @@ class SlabPipeline:
         st = self.stats()
         _, pose, status, _ = self.track_result()
         bits = np.ascontiguousarray(pose, np.float32).view(np.uint32).astype(np.int64).reshape(-1)
-        mine = torch.tensor([int(st["frames_fused"]), int(st["frames_lost"]), int(status)] + bits.tolist(), dtype=torch.int64, device=self.ex.t.device)
+        mine = torch.tensor([int(st["frames_fused"]), int(st["frames_lost"]), int(status)] + bits.tolist(), dtype=torch.int64, device=self.ex.ta.device)
         every = [torch.zeros_like(mine) for _ in range(self.world)]
         dist.all_gather(every, mine)
         for r, other in enumerate(every):

@@ -180,28 +180,33 @@ int kf_set_defer(kf_ctx* ctx, int mode);
 int kf_raycast_volume(kf_ctx* ctx, int has_color, const kf_mat44* transform, const kf_raycast_params* raycast_params,
                       const kf_camera_params* depth_camera, float near_plane, float far_plane);
 
-/* z-slab partitioning (no counterpart in the single-GPU reference).  Each slab context marches every
- * ray and reports the first crossing whose negative sample lies in the layers it owns: dev_t[px] = its ray parameter (+inf
- * if none), dev_v/dev_n[px] = float4 vertex / normal (zeros when the reference's march gives up at that crossing).  The
- * caller takes, per pixel, the entry with the smallest t over all slabs and returns the merged maps to every context. */
+/* z-slab partitioning (no counterpart in the single-GPU reference: raycastKernel / raySample / gradientForPoint,
+ * src/cuda/raycastingVolume.cu:16-156, run on one whole volume).  What pipeline.SlabPipeline runs per frame:
+ *   kf_raycast_volume_slab_cross  every slab context marches every ray and writes, per pixel, ONE 64-bit word: (bits of the ray parameter of the first
+ *                                 crossing whose negative sample lies in the layers it owns) << 32 | bits of the VERTEX's ray parameter alpha
+ *                                 (:89-90) -- +inf / 0 without a crossing, alpha 0 where the reference gives up at the crossing (:87-88);
+ *   MIN all-reduce of the words   (caller; positive floats order like their bits: the first crossing along the ray wins and brings its alpha);
+ *   kf_slab_ray_normals           every context rebuilds the winners' vertices from the pixels' rays -- a pure function of pose and camera, which all
+ *                                 contexts hold bit for bit -- and the one that OWNS a vertex's voxel layer evaluates gradientForPoint (:16-42) for it:
+ *                                 dev_cand[px] = float4 (normal xyz, 1), zeros elsewhere.  (The vertex is an extrapolation that can land far from the
+ *                                 crossing, outside the crossing slab's halo: its taps belong to the vertex's owner.)
+ *   integer SUM all-reduce        of dev_cand (caller; one contributor per pixel: the owner's bits);
+ *   kf_set_model_maps_rays        vertices from alpha, normals from dev_cand -> model maps and levels 1, 2 of their pyramids.
+ * Same transform / camera / increment / planes in all three calls (NULL transform: the device-resident pose). */
+int kf_raycast_volume_slab_cross(kf_ctx* ctx, const kf_mat44* transform, const kf_raycast_params* raycast_params,
+                                 const kf_camera_params* depth_camera, float near_plane, float far_plane, uint64_t* dev_ta);
+int kf_slab_ray_normals(kf_ctx* ctx, const kf_mat44* transform, const kf_raycast_params* raycast_params, const kf_camera_params* depth_camera,
+                        float near_plane, float far_plane, const uint64_t* dev_ta_min, float* dev_cand);
+int kf_set_model_maps_rays(kf_ctx* ctx, const kf_mat44* transform, const kf_camera_params* depth_camera, const uint64_t* dev_ta_min, const float* dev_cand);
+/* MAP FORM of the merge (the earlier protocol, kept for per-kernel tests): the slab that meets a crossing evaluates the whole hit itself -- dev_t[px] =
+ * the crossing's ray parameter (+inf if none), dev_v / dev_n[px] = float4 vertex / normal (zeros when the march gives up there) -- and the caller keeps,
+ * per pixel, the entry with the smallest t (kf_slab_mask_candidates zeroes the losers for an integer SUM).  It drops the rare pixel whose extrapolated
+ * vertex leaves the crossing slab's halo; SlabPipeline does not use it. */
 int kf_raycast_volume_slab(kf_ctx* ctx, int has_color, const kf_mat44* transform, const kf_raycast_params* raycast_params,
                            const kf_camera_params* depth_camera, float near_plane, float far_plane,
                            float* dev_t, float* dev_v, float* dev_n);
-/* merge helper: with dev_tmin = MIN over all slabs of dev_t (an all-reduce), zero this context's candidate where it is not the
- * first crossing; an integer SUM over the slabs of the masked dev_v / dev_n then yields the winner's bits everywhere */
 int kf_slab_mask_candidates(kf_ctx* ctx, const float* dev_t, const float* dev_tmin, float* dev_v, float* dev_n);
 int kf_set_model_maps_device(kf_ctx* ctx, const float* dev_v, const float* dev_n);   /* model_{vertices,normals}_pyramid[0] <- device buffers */
-/* the same merge in RAY FORM, 16 instead of 32 bytes per pixel on the wire (what pipeline.SlabPipeline runs): dev_cand[px] = float4
- * (ray parameter of the vertex, normal xyz) -- a vertex is `origin + direction * parameter` and the pixel's ray is a pure function
- * of pose and camera, which every slab context holds bit for bit.  kf_raycast_volume_slab_rays writes dev_t and dev_cand (zeros where
- * the reference's march gives up at the crossing); kf_slab_mask_rays zeroes dev_cand where dev_t is not dev_tmin; after the caller's
- * integer SUM all-reduce of dev_cand, kf_set_model_maps_rays (same transform / camera as the raycast) rebuilds the vertices and
- * writes the model maps */
-int kf_raycast_volume_slab_rays(kf_ctx* ctx, int has_color, const kf_mat44* transform, const kf_raycast_params* raycast_params,
-                                const kf_camera_params* depth_camera, float near_plane, float far_plane, float* dev_t, float* dev_t_copy,
-                                float* dev_cand);       /* dev_t_copy (may be null): a second copy of dev_t, for the in-place MIN all-reduce */
-int kf_slab_mask_rays(kf_ctx* ctx, const float* dev_t, const float* dev_tmin, float* dev_cand);
-int kf_set_model_maps_rays(kf_ctx* ctx, const kf_mat44* transform, const kf_camera_params* depth_camera, const float* dev_cand);
 
 /* Pixel-partitioned ICP ("partition pixels across GPUs, all-reduce the 27-float system").  `dev_sums` is a
  * caller-owned 32-float device buffer.  kf_icp_partition_begin builds the pyramids and arms the loop; for step = 0 ..

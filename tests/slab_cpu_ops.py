@@ -1,5 +1,5 @@
-"""CPU restatements of the two device launches of the z-slab raycast merge (csrc/raycast.hip: k_slab_rays_mask,
-k_slab_rays_unpack) and a synthetic candidate generator.  Test infrastructure: the CPU-only world-2 tests run
+"""CPU restatements of the device launches of the z-slab raycast merge (csrc/raycast.hip: k_slab_rays_unpack; the map form's k_slab_mask) and a
+synthetic generator of per-slab crossings.  Test infrastructure: the CPU-only world-2 tests run
 pipeline.SlabExchange -- the collective sequence SlabPipeline issues on the GPU -- with these in place of the kernels;
 tests/test_gpu_slabs.py checks on the GPU that the kernels produce the same bits as these functions."""
 import numpy as np
@@ -34,45 +34,75 @@ def pixel_rays(pose, cam, rows, cols):
     return T[:3, 3].copy(), out
 
 
-def unpack(cand, pose=POSE, cam=CAM):
-    """k_slab_rays_unpack: a unit normal is never all-zero, which marks a valid pixel: vertex = origin + direction * parameter, w = 1
-    (else the zero vertex); the normal's w is 0."""
+def pack_ta(t, alpha):
+    """(bits of the crossing's ray parameter) << 32 | bits of the vertex's ray parameter, as int64 -- what kf_raycast_volume_slab_cross writes"""
+    hi = t.contiguous().view(torch.int32).to(torch.int64) << 32
+    lo = alpha.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    return hi | lo
+
+
+def ta_alpha(ta):
+    return torch.from_numpy((ta.numpy() & 0xFFFFFFFF).astype(np.uint32).view(np.float32))
+
+
+def unpack(ta, cand, pose=POSE, cam=CAM):
+    """k_slab_rays_unpack: where the vertex's owner found a gradient (cand.w != 0): vertex = origin + direction * alpha, w = 1, normal = cand.xyz with w = 0;
+    zeros elsewhere."""
     c = cand.numpy()
     rows, cols = c.shape[:2]
     org, dirs = pixel_rays(pose, cam, rows, cols)
-    valid = (c[..., 1:4] != 0).any(axis=-1)
+    valid = c[..., 3] != 0
+    alpha = ta_alpha(ta).numpy()
     v = np.zeros((rows, cols, 4), np.float32)
     n = np.zeros_like(v)
-    vt = org[None, None, :] + dirs * c[..., 0:1]
+    vt = org[None, None, :] + dirs * alpha[..., None]
     v[..., 0:3] = np.where(valid[..., None], vt, np.float32(0.0))
     v[..., 3] = valid.astype(np.float32)
-    n[..., 0:3] = c[..., 1:4]
+    n[..., 0:3] = np.where(valid[..., None], c[..., 0:3], np.float32(0.0))
     return torch.from_numpy(v), torch.from_numpy(n)
 
 
-def synthetic_candidates(rows, cols, rank, world, seed):
-    """What `world` slabs would report for one frame, generated identically on every rank from `seed`: per pixel an owner
-    slab (or none), the owner's crossing (some of them 'failed': the reference gives up there and leaves zeros -- the zeros must
-    still win), later slabs report a losing crossing further along the ray.  Returns this rank's (t, cand) and the merged model
-    maps (vertex, normal) every rank must end up with."""
+def synthetic_crossings(rows, cols, rank, world, seed):
+    """What `world` slabs would report for one frame, generated identically on every rank from `seed`.  Per pixel: the slab that meets the first crossing
+    (or none), its parameter t and the vertex's parameter alpha -- sometimes far beyond t, the extrapolation that sends the vertex into ANOTHER slab;
+    alpha 0 where the reference gives up at the crossing (the empty pixel must still win) --, later slabs reporting a losing crossing further along the
+    ray, the slab that owns the vertex (independent of the one that met the crossing) and the normal it finds (none where the gradient fails).
+    Returns this rank's words, its `normals(ta_min, cand)` step (which also checks that the MIN all-reduce delivered the winners) and the merged model
+    maps every rank must end up with."""
     g = torch.Generator().manual_seed(seed)
-    owner = torch.randint(0, world + 1, (rows, cols), generator=g)              # == world: no crossing anywhere
+    crosser = torch.randint(0, world + 1, (rows, cols), generator=g)            # == world: no crossing anywhere
     t_true = torch.rand((rows, cols), generator=g) * 3 + 0.3
-    c_true = torch.randn((rows, cols, 4), generator=g)
-    c_true[..., 0] = t_true - 0.01 * torch.rand((rows, cols), generator=g)     # the vertex lies a little before the crossing's sample
-    c_true[0, 0, 1:] = torch.tensor([-0.0, 1.0, -0.0])                         # signed zeros must survive the integer sum
-    failed = torch.rand((rows, cols), generator=g) < 0.2
-    c_true[failed] = 0
-    mine = owner == rank
-    later = (owner < rank) & (owner < world)
+    alpha = t_true - 0.01 * torch.rand((rows, cols), generator=g)              # usually the vertex lies a little before the crossing's sample ...
+    far = torch.rand((rows, cols), generator=g) < 0.1
+    alpha = torch.where(far, t_true + 2.0 * torch.rand((rows, cols), generator=g), alpha)      # ... sometimes far beyond it
+    gave_up = torch.rand((rows, cols), generator=g) < 0.15
+    alpha = torch.where(gave_up, torch.zeros_like(alpha), alpha)
+    v_owner = torch.randint(0, world, (rows, cols), generator=g)
+    n_true = torch.randn((rows, cols, 3), generator=g)
+    n_true[0, 0] = torch.tensor([-0.0, 1.0, -0.0])                              # signed zeros must survive the integer sum
+    no_grad = torch.rand((rows, cols), generator=g) < 0.1
     inf = torch.full_like(t_true, float("inf"))
+    mine = crosser == rank
+    later = (crosser < rank) & (crosser < world)
     t = torch.where(mine, t_true, torch.where(later, t_true + 0.5, inf))
-    seven = torch.full_like(c_true, 7.0)
-    zero = torch.zeros_like(c_true)
-    cand = torch.where(mine.unsqueeze(-1), c_true, torch.where(later.unsqueeze(-1), seven, zero))
-    has = (owner < world).unsqueeze(-1)
-    want_v, want_n = unpack(torch.where(has, c_true, zero).contiguous())
-    return t.contiguous(), cand.contiguous(), want_v, want_n
+    a = torch.where(mine, alpha, torch.where(later, torch.full_like(alpha, 7.0), torch.zeros_like(alpha)))
+    ta = pack_ta(t, a)
+    has = crosser < world
+    want_ta = pack_ta(torch.where(has, t_true, inf), torch.where(has, alpha, torch.zeros_like(alpha)))
+    valid = has & ~gave_up & ~no_grad
+
+    def normals(ta_min, cand):
+        assert torch.equal(ta_min, want_ta), "the MIN all-reduce did not deliver the first crossings"
+        cand.zero_()
+        sel = valid & (v_owner == rank)
+        cand[..., 0:3] = torch.where(sel.unsqueeze(-1), n_true, torch.zeros_like(n_true))
+        cand[..., 3] = sel.to(torch.float32)
+
+    full = torch.zeros((rows, cols, 4))
+    full[..., 0:3] = torch.where(valid.unsqueeze(-1), n_true, torch.zeros_like(n_true))
+    full[..., 3] = valid.to(torch.float32)
+    want_v, want_n = unpack(want_ta, full.contiguous())
+    return ta.contiguous(), normals, want_ta, full.contiguous(), want_v, want_n
 
 
 # ---- a numpy stand-in for one rank's slab of the volume: what SlabMigrator moves, without a GPU ---------------------------------------------------

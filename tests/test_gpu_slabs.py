@@ -68,18 +68,25 @@ def test_slabs_equal_whole_volume(world, maxw, frames, balanced):
         assert int((wv[..., 3] != 0).sum()) > 10000
         assert np.array_equal(merged[0].cpu().numpy().view(np.uint32), wv.view(np.uint32))
         assert np.array_equal(merged[1].cpu().numpy().view(np.uint32), wn.view(np.uint32))
-        # the same merge in ray form (what SlabPipeline sends: 16 bytes per pixel): candidates (vertex's ray parameter, normal), masked by
-        # the device launch, integer-summed, vertices rebuilt from the rays -- must arrive at the same bits as the maps above
+        # the merge SlabPipeline runs: 64-bit crossing words (MIN), normals by the vertex's owner (integer SUM), vertices rebuilt from the rays --
+        # must arrive at the same bits as the whole-volume maps
+        tas = []
+        for c in slabs:
+            ta = torch.empty((cam[1], cam[0]), dtype=torch.int64, device=dev)
+            c.raycast_slab_cross(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], ta.data_ptr())
+            c.sync()
+            tas.append(ta)
+        ta_min = torch.stack(tas).min(dim=0).values.contiguous()
         acc = torch.zeros((cam[1], cam[0], 4), dtype=torch.int32, device=dev)
-        for c, (t, _, _) in zip(slabs, bufs):
+        for c in slabs:
             cand = torch.empty((cam[1], cam[0], 4), dtype=torch.float32, device=dev)
-            c.raycast_slab_rays(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], t.data_ptr(), cand.data_ptr())
-            c.slab_mask_rays(t.data_ptr(), tmin.data_ptr(), cand.data_ptr())
+            c.slab_ray_normals(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], ta_min.data_ptr(), cand.data_ptr())
             c.sync()
             acc += cand.view(torch.int32)
         rays = acc.view(torch.float32).contiguous()
+        assert int(((rays[..., 3] != 0) & (rays[..., 3] != 1)).sum()) == 0                 # exactly one owner per vertex
         for c in slabs:
-            c.set_model_maps_rays(None, rays.data_ptr())
+            c.set_model_maps_rays(None, ta_min.data_ptr(), rays.data_ptr())
             c.sync()
             assert np.array_equal(c.download_map(K.MAP_MODEL_VERTICES).view(np.uint32), wv.view(np.uint32))
             assert np.array_equal(c.download_map(K.MAP_MODEL_NORMALS).view(np.uint32), wn.view(np.uint32))
@@ -218,30 +225,27 @@ def test_slab_pipeline_over_rccl_matches_single_gpu_pipeline():
         dist.destroy_process_group()
 
 
-def test_mask_unpack_kernels_equal_cpu_restatement():
-    """k_slab_rays_mask / k_slab_rays_unpack (what SlabPipeline launches between its two all-reduces) == tests/slab_cpu_ops.py, the
-    restatement the CPU-only world-2 tests run in their place -- bit for bit, for every rank's view of a synthetic frame; the vertex
+def test_unpack_kernel_equals_cpu_restatement():
+    """k_slab_rays_unpack (what SlabPipeline launches behind its second all-reduce) == tests/slab_cpu_ops.py, the restatement the CPU-only gloo tests
+    run in its place -- bit for bit on a synthetic frame (far-extrapolated vertices, given-up crossings, failed gradients, signed zeros); the vertex
     rebuilt from its ray parameter included (rc_pixel_ray operation for operation in numpy fp32)."""
     import slab_cpu_ops as ops
     ctx = K.Context(K.camera(*ops.CAM), 32, 3.0, levels=3)
     world = 3
+    tas = [ops.synthetic_crossings(48, 64, r, world, seed=11) for r in range(world)]
+    ta_min = torch.stack([x[0] for x in tas]).min(dim=0).values.contiguous()
+    _, _, want_ta, merged, want_v, want_n = tas[0]
+    assert torch.equal(ta_min, want_ta)
     total = torch.zeros((48, 64, 4), dtype=torch.int32)
-    for rank in range(world):
-        t, cand, want_v, want_n = ops.synthetic_candidates(48, 64, rank, world, seed=11)
-        ts = torch.stack([ops.synthetic_candidates(48, 64, r, world, seed=11)[0] for r in range(world)])
-        tmin = ts.min(dim=0).values
-        want = cand.clone()
-        ops.mask(t, tmin, want)
-        td, tmd, cd = t.cuda(), tmin.cuda(), cand.cuda()
-        ctx.slab_mask_rays(td.data_ptr(), tmd.data_ptr(), cd.data_ptr())
-        ctx.sync()
-        assert torch.equal(cd.cpu().view(torch.int32), want.view(torch.int32))
-        total += want.view(torch.int32)
-    merged = total.view(torch.float32).contiguous()
-    md = merged.cuda()
-    ctx.set_model_maps_rays(ops.POSE, md.data_ptr())
+    for r in range(world):                                        # every rank's normals step (also checks the winners it is handed), integer-summed
+        cand = torch.empty((48, 64, 4))
+        tas[r][1](ta_min, cand)
+        total += cand.view(torch.int32)
+    assert torch.equal(total, merged.view(torch.int32))
+    tad, md = ta_min.cuda(), merged.cuda()
+    ctx.set_model_maps_rays(ops.POSE, tad.data_ptr(), md.data_ptr())
     ctx.sync()
-    uv, un = ops.unpack(merged)
+    uv, un = ops.unpack(ta_min, merged)
     assert np.array_equal(ctx.download_map(K.MAP_MODEL_VERTICES).view(np.uint32), uv.numpy().view(np.uint32))
     assert np.array_equal(ctx.download_map(K.MAP_MODEL_NORMALS).view(np.uint32), un.numpy().view(np.uint32))
     assert torch.equal(uv.view(torch.int32), want_v.view(torch.int32)) and torch.equal(un.view(torch.int32), want_n.view(torch.int32))
@@ -455,3 +459,56 @@ def test_layer_work_counts_the_updates_per_brick_layer():
     assert np.array_equal(gs[lo:hi], want[lo:hi]) and not gs[:lo].any() and not gs[hi:].any()
     assert not whole.read_layer_work().any()                       # read with reset: cleared
     whole.close(); slab.close()
+
+
+def test_vertex_extrapolated_out_of_the_crossing_slab():
+    """Found in round 4 (tools/debug_slab_mismatch.py): the reference's vertex is org + dir * alpha with alpha = t - inc * f(t) / (f(t) - f(t - inc))
+    (raycastingVolume.cu:89-90) -- an extrapolation whenever both interpolated values have the same sign, e.g. behind an isolated negative voxel at a
+    sphere's silhouette -- and then it lands far along the ray, in ANOTHER slab (here: crossing at layer 93, vertex at layer 134.75 on the floor).  The
+    merge therefore lets the vertex's owner evaluate the gradient.  A camera that dollies into the scene produces such a pixel at frame 13: every frame's
+    merged maps must equal the whole-volume raycast bit for bit, and at least one winner's vertex must be owned by a slab that did not meet its crossing."""
+    cam, size, res = S.vga_camera(), 3.0, 256
+    kcam = K.camera(*cam)
+    inc = P["raycast_increment_factor"] * P["integrate_sdf_trunc"]
+    halo = PL.slab_halo_layers(res, size, inc)
+    ranges = PL.slab_ranges(res, 2)
+    whole = K.Context(kcam, res, size, P["volume_max_weight"], levels=3)
+    slabs = [K.Context(kcam, res, size, P["volume_max_weight"], levels=3, slab=r, halo=halo) for r in ranges]
+    dev = torch.device("cuda", 0)
+    for c in [whole] + slabs:
+        c.set_pose(S.pose0(size))
+    foreign = 0
+    for k in range(14):
+        p = S.trajectory_pose(k, size)
+        p = p @ np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0.4 * k / 31.0], [0, 0, 0, 1.0]])
+        mm = S.render_depth_mm(p, cam, size)
+        for c in [whole] + slabs:
+            c.upload_depth_mm(mm)
+            c.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+            c.icp_track(k, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+            c.integrate(None, P["integrate_sdf_trunc"], P["integrate_depth_trunc"])
+        whole.raycast(None, inc, P["depth_trunc_min"], P["depth_trunc_max"])
+        wv, wn = whole.download_map(K.MAP_MODEL_VERTICES), whole.download_map(K.MAP_MODEL_NORMALS)
+        tas = []
+        for c in slabs:
+            ta = torch.empty((cam[1], cam[0]), dtype=torch.int64, device=dev)
+            c.raycast_slab_cross(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], ta.data_ptr())
+            c.sync()
+            tas.append(ta)
+        ta_min = torch.stack(tas).min(dim=0).values.contiguous()
+        acc = torch.zeros((cam[1], cam[0], 4), dtype=torch.int32, device=dev)
+        for r, c in enumerate(slabs):
+            cand = torch.empty((cam[1], cam[0], 4), dtype=torch.float32, device=dev)
+            c.slab_ray_normals(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], ta_min.data_ptr(), cand.data_ptr())
+            c.sync()
+            acc += cand.view(torch.int32)
+            foreign += int(((cand[..., 3] == 1) & (tas[r] != ta_min)).sum())           # this slab owns the vertex of a crossing another slab met
+        rays = acc.view(torch.float32).contiguous()
+        for c in slabs:
+            c.set_model_maps_rays(None, ta_min.data_ptr(), rays.data_ptr())
+            c.sync()
+            assert np.array_equal(c.download_map(K.MAP_MODEL_VERTICES).view(np.uint32), wv.view(np.uint32)), k
+            assert np.array_equal(c.download_map(K.MAP_MODEL_NORMALS).view(np.uint32), wn.view(np.uint32)), k
+    assert foreign >= 1
+    for c in [whole] + slabs:
+        c.close()

@@ -91,17 +91,22 @@ for k in range(n):
             print("frame %d: VOLUME of slab %s (stored %s) differs from the whole volume at %d voxels, first (z, y, x) = %s" % (k, c.owned, c.stored, len(bad), (bad[0] + [z0, 0, 0]).tolist()))
             sys.exit(1)
     whole.raycast(None, inc, P["depth_trunc_min"], P["depth_trunc_max"])
-    for c, (t, v, nn) in zip(slabs, bufs):
-        c.raycast_slab(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], t.data_ptr(), v.data_ptr(), nn.data_ptr())
-        c.sync()
-    ts = torch.stack([b[0] for b in bufs]); tmin_ = ts.min(dim=0).values
-    merged = []
-    for which in (1, 2):
-        acc = torch.zeros((cam[1], cam[0], 4), dtype=torch.int32, device=dev)
-        for b in bufs:
-            win = (b[0] == tmin_) & torch.isfinite(b[0])
-            acc += b[which].view(torch.int32) * win.unsqueeze(-1).to(torch.int32)
-        merged.append(acc.view(torch.float32).contiguous())
+    tas = []
+    for c in slabs:
+        ta = torch.empty((cam[1], cam[0]), dtype=torch.int64, device=dev)
+        c.raycast_slab_cross(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], ta.data_ptr()); c.sync()
+        tas.append(ta)
+    ta_min = torch.stack(tas).min(dim=0).values.contiguous()
+    acc = torch.zeros((cam[1], cam[0], 4), dtype=torch.int32, device=dev)
+    for c in slabs:
+        cand = torch.empty((cam[1], cam[0], 4), dtype=torch.float32, device=dev)
+        c.slab_ray_normals(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], ta_min.data_ptr(), cand.data_ptr()); c.sync()
+        acc += cand.view(torch.int32)
+    rays = acc.view(torch.float32).contiguous()
+    slabs[0].set_model_maps_rays(None, ta_min.data_ptr(), rays.data_ptr()); slabs[0].sync()
+    merged = [torch.from_numpy(slabs[0].download_map(K.MAP_MODEL_VERTICES)).to(dev), torch.from_numpy(slabs[0].download_map(K.MAP_MODEL_NORMALS)).to(dev)]
+    for b_, ta in zip(bufs, tas):                              # (for the print-out: the crossing parameters)
+        b_[0].copy_((ta >> 32).to(torch.int32).view(torch.float32))
     wv, wn = whole.download_map(K.MAP_MODEL_VERTICES), whole.download_map(K.MAP_MODEL_NORMALS)
     mv, mn = merged[0].cpu().numpy(), merged[1].cpu().numpy()
     same = np.array_equal(mv.view(np.uint32), wv.view(np.uint32)) and np.array_equal(mn.view(np.uint32), wn.view(np.uint32))

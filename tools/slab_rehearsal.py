@@ -81,8 +81,6 @@ def worker(a):
     if a.trace:
         ta, tb = trace["SingleGpuPipeline"], trace["SlabPipeline"]
         first_map = next((k for k in range(n) if ta[k][0] != tb[k][0]), None)
-        upd = torch.tensor([t[1] for t in tb], dtype=torch.int64)
-        dist.all_reduce(upd, op=dist.ReduceOp.SUM)
         if rank == 0:
             print("trace: first frame whose merged model maps differ from the single-GPU pipeline's: %s; first frame whose pose differs: %s" % (
                 first_map, pose_ok.index(False) if False in pose_ok else None), flush=True)
