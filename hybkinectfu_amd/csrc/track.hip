@@ -799,9 +799,14 @@ __device__ __forceinline__ void icp_solo_finish(const IcpLoopArgs& L, float (*s_
       if (s_abort == 2) __hip_atomic_store(L.stall_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
     } \
     __syncthreads(); \
-    if (s_abort == 2) icp_solo_finish(L, s_pose, s_linv, s_wave, s_tot, &s_abort); \
+    if (s_abort == 2) ICP_SOLO_CALL; \
     return; \
   } while (0)
+#ifdef KF_ICP_NO_SOLO          /* A/B variant only (tools/build_variant.sh): what the solo path costs the hot loop in registers / code placement */
+#define ICP_SOLO_CALL do { if (threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; } } while (0)
+#else
+#define ICP_SOLO_CALL icp_solo_finish(L, s_pose, s_linv, s_wave, s_tot, &s_abort)
+#endif
 
 // a rider workgroup of a tracking launch: two 64x4 tiles of the NEXT frame's gate + bilateral filter (IcpLoopArgs::bil)
 __device__ __forceinline__ void icp_rider(const IcpLoopArgs& L) {
@@ -867,6 +872,38 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
     }
     for (int it = 0; it < L.iters[l]; ++it, ++step) {
       KF_STAMP(0);
+#ifdef KF_EXPERIMENTS
+      if (step > 0 && KF_EXP_MODE(L) == 14) {
+        // experiment (VERDICT r3 #3b, "leader fold"): workgroup 0 alone folds and solves; everybody else polls ONE line -- the new transform as 16
+        // tagged words (+ the verdict) -- instead of folding the 200 x 27 partial sums itself.  Same bits; timing: profiles/r04_icp_exchange.txt
+        unsigned long long* bc = L.slots + (size_t)28 * KF_ICP_LOOP_MAX_WG * 32 + (size_t)(step - 1) * 32;
+        const unsigned tag = L.tag_base + (unsigned)(step - 1);
+        if (blockIdx.x == 0) {
+          fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, tag, s_tot, &s_abort);
+          s_code = apply_step(a, s_tot, s_cur, nullptr, s_pose[cur_buf ^ 1]);
+          if (threadIdx.x < 17) {
+            const unsigned bits = threadIdx.x < 16 ? __float_as_uint(s_pose[cur_buf ^ 1][threadIdx.x]) : (unsigned)s_code;
+            __hip_atomic_store(bc + threadIdx.x, ((unsigned long long)tag << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        } else {
+          __shared__ int s_bc_code;
+          if (threadIdx.x < 17) {
+            unsigned long long u;
+            do { u = __hip_atomic_load(bc + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if ((unsigned)(u >> 32) != tag) __builtin_amdgcn_s_sleep(1); } while ((unsigned)(u >> 32) != tag);
+            if (threadIdx.x < 16) s_pose[cur_buf ^ 1][threadIdx.x] = __uint_as_float((unsigned)u); else s_bc_code = (int)(unsigned)u;
+          }
+          __syncthreads();
+          s_code = s_bc_code;
+        }
+        if (s_code != STEP_APPLIED) {
+          if (blockIdx.x == 0 && threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; st->converged = 0; st->rescued = 0; }
+          return;
+        }
+        cur_buf ^= 1; s_cur = s_pose[cur_buf];
+        __syncthreads();
+        ++applied;
+      } else
+#endif
       if (step > 0) {
         fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, (KF_EXP_MODE(L) == 2 && n_prev > 16) ? 16 : n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort, KF_EXP_MODE(L), &st->rescue_tag, L.tag_base);
         if (s_abort) { timed_out = true; break; }

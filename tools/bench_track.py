@@ -30,7 +30,7 @@ if os.environ.get("KF_ICP_EXP") == "8":
     # per-workgroup wall-clock stamps (s_memrealtime, 10 ns ticks): [step][wg] -> (published its partial, finished folding everyone's)
     import ctypes as C
     buf = np.zeros(19 * 1024, np.uint64)
-    ctx.lib.kf_exp_read_icp_slots(ctx.h, buf.ctypes.data_as(C.c_void_p), C.c_size_t(24 * 512 * 32), C.c_size_t(buf.size))
+    ctx.lib.kf_exp_read_icp_slots(ctx.h, buf.ctypes.data_as(C.c_void_p), C.c_size_t(24 * 1024 * 32), C.c_size_t(buf.size))
     b = buf.reshape(19, 512, 2).astype(np.int64)
     grids = [13] * 4 + [50] * 5 + [200] * 10
     for s_, g in enumerate(grids):
