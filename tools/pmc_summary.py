@@ -14,7 +14,7 @@ lines = []
 
 
 def per_launch(cfg, counter, kind, want, launches_per_unit=None, tail=None):
-    """mean counter value (bytes) per dispatch of the kernels `want(name)` selects (tail: over the last `tail` of those dispatches only); with
+    """median counter value (bytes) per dispatch of the kernels `want(name)` selects (tail: over the last `tail` of those dispatches only); with
     launches_per_unit: summed over all their dispatches / units"""
     files = glob.glob(os.path.join(out, "pmc_%s_%s" % (kind, cfg), "*", "*counter_collection.csv"))
     if not files:
@@ -30,8 +30,10 @@ def per_launch(cfg, counter, kind, want, launches_per_unit=None, tail=None):
         return None
     if tail:
         per_dispatch = {k: per_dispatch[k] for k in sorted(per_dispatch)[-tail:]}
-    tot = sum(per_dispatch.values()) * 1024.0
-    return tot / (launches_per_unit if launches_per_unit else len(per_dispatch))
+    if launches_per_unit:
+        return sum(per_dispatch.values()) * 1024.0 / launches_per_unit
+    vals = sorted(per_dispatch.values())           # the MEDIAN launch: a run's first fusion launch (empty volume) and the launches right after bench.py's
+    return vals[len(vals) // 2] * 1024.0           # plain-kernel leg (deferred states being re-established) move several times the steady amount
 
 
 def hbm(cfg, want, units=None, tail=None):
@@ -43,11 +45,15 @@ def hbm(cfg, want, units=None, tail=None):
 
 # every bench.py run launches BOTH forms of the fusion kernel: the DEFER form (k_integrate_pairs<BR, true, false>) on the stream's frames and the
 # plain read-modify-write form (<BR, false, false>) on the frames of the `roofline` leg that follows the timed region (kf_set_defer(0))
-plain = lambda n: "k_integrate_pairs" in n and "false, false>" in n
-defer = lambda n: "k_integrate_pairs" in n and "true, false>" in n
+import re
+def _form(n):                       # k_integrate_pairs<BR, DEFER, COLOR, LAYERS>: the second template argument
+    m = re.search(r"k_integrate_pairs<\d+, (true|false)", n)
+    return m.group(1) if m else None
+plain = lambda n: _form(n) == "false"
+defer = lambda n: _form(n) == "true"
 for c in ("c2", "c4", "c5"):
     for run_name, forms in ((c, (("plain", plain, c.upper(), None), ("DEFER", defer, c.upper() + "_deferred", None))),
-                            (c + "_saturated", (("DEFER past saturation: last 20 launches", defer, c.upper() + "_saturated", 20),))):
+                            (c + "_saturated", (("DEFER past saturation: last 40 launches", defer, c.upper() + "_saturated", 40),))):
         for label, want, key, tail in forms:
             h = hbm(run_name, want, tail=tail)
             if h:
@@ -73,7 +79,7 @@ h = hbm("mc_c2", lambda n: "k_mc_" in n, units=3)            # tools/bench_mcube
 if h:
     res["C2_marching_cubes"] = int(h[2])
     lines.append("C2 marching cubes (all k_mc_* kernels of one extraction): 2 x FETCH %.1f MB + WRITE %.1f MB = %.1f MB" % (2 * h[0] / 1e6, h[1] / 1e6, h[2] / 1e6))
-res["source"] = ("profiles/%s_summary.txt: builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh), 2 x FETCH + WRITE per launch, mean over the "
+res["source"] = ("profiles/%s_summary.txt: builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh), 2 x FETCH + WRITE per launch, median over the "
                  "run's launches of that kernel; not measured in the bench run itself" % os.path.basename(out.rstrip("/")))
 json.dump(res, open(os.path.join(out, "integrate_traffic.json"), "w"))
 open(os.path.join(out, "summary.txt"), "w").write("\n".join(lines) + "\n")
