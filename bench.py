@@ -238,7 +238,7 @@ def steady_state(name, n_timed=100):
     tpath = os.path.join(ROOT, "profiles", "integrate_traffic.json")
     try:
         tj = json.load(open(tpath))
-        tr = tj.get(wl["name"] + "_saturated")
+        tr = tj.get(wl["name"] + "_saturated") if wl["res"] >= 768 else tj.get(wl["name"])      # (below 768^3 the plain kernel runs: its own traffic figure)
     except Exception:
         tj, tr = {}, None
     out["kernel_traffic_bytes_per_launch"] = tr
