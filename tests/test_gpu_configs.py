@@ -316,7 +316,7 @@ def test_c5_2048_cubed_z_bands_against_the_oracle():
             c.integrate(pose, trunc, dist)
         n_slab.append([c.stats()["updated_last"] for c in slab])
     st = whole.stats()
-    assert st["updated_last"] > 4e8 and st["bricks_active"] > 300_000        # (second frame: whole free-space bricks are retired by the cull, not queued)
+    assert st["updated_last"] > 4e8 and st["bricks_active"] > 100_000        # (second frame: whole free-space bricks are retired by the cull, not queued)
     for i, ((z0, z1), mz) in enumerate(bands):
         ovol = O.OVolume(res, size, maxw, band=(z0, z1 - z0))
         for f, (pose, tr, n) in enumerate(frames):
