@@ -16,73 +16,66 @@
 
 // contexts alive per device: the persistent ICP loop needs its workgroups co-resident, which only one context per GPU guarantees
 static int g_live_ctx[64];
-int kf_live_contexts(int device) { return (device >= 0 && device < 64) ? g_live_ctx[device] : 2; }
+int kf_live_contexts(int device) { return (device >= 0 && device < 64) ? __atomic_load_n(&g_live_ctx[device], __ATOMIC_RELAXED) : 2; }
 
 // ---- the same question across PROCESSES ------------------------------------------------------------------------------------------
 // Two processes that each run a persistent ICP loop on one GPU can leave both loops partly resident, each waiting for workgroups the
-// other one keeps off the chip (the 2-rank shared-GPU rehearsal lost a frame to exactly that).  Processes of this library
-// therefore register per physical device (keyed by PCI bus id, so HIP_VISIBLE_DEVICES renumbering does not matter) in a small POSIX
-// shared-memory segment: a slot table of process ids plus a generation word bumped by every change.  kf_device_shared() is one volatile
-// read per frame; the table is only rescanned (kill(pid, 0) liveness probes) when the generation moved.  A crashed process leaves a
-// stale slot until the next rescan finds its pid dead -- the error is on the safe side (per-step launches, slower, same bits).
-// No segment (no /dev/shm): the answer is "not shared" and the loop's own stall detection remains the safety net.
-struct KfShmDevice { unsigned gen; unsigned pad_; int pids[62]; };
-static KfShmDevice* g_shm[64];
-static unsigned g_shm_seen_gen[64];
-static int g_shm_others[64];
-static KfShmDevice* shm_for_device(int device) {
-  if (device < 0 || device >= 64) return nullptr;
-  if (g_shm[device]) return g_shm[device];
-  char bus[64] = {0}, name[128];
-  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, device) != hipSuccess) return nullptr;
+// other one keeps off the chip (since round 4 such a loop is finished by one workgroup instead of losing the frame, but that costs tens of
+// milliseconds).  Processes of this library therefore register per physical device (keyed by PCI bus id, so HIP_VISIBLE_DEVICES renumbering
+// does not matter): each holds an exclusive advisory lock (flock) on ONE slot file /dev/shm/hybkf_<uid>_<bus>.<slot> for as long as it has
+// a context on the device.  Ownership is the kernel's business: a process that dies releases its lock, whatever its pid was and whichever
+// pid namespace it lived in (round 3 probed raw pids with kill(pid, 0): a live peer in another namespace looked dead, a recycled pid
+// looked alive).  "Is the device shared?" = can a lock on somebody else's slot NOT be taken.  Probing costs a few system calls, so it is
+// done once per 256 frames and whenever this process's own contexts change; everything is behind one mutex (contexts may be created and
+// tracked from several threads).  No /dev/shm: the answer is "not shared" and the loop's solo finish remains the safety net.
+#include <sys/file.h>
+#include <mutex>
+#define KF_SHM_SLOTS 16
+static std::mutex g_reg_mutex;
+static int g_slot_fd[64];                     // this process's slot file per device (0: none; fds are > 2)
+static int g_slot_idx[64];
+static int g_shared_cached[64];
+static unsigned g_shared_calls[64];
+static bool slot_path(int device, int slot, char* out, size_t n) {
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, device) != hipSuccess) return false;
   for (char* q = bus; *q; ++q) if (*q == ':' || *q == '.') *q = '_';
-  snprintf(name, sizeof(name), "/hybkf_%u_%s", (unsigned)getuid(), bus);
-  const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
-  if (fd < 0) return nullptr;
-  if (ftruncate(fd, (off_t)sizeof(KfShmDevice)) != 0) { close(fd); return nullptr; }
-  void* m = mmap(nullptr, sizeof(KfShmDevice), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (m == MAP_FAILED) return nullptr;
-  g_shm[device] = (KfShmDevice*)m;
-  g_shm_seen_gen[device] = ~0u;
-  return g_shm[device];
+  snprintf(out, n, "/dev/shm/hybkf_%u_%s.%d", (unsigned)getuid(), bus, slot);
+  return true;
 }
-static bool pid_alive(int pid) { return pid > 0 && (kill(pid, 0) == 0 || errno == EPERM); }
-static void shm_register(int device) {
-  KfShmDevice* t = shm_for_device(device);
-  if (!t) return;
-  const int me = (int)getpid();
-  for (int i = 0; i < 62; ++i) if (__atomic_load_n(&t->pids[i], __ATOMIC_RELAXED) == me) return;      // (another context of this process)
-  for (int i = 0; i < 62; ++i) {
-    int cur = __atomic_load_n(&t->pids[i], __ATOMIC_RELAXED);
-    if (cur != 0 && pid_alive(cur)) continue;
-    if (__atomic_compare_exchange_n(&t->pids[i], &cur, me, false, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED)) break;
+static void shm_register(int device) {                       // (under g_reg_mutex)
+  if (device < 0 || device >= 64 || g_slot_fd[device] > 0) return;
+  char path[160];
+  for (int s = 0; s < KF_SHM_SLOTS; ++s) {
+    if (!slot_path(device, s, path, sizeof(path))) return;
+    const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+    if (fd < 0) return;
+    if (flock(fd, LOCK_EX | LOCK_NB) == 0) { g_slot_fd[device] = fd; g_slot_idx[device] = s; g_shared_calls[device] = 0; return; }
+    close(fd);
   }
-  __atomic_fetch_add(&t->gen, 1u, __ATOMIC_ACQ_REL);
 }
-static void shm_unregister(int device) {
-  KfShmDevice* t = (device >= 0 && device < 64) ? g_shm[device] : nullptr;
-  if (!t) return;
-  const int me = (int)getpid();
-  for (int i = 0; i < 62; ++i) { int cur = me; __atomic_compare_exchange_n(&t->pids[i], &cur, 0, false, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED); }
-  __atomic_fetch_add(&t->gen, 1u, __ATOMIC_ACQ_REL);
+static void shm_unregister(int device) {                     // (under g_reg_mutex)
+  if (device < 0 || device >= 64 || g_slot_fd[device] <= 0) return;
+  flock(g_slot_fd[device], LOCK_UN); close(g_slot_fd[device]);
+  g_slot_fd[device] = 0; g_shared_cached[device] = 0;
 }
 // does another live process of this library hold a context on `device`?
 int kf_device_shared(int device) {
-  KfShmDevice* t = (device >= 0 && device < 64) ? g_shm[device] : nullptr;
-  if (!t) return 0;
-  const unsigned gen = __atomic_load_n(&t->gen, __ATOMIC_ACQUIRE);
-  // rescan when the table changed -- and every 512th call while somebody else is listed: a process that died without unregistering
-  // bumps no generation, and its slot must not keep the survivors on per-step launches for good
-  static unsigned calls[64];
-  const bool periodic = g_shm_others[device] > 0 && (++calls[device] & 511u) == 0u;
-  if (gen != g_shm_seen_gen[device] || periodic) {
-    const int me = (int)getpid();
-    int others = 0;
-    for (int i = 0; i < 62; ++i) { const int p = __atomic_load_n(&t->pids[i], __ATOMIC_RELAXED); if (p != 0 && p != me && pid_alive(p)) ++others; }
-    g_shm_others[device] = others; g_shm_seen_gen[device] = gen;
+  if (device < 0 || device >= 64) return 0;
+  std::lock_guard<std::mutex> lock(g_reg_mutex);
+  if (g_slot_fd[device] <= 0) return 0;
+  if ((g_shared_calls[device]++ & 255u) != 0u) return g_shared_cached[device];
+  int others = 0;
+  char path[160];
+  for (int s = 0; s < KF_SHM_SLOTS && !others; ++s) {
+    if (s == g_slot_idx[device] || !slot_path(device, s, path, sizeof(path))) continue;
+    const int fd = open(path, O_RDWR | O_CLOEXEC);
+    if (fd < 0) continue;                                    // never created: nobody there
+    if (flock(fd, LOCK_EX | LOCK_NB) != 0) others = 1; else flock(fd, LOCK_UN);
+    close(fd);
   }
-  return g_shm_others[device] > 0;
+  g_shared_cached[device] = others;
+  return others;
 }
 
 extern "C" const char* kf_version(void) { return "hybkf-gfx950 0.1"; }
@@ -136,7 +129,8 @@ extern "C" int kf_destroy(kf_ctx* c) {
   if (c->own_stream) c->stream = c->own_stream;
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->registered && c->cfg.device >= 0 && c->cfg.device < 64) {
-    if (__atomic_sub_fetch(&g_live_ctx[c->cfg.device], 1, __ATOMIC_RELAXED) == 0) shm_unregister(c->cfg.device);     // the process's last context on the device
+    std::lock_guard<std::mutex> lock(g_reg_mutex);
+    if (--g_live_ctx[c->cfg.device] == 0) shm_unregister(c->cfg.device);     // the process's last context on the device
   }
   delete c;
   return 0;
@@ -224,7 +218,7 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
   TRY(kf_reset_volume(c));
   TRY((int)hipStreamSynchronize(c->stream));
 #undef TRY
-  if (cfg->device >= 0 && cfg->device < 64) { __atomic_fetch_add(&g_live_ctx[cfg->device], 1, __ATOMIC_RELAXED); c->registered = 1; shm_register(cfg->device); }
+  if (cfg->device >= 0 && cfg->device < 64) { std::lock_guard<std::mutex> lock(g_reg_mutex); ++g_live_ctx[cfg->device]; c->registered = 1; shm_register(cfg->device); }
   *out = c;
   return 0;
 }
