@@ -346,33 +346,33 @@ def collective_selftest(args):
     return 0 if flag.item() else 1
 
 
-def pcie_inclusive(wl, frames_mm, n_frames=100, warmup=10):
-    """Frames/s when every frame starts in HOST memory (kf_upload_depth_mm: pinned double-buffered staging, DMA on a copy stream
-    while the previous frame is computed).  Reported beside `value`, never as `value`."""
+def pcie_inclusive(wl, frames_mm, n_frames=100, warmup=10, repeats=3):
+    """Frames/s when every frame starts in HOST memory: SingleGpuPipeline.process_frame_host -- pinned staging, DMA on a copy stream, frame k + 2
+    crossing PCIe (kf_upload_depth_mm_next, a free upload slot) while frame k is processed and frame k + 1's front end rides in frame k's launches.
+    Every frame is uploaded inside the timed region.  Reported beside `value`, never as `value`.  The rate depends on where the runtime places the
+    pinned staging buffers (it differs from context to context on the same box), so `repeats` fresh contexts are timed: value = their median."""
     import torch
     from hybkinectfu_amd.pipeline import SingleGpuPipeline
     cam = wl["cam"]
-    pipe = SingleGpuPipeline(K.camera(*cam), wl["res"], wl["size"], wl, device=torch.cuda.current_device())
-    c = pipe.ctx
     host = [np.ascontiguousarray(f, np.uint16) for f in frames_mm]
 
-    def run(first, count):
-        for k in range(first, first + count):
-            mm = host[k % len(host)]
-            K._chk(c.lib.kf_upload_depth_mm(c.h, K._p(mm), mm.shape[1], mm.shape[0]), "kf_upload_depth_mm")
-            c.preprocess(P["depth_trunc_min"], pipe.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
-            c.icp_track(k, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
-            c.integrate(None, P["integrate_sdf_trunc"], pipe.integ_dist)
-            c.raycast(None, pipe.inc, P["depth_trunc_min"], pipe.trunc_max)
-    run(0, warmup)
-    pipe.sync()
-    t0 = time.perf_counter()
-    run(warmup, n_frames)
-    pipe.sync()
-    dt = time.perf_counter() - t0
-    pipe.close()
-    return dict(value=round(n_frames / dt, 2), unit="frames/s", steps=n_frames, bytes_per_frame=int(cam[0] * cam[1] * 2),
-                note="every frame uploaded from host memory over PCIe inside the timed region (kf_upload_depth_mm)")
+    def frame_of(k):
+        return host[k % len(host)]
+    rates = []
+    for _ in range(repeats):
+        pipe = SingleGpuPipeline(K.camera(*cam), wl["res"], wl["size"], wl, device=torch.cuda.current_device())
+        for k in range(warmup):
+            pipe.process_frame_host(frame_of, k)
+        pipe.sync()
+        t0 = time.perf_counter()
+        for k in range(warmup, warmup + n_frames):
+            pipe.process_frame_host(frame_of, k)
+        pipe.sync()
+        rates.append(round(n_frames / (time.perf_counter() - t0), 2))
+        pipe.close()
+    return dict(value=sorted(rates)[len(rates) // 2], unit="frames/s", steps=n_frames, runs=rates, bytes_per_frame=int(cam[0] * cam[1] * 2),
+                note="every frame uploaded from host memory over PCIe inside the timed region, two frames ahead of its use (kf_upload_depth_mm_next + "
+                     "kf_prefetch_frame); median of %d fresh contexts" % repeats)
 
 
 def profiled_traffic(key):
@@ -831,7 +831,7 @@ def main():
         # the metric's own wording includes the upload ("upload + preprocess + track + integrate + raycast"): both rates side by side
         out["value_pcie_inclusive"] = out["pcie_inclusive"]["value"]
         out["value_note"] = ("value = value_resident: frames already in HBM when the timed region starts (the bench contract); value_pcie_inclusive: every frame "
-                             "crosses PCIe inside the timed region (kf_upload_depth_mm), the metric's literal wording")
+                             "crosses PCIe inside the timed region (kf_upload_depth_mm / kf_upload_depth_mm_next), the metric's literal wording")
         out["steady_state"] = {"C2": steady_state("c2"), "C4": steady_state("c4")}
         if args.config == "auto":
             out["scene_noise"] = scene_noise_block(wl)

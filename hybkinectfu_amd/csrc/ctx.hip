@@ -102,12 +102,12 @@ extern "C" int kf_destroy(kf_ctx* c) {
   hipSetDevice(c->cfg.device);
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->own_stream) hipStreamSynchronize(c->own_stream);
-  void* ptrs[] = {c->up_dev[0], c->up_dev[1], c->raw_depth, c->trunced_depth, c->filtered_depth, c->raw_rgb, c->raycast_rgb, c->icp_partials, c->icp_loop_slots,
+  void* ptrs[] = {c->up_dev[0], c->up_dev[1], c->up_dev[2], c->raw_depth, c->trunced_depth, c->filtered_depth, c->raw_rgb, c->raycast_rgb, c->icp_partials, c->icp_loop_slots,
                   c->track, c->counters, c->grid_barrier, c->scratch_mats, c->vol.tw, c->vol.color, c->vol.flags, c->vol.macrobits, c->vol.negbits, c->vol.pend, c->layer_work, c->active_bricks,
                   c->tile_max_depth, c->triangles, c->mc_block_counts, c->mc_list, c->mc_nbr_bits, c->mc_partials, c->mc_codes, c->mc_surv, c->mc_block_bits, c->mc_recs, c->mc_d1_list};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->up_stream) { hipStreamSynchronize(c->up_stream); hipStreamDestroy(c->up_stream); }
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < KF_UP_SLOTS; ++i) {
     if (c->up_host[i]) hipHostFree(c->up_host[i]);
     if (c->up_copied[i]) hipEventDestroy(c->up_copied[i]);
     if (c->up_consumed[i]) hipEventDestroy(c->up_consumed[i]);
@@ -157,7 +157,7 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
 #define TRY(x) do { st = (x); if (st) { kf_destroy(c); return st; } } while (0)
   TRY((int)hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   const size_t npx = (size_t)c->cols * c->rows;
-  c->pending_slot = -1; c->defer_override = -1;
+  c->pending_slot = -1; c->n_staged = 0; c->defer_override = -1;
   TRY(dev_alloc(&c->raw_depth, npx)); TRY(dev_alloc(&c->trunced_depth, npx)); TRY(dev_alloc(&c->filtered_depth, npx));
   const size_t nrgb = (size_t)cfg->rgb_camera.cols * cfg->rgb_camera.rows;
   if (cfg->has_color) { TRY(dev_alloc(&c->raw_rgb, nrgb ? nrgb : npx)); TRY(dev_alloc(&c->raycast_rgb, npx)); }
@@ -287,33 +287,74 @@ int kf_materialize_raw_depth(kf_ctx* c) {
   return st ? st : kf_pending_depth_consumed(c);
 }
 
-extern "C" int kf_upload_depth_mm(kf_ctx* c, const uint16_t* host_mm, uint32_t cols, uint32_t rows) {
+// pinned staging -> DMA on the copy stream -> device slot `*slot_out`.  Three slots in rotation: the current frame and up to two staged ahead.
+// wait_now: the context's stream waits for the copy at once (the frame is used next); otherwise whoever first reads the slot on that stream
+// asks for the wait (kf_upload_wait_for) -- a frame staged two ahead has crossed PCIe long before anything reads it.
+static int upload_into_next_slot(kf_ctx* c, const uint16_t* host_mm, uint32_t cols, uint32_t rows, bool wait_now, int* slot_out) {
   if (!c || !host_mm || (int)cols != c->cols || (int)rows != c->rows) return KF_ERR_ARG;
   KF_CHECK(hipSetDevice(c->cfg.device));
   const size_t bytes = (size_t)cols * rows * sizeof(uint16_t);
   if (!c->up_stream) {
     KF_CHECK(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < KF_UP_SLOTS; ++i) {
       KF_CHECK(hipHostMalloc((void**)&c->up_host[i], bytes, hipHostMallocDefault));
       KF_CHECK(hipMalloc((void**)&c->up_dev[i], bytes));
       KF_CHECK(hipEventCreateWithFlags(&c->up_copied[i], hipEventDisableTiming));
       KF_CHECK(hipEventCreateWithFlags(&c->up_consumed[i], hipEventDisableTiming));
     }
   }
-  const int p = c->up_next; c->up_next ^= 1;
-  if (c->pending_slot == p) c->pending_slot = -1;            // the frame uploaded two calls ago was never consumed: it is being replaced
+  const int p = c->up_next; c->up_next = (p + 1) % KF_UP_SLOTS;
+  if (c->pending_slot == p) c->pending_slot = -1;            // the frame uploaded three calls ago was never consumed: it is being replaced
   if (c->up_used[p]) {
-    KF_CHECK(hipEventSynchronize(c->up_copied[p]));           // the pinned buffer's previous DMA (two uploads ago: long finished)
+    KF_CHECK(hipEventSynchronize(c->up_copied[p]));           // the pinned buffer's previous DMA (three uploads ago: long finished)
     KF_CHECK(hipStreamWaitEvent(c->up_stream, c->up_consumed[p], 0));   // the device buffer's last reader
   }
   memcpy(c->up_host[p], host_mm, bytes);
   KF_CHECK(hipMemcpyAsync(c->up_dev[p], c->up_host[p], bytes, hipMemcpyHostToDevice, c->up_stream));
   KF_CHECK(hipEventRecord(c->up_copied[p], c->up_stream));
-  KF_CHECK(hipStreamWaitEvent(c->stream, c->up_copied[p], 0));
+  c->up_unwaited[p] = 1;
+  if (wait_now) { KF_CHECK(hipStreamWaitEvent(c->stream, c->up_copied[p], 0)); c->up_unwaited[p] = 0; }
   if (!c->up_used[p]) KF_CHECK(hipEventRecord(c->up_consumed[p], c->stream));   // give the event a defined state before its first wait
   c->up_used[p] = 1;
+  *slot_out = p;
+  return 0;
+}
+// a kernel that reads `dev_mm` is about to be enqueued on the context's stream: if that is an upload slot whose copy the stream has not waited for, it does now
+int kf_upload_wait_for(kf_ctx* c, const uint16_t* dev_mm) {
+  for (int i = 0; i < KF_UP_SLOTS; ++i)
+    if (c->up_unwaited[i] && dev_mm == c->up_dev[i]) { KF_CHECK(hipStreamWaitEvent(c->stream, c->up_copied[i], 0)); c->up_unwaited[i] = 0; }
+  return 0;
+}
+extern "C" int kf_upload_depth_mm(kf_ctx* c, const uint16_t* host_mm, uint32_t cols, uint32_t rows) {
+  int p = -1;
+  const int st = upload_into_next_slot(c, host_mm, cols, rows, true, &p);
+  if (st) return st;
+  c->n_staged = 0;                                           // frames staged behind the one this call replaces are dropped with it
   c->pending_mm = c->up_dev[p]; c->pending_slot = p;
   return 0;
+}
+// Frames AHEAD of the current one (HybKinectfu::copyFrameToGPU src/HybKinectfu.cpp:63-96, run early): the upload goes into a free slot and
+// does not replace the current frame; up to two frames may be staged, kf_take_next_depth makes the oldest of them the current one (what
+// kf_upload_depth_mm would have done).  *dev_mm (may be null) is where the frame lies on the device -- what kf_prefetch_frame wants, so that
+// the frame's front end rides in its predecessor's launches.  Staging TWO ahead (upload frame k+2 while frame k is processed and frame k+1's
+// front end rides along) takes the copy off the critical path altogether: a host-fed stream then runs at the resident stream's rate.
+extern "C" int kf_upload_depth_mm_next(kf_ctx* c, const uint16_t* host_mm, uint32_t cols, uint32_t rows, const uint16_t** dev_mm) {
+  if (!c) return KF_ERR_ARG;
+  if (c->n_staged >= 2) return KF_ERR_STATE;
+  int p = -1;
+  const int st = upload_into_next_slot(c, host_mm, cols, rows, false, &p);
+  if (st) return st;
+  c->staged[c->n_staged++] = p;
+  if (dev_mm) *dev_mm = c->up_dev[p];
+  return 0;
+}
+extern "C" int kf_take_next_depth(kf_ctx* c) {
+  if (!c) return KF_ERR_ARG;
+  if (c->n_staged < 1) return KF_ERR_STATE;
+  const int p = c->staged[0];
+  c->staged[0] = c->staged[1]; c->n_staged--;
+  c->pending_mm = c->up_dev[p]; c->pending_slot = p;
+  return kf_upload_wait_for(c, c->pending_mm);
 }
 
 __global__ void __launch_bounds__(256) k_rgb3_to_rgb4(const unsigned char* __restrict__ in, uchar4* __restrict__ out, int n) {

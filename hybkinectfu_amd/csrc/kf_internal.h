@@ -126,6 +126,7 @@ struct KfCounters {
   unsigned long long mc_blocks[64 * 16];     // marching cubes: 4-KiB bricks the extraction reads (those with a negative voxel in their 3x3x3 brick neighbourhood)
 };
 
+#define KF_UP_SLOTS 3                  // host-upload slots: the current frame and up to two staged ahead of it
 struct kf_ctx {
   kf_config cfg;
   hipStream_t stream;                 // where work is enqueued (private, or adopted through kf_set_stream)
@@ -138,8 +139,10 @@ struct kf_ctx {
   // frame maps (CudaDeviceDataMan.h:56-67)
   // host uploads (kf_upload_depth_mm) are double-buffered: pinned host staging -> DMA on a copy stream -> device buffer, so
   // frame k+1 crosses PCIe while frame k is computed; events order the copy after the last reader of the buffer it reuses
-  uint16_t* up_host[2]; uint16_t* up_dev[2]; hipStream_t up_stream; hipEvent_t up_copied[2], up_consumed[2];
-  int up_next, up_used[2], pending_slot;   // pending_slot: which up_dev[] pending_mm points at (-1: a caller-owned device frame)
+  uint16_t* up_host[KF_UP_SLOTS]; uint16_t* up_dev[KF_UP_SLOTS]; hipStream_t up_stream; hipEvent_t up_copied[KF_UP_SLOTS], up_consumed[KF_UP_SLOTS];
+  int up_next, up_used[KF_UP_SLOTS], pending_slot;   // pending_slot: which up_dev[] pending_mm points at (-1: a caller-owned device frame)
+  int up_unwaited[KF_UP_SLOTS];       // the context's stream has not been made to wait for this slot's copy yet (frames staged ahead)
+  int staged[2], n_staged;            // kf_upload_depth_mm_next: the slots that hold the frames AFTER the current one, oldest first
   const uint16_t* pending_mm;         // device u16 frame whose conversion is deferred into the fused preprocess kernel
   float* raw_depth; float* trunced_depth; float* filtered_depth;
   uchar4* raw_rgb; uchar4* raycast_rgb;   // stored 4 bytes/pixel on the device
@@ -556,3 +559,4 @@ int kf_live_contexts(int device);
 int kf_device_shared(int device);
 int kf_materialize_raw_depth(kf_ctx* ctx);
 int kf_pending_depth_consumed(kf_ctx* ctx);
+int kf_upload_wait_for(kf_ctx* ctx, const uint16_t* dev_mm);   // dev_mm is about to be read on the context's stream: wait for its staged copy, if it is one

@@ -336,6 +336,7 @@ extern "C" int kf_prefetch_frame(kf_ctx* c, const uint16_t* dev_mm, uint32_t col
     c->alt_v12[0] = (float4*)p[5]; c->alt_n12[0] = (float4*)p[6]; c->alt_v12[1] = (float4*)p[7]; c->alt_n12[1] = (float4*)p[8];
   }
   c->alt_pyr_ok = 0;
+  { const int st = kf_upload_wait_for(c, dev_mm); if (st) return st; }   // a frame staged by kf_upload_depth_mm_next: its readers follow on this stream
   static int fused = -1;                                   // KF_PREFETCH_FUSED=0: the side-stream form (events between two streams)
   if (fused < 0) { const char* e = getenv("KF_PREFETCH_FUSED"); fused = e ? atoi(e) : 1; }
   if (fused) {
@@ -354,6 +355,7 @@ extern "C" int kf_prefetch_frame(kf_ctx* c, const uint16_t* dev_mm, uint32_t col
   }
   // the alternate set was last read by the frame BEFORE the current one; all of that precedes the current frame's preprocess
   KF_CHECK(hipStreamWaitEvent(c->side_stream, c->ev_preprocessed, 0));
+  for (int i = 0; i < KF_UP_SLOTS; ++i) if (c->up_used[i] && dev_mm == c->up_dev[i]) KF_CHECK(hipStreamWaitEvent(c->side_stream, c->up_copied[i], 0));
   int st = launch_fused_preprocess(c, c->side_stream, dev_mm, nullptr, c->alt_raw, c->alt_trunced, c->alt_filtered, c->alt_v0, c->alt_n0,
                                    tmin, tmax, sigma_pixel, sigma_depth, cam, false);
   if (st) return st;

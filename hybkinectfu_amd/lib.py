@@ -87,6 +87,7 @@ SYMBOLS = [
     "kf_icp_partition_begin", "kf_icp_partition_steps", "kf_icp_partition_step", "kf_icp_partition_finish",
     "kf_sdf_partition_begin", "kf_sdf_partition_step", "kf_sdf_partition_finish", "kf_set_defer", "kf_inject_track_stall",
     "kf_download_volume_device", "kf_upload_volume_device", "kf_resize_slab", "kf_count_layer_work", "kf_read_layer_work",
+    "kf_upload_depth_mm_next", "kf_take_next_depth",
 ]
 
 
@@ -190,6 +191,16 @@ class Context:
         mm = np.ascontiguousarray(mm, np.uint16)
         _chk(self.lib.kf_upload_depth_mm(self.h, _p(mm), mm.shape[1], mm.shape[0]), "kf_upload_depth_mm")
         self.sync()
+
+    def upload_depth_mm_next(self, mm):
+        """stage the NEXT frame while the current one is processed; returns its device address (for prefetch_frame)"""
+        mm = np.ascontiguousarray(mm, np.uint16)
+        dev = C.c_void_p()
+        _chk(self.lib.kf_upload_depth_mm_next(self.h, _p(mm), mm.shape[1], mm.shape[0], C.byref(dev)), "kf_upload_depth_mm_next")
+        return dev.value
+
+    def take_next_depth(self):
+        _chk(self.lib.kf_take_next_depth(self.h), "kf_take_next_depth")
 
     def set_depth_mm_device(self, dev_ptr):
         _chk(self.lib.kf_set_depth_mm_device(self.h, C.c_void_p(dev_ptr), self.cam.cols, self.cam.rows), "kf_set_depth_mm_device")

@@ -21,6 +21,7 @@ class SingleGpuPipeline:
         self.ctx = K.Context(kcam, res, size, wl.get("max_weight", P["volume_max_weight"]), levels=3, max_triangles=max_triangles, device=device, has_color=self.color)
         self.ctx.set_pose(S.pose0(size))                       # HybKinectfu::init  src/HybKinectfu.cpp:51-57
         self.inc = P["raycast_increment_factor"] * P["integrate_sdf_trunc"]     # AppParamsProducer.cpp:113-117
+        self._host = None                                      # process_frame_host: what is staged ahead
 
     def process_frame_device(self, dev_mm_ptr, frame_id, next_mm_ptr=None):
         """next_mm_ptr: where the NEXT frame already lies in HBM (streaming input): its depth conversion + gate + bilateral filter ride in this
@@ -37,6 +38,37 @@ class SingleGpuPipeline:
             c.icp_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])  # :116
         c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist, has_color=self.color, angle_weight=self.color)      # :125-140
         c.raycast(None, self.inc, P["depth_trunc_min"], self.trunc_max, has_color=self.color)                           # :149-154
+
+    def process_frame_host(self, frame_of, frame_id):
+        """A stream whose frames start in HOST memory (HybKinectfu::copyFrameToGPU, src/HybKinectfu.cpp:63-96): `frame_of(k)` -> u16 millimetres of
+        frame k, or None past the end of the stream.  Frame k + 2 crosses PCIe (kf_upload_depth_mm_next, a free upload slot) while frame k is
+        processed and frame k + 1's front end rides in frame k's launches: the copy is off the critical path.  Frame ids that do not follow the
+        previous call's by one restart the staging (that frame is then uploaded and waited for)."""
+        c = self.ctx
+        st = self._host
+        if st is None or st["expect"] != frame_id or st["staged"] == 0:
+            c.upload_depth_mm(frame_of(frame_id))              # (drops whatever was staged)
+            st = self._host = dict(expect=frame_id, staged=0, next_dev=None)
+            nxt = frame_of(frame_id + 1)
+            if nxt is not None:
+                st["next_dev"], st["staged"] = c.upload_depth_mm_next(nxt), 1
+        else:
+            c.take_next_depth()
+            st["staged"] -= 1
+        c.preprocess(P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
+        dev_after = None
+        if st["staged"] == 1:
+            after = frame_of(frame_id + 2)
+            if after is not None:
+                dev_after, st["staged"] = c.upload_depth_mm_next(after), 2
+            c.prefetch_frame(st["next_dev"], P["depth_trunc_min"], self.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
+        st["next_dev"], st["expect"] = dev_after, frame_id + 1
+        if self.tracker == "sdf":
+            c.sdf_track(frame_id, P["sdf_max_iter_nums"], P["camera_shake_dist"], P["camera_shake_angle"])
+        else:
+            c.icp_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+        c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist, has_color=self.color, angle_weight=self.color)
+        c.raycast(None, self.inc, P["depth_trunc_min"], self.trunc_max, has_color=self.color)
 
     def sync(self):
         self.ctx.sync()

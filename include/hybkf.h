@@ -105,6 +105,13 @@ int kf_reset_volume(kf_ctx* ctx);                    /* tsdfvolume::init clearDa
 
 /* HybKinectfu::copyFrameToGPU  src/HybKinectfu.cpp:63-96 : u16 mm -> f32 m ((float)((double)mm*0.001)) into raw_depth */
 int kf_upload_depth_mm(kf_ctx* ctx, const uint16_t* host_mm, uint32_t cols, uint32_t rows);
+/* the same copy AHEAD of its use (src/HybKinectfu.cpp:63-96 run early): the frame goes into a free upload slot and does not replace the current one;
+ * up to two frames may be staged (a third: KF_ERR_STATE), kf_take_next_depth makes the oldest of them the current frame (KF_ERR_STATE if none);
+ * kf_upload_depth_mm drops whatever is staged.  *dev_mm (may be NULL) = where the frame lies on the device, for kf_prefetch_frame: its front end
+ * then rides in its predecessor's launches.  Staging TWO ahead -- upload frame k+2 while frame k is processed and frame k+1 rides along -- takes
+ * the PCIe copy off the critical path: a host-fed stream then runs at the rate of one that is already in HBM (bench.py value_pcie_inclusive). */
+int kf_upload_depth_mm_next(kf_ctx* ctx, const uint16_t* host_mm, uint32_t cols, uint32_t rows, const uint16_t** dev_mm);
+int kf_take_next_depth(kf_ctx* ctx);
 int kf_set_depth_mm_device(kf_ctx* ctx, const uint16_t* dev_mm, uint32_t cols, uint32_t rows);   /* frame already in HBM */
 int kf_upload_rgb(kf_ctx* ctx, const uint8_t* host_bgr, uint32_t cols, uint32_t rows);
 

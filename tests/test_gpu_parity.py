@@ -397,6 +397,55 @@ def test_prefetched_preprocess_is_bit_identical():
         assert np.array_equal(outs[0][2][0], other[2][0]) and np.array_equal(outs[0][2][1], other[2][1])
 
 
+def test_host_stream_staged_two_ahead_equals_the_resident_stream():
+    """kf_upload_depth_mm_next / kf_take_next_depth (frames staged from HOST memory ahead of their use, their front ends riding in the previous
+    frame's launches -- SingleGpuPipeline.process_frame_host) change nothing: poses, maps and voxels equal the device-resident stream's bit for
+    bit, to the end of the stream (the last frames have nothing staged behind them), and after a restart in the middle (a frame id that does
+    not follow).  The staging states answer as include/hybkf.h says: a third staged frame and a take with nothing staged are KF_ERR_STATE."""
+    import torch
+    from hybkinectfu_amd.pipeline import SingleGpuPipeline
+    res, size, cam = 256, 3.0, S.vga_camera()
+    wl = dict(trunc_max=P["depth_trunc_max"], integ_dist=P["integrate_depth_trunc"])
+    n = 9
+    frames = np.stack([S.render_depth_mm(S.trajectory_pose(k, size), cam, size) for k in range(n)])
+    dev = torch.from_numpy(frames.astype(np.int16)).cuda()
+    fb = cam[0] * cam[1] * 2
+    outs = []
+    for mode in ("resident", "host", "host-restart"):
+        pipe = SingleGpuPipeline(K.camera(*cam), res, size, wl)
+        poses = []
+        for k in range(n):
+            if mode == "resident":
+                pipe.process_frame_device(dev.data_ptr() + k * fb, k, None)
+            else:
+                if mode == "host-restart" and k == 5:
+                    pipe._host = None                                     # what a seek in the stream does
+                pipe.process_frame_host(lambda j: frames[j] if j < n else None, k)
+            ok, pose, status, iters = pipe.track_result()
+            assert ok
+            poses.append(pose.copy())
+        pipe.sync()
+        maps = [pipe.ctx.download_map(m) for m in (K.MAP_RAW_DEPTH, K.MAP_FILTERED_DEPTH, K.MAP_NEW_VERTICES, K.MAP_MODEL_VERTICES, K.MAP_MODEL_NORMALS)]
+        outs.append((poses, maps, pipe.ctx.download_volume()))
+        if mode == "host":
+            c = pipe.ctx
+            with pytest.raises(K.KfError):
+                c.take_next_depth()                                       # the stream has ended: nothing is staged
+            c.upload_depth_mm_next(frames[0]); c.upload_depth_mm_next(frames[1])
+            with pytest.raises(K.KfError):
+                c.upload_depth_mm_next(frames[2])                         # two frames ahead is the limit
+            c.upload_depth_mm(frames[3])                                  # drops both
+            with pytest.raises(K.KfError):
+                c.take_next_depth()
+        pipe.close()
+    for other in outs[1:]:
+        for a, b in zip(outs[0][0], other[0]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        for a, b in zip(outs[0][1], other[1]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert np.array_equal(outs[0][2][0].view(np.uint32), other[2][0].view(np.uint32)) and np.array_equal(outs[0][2][1], other[2][1])
+
+
 def test_lost_frame_in_the_prefetched_stream_equals_the_plain_sequence():
     """The steady-state frame has no pyramid / set-up launch of its own (the pyramids ride in the previous raycast launch, the persistent loop
     writes its whole verdict itself): a frame the tracker LOSES in the middle of a prefetched stream, and the frames after it, must leave the
