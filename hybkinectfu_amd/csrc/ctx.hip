@@ -572,6 +572,7 @@ extern "C" int kf_resize_slab(kf_ctx* c, uint32_t z_begin, uint32_t z_end, uint3
   const uint32_t R = (uint32_t)v.res;
   if (z_begin >= z_end || z_end > R || (z_begin % KF_BRICK) || (z_end % KF_BRICK)) return KF_ERR_ARG;
   KF_CHECK(hipSetDevice(c->cfg.device));
+  { const int ds = kf_tail_cull_discard(c); if (ds) return ds; }   // (a cull that ran for the old slab)
   const int halo_b = (int)((halo + KF_BRICK - 1) / KF_BRICK);
   int nb0 = (int)(z_begin / KF_BRICK) - halo_b, nb1 = (int)(z_end / KF_BRICK) + halo_b;
   nb0 = nb0 < 0 ? 0 : nb0; nb1 = nb1 > v.nb ? v.nb : nb1;

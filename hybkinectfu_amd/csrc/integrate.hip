@@ -14,36 +14,9 @@
 #include "kf_internal.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <string.h>
 
-struct IntegrateArgs {
-  KfVolume vol;
-  KfCam dcam, rcam;
-  const float* depth;            // trunced_depth
-  const float4* normals;         // new_normals_pyramid[0]
-  const uchar4* rgb;             // raw_rgb
-  const float* tinv;             // device: world -> camera = Mat44::getInverse of the pose (integrateVolume.cu:84), kept next to the
-                                 // device-resident pose by whoever commits it (KfTrackState::pose_inv); null: tinv_val
-  KfMat tinv_val;                // the inverse of a host-supplied transform, computed on the host with the same arithmetic
-  float* tile_max;               // device: max of the depth gated by max_dist over 8-pixel and 16-pixel tiles (two tables, see tile_off)
-  int tile_off[2], tile_w[2], tile_h[2];   // offset / width / height of each level's table inside tile_max
-  int fine_tiles;                // 1: bricks are small on screen, the cull reads the 8-pixel table where the footprint allows
-  unsigned* queue;               // active brick slots
-  const unsigned* queue_pad;     // 16 aligned bytes nobody writes during the fusion pass (what non-updating lanes load)
-  unsigned queue_cap;            // entries the queue can hold (= stored bricks)
-  KfCounters* cnt;
-  const KfTrackState* track;     // non-null: integrate only when track->tracked
-  float sdf_trunc, max_dist;
-  int has_color, color_angled;
-  float fr_slope[4], fr_norm[4]; // frustum side planes through the eye (left, right, top, bottom), widened by one pixel: slope and sqrt(1+slope^2)
-  int exp_mode;                  // timing experiments only (KF_INTEGRATE_EXP): 1 = no store, 2 = no load/store
-  int parity;                    // which of the double-buffered counter sets (KfCounters) this call uses
-  int clear_tiles, n_tile_floats;   // the fusion pass clears the tile tables (maxima to 0, minima to +inf) once the cull has read them
-  int defer_cull;                // deferred-weight words are in use (k_integrate_pairs<.., DEFER>) and the tile minima describe this depth map: the cull may
-                                 // retire whole free-space bricks (counted, their pending counts bumped, never queued)
-  int free_ok;                   // sdf_trunc > 0 (and the shortcut not disabled): free-space waves skip the quotients (k_integrate_pairs)
-  unsigned long long* layer_work;   // non-null on sampled frames (kf_count_layer_work): voxels updated per BRICK LAYER of the whole volume, queued bricks only --
-                                    // what z-slab ranks balance their boundaries on (pipeline.SlabPipeline.rebalance)
-};
+#include "cull.h"                 // IntegrateArgs, the cull's test of a macro cell (shared with the tracking launch's tail)
 
 // Retire the OTHER parity's counters (nobody touches them during this launch) and clear the tile tables for the next frame's fused
 // preprocess kernel: run by workgroup 0 of the fusion pass, so a frame needs no bookkeeping launch.
@@ -53,7 +26,12 @@ __device__ __forceinline__ void integrate_maintenance(const IntegrateArgs& a) {
     a.cnt->upd_total_shard[threadIdx.x] += a.cnt->upd_shard[o][threadIdx.x * 16];
     a.cnt->upd_shard[o][threadIdx.x * 16] = 0ull;
   }
-  if (threadIdx.x == 0) a.cnt->n_active[o] = 0u;
+  if (threadIdx.x == 0) {
+    a.cnt->n_active[o] = 0u;
+    // one fusion pass = one frame fused, or one frame skipped because tracking failed (HybKinectfu.cpp:123): counted here, once per pass, so that the
+    // cull stays free of side effects other than the queue -- it may have run as the tail of the tracking launch (track.hip)
+    if (a.track && !a.track->tracked) a.cnt->frames_lost += 1; else a.cnt->frames_fused += 1;
+  }
   if (a.clear_tiles) for (int i = threadIdx.x; i < a.n_tile_floats; i += blockDim.x) { a.tile_max[i] = 0.f; a.tile_max[a.n_tile_floats + i] = __builtin_huge_valf(); }
 }
 
@@ -111,42 +89,13 @@ __global__ void __launch_bounds__(256) k_integrate_prepare(IntegrateArgs a) {
   }
 }
 
-// pass 1: one WAVE per 32^3-voxel macro cell (4x4x4 bricks = 64 lanes).  The wave first tests the macro cell's bounding
-// sphere against the depth range and the frustum (uniform: a culled macro cell costs a few scalar-ish instructions for 64
-// bricks), then each lane tests its own brick, and the survivors are appended with ONE atomic per wave.  All tests are
-// conservative: a brick is dropped only when no voxel of it can pass the reference's predicate.
-__device__ __forceinline__ bool cull_sphere_visible(const IntegrateArgs& a, const float* m, float cx, float cy, float cz, float r,
-                                                    float& px, float& py, float& pz) {
-  px = m[0] * cx + m[1] * cy + m[2] * cz + m[3];
-  py = m[4] * cx + m[5] * cy + m[6] * cz + m[7];
-  pz = m[8] * cx + m[9] * cy + m[10] * cz + m[11];
-  if (pz + r <= 0.f) return false;                                     // every voxel has pf.z <= 0
-  if (pz - r >= a.max_dist + a.sdf_trunc) return false;                // needs pf.z < depth + trunc < max_dist + trunc
-  if ((px - a.fr_slope[0] * pz) < -r * a.fr_norm[0]) return false;
-  if ((a.fr_slope[1] * pz - px) < -r * a.fr_norm[1]) return false;
-  if ((py - a.fr_slope[2] * pz) < -r * a.fr_norm[2]) return false;
-  if ((a.fr_slope[3] * pz - py) < -r * a.fr_norm[3]) return false;
-  return true;
-}
-
-// one more whole-quarter free-space observation of a quarter in a deferred state p >= 1 (k = p - 1 pending): p + 1, or KF_PEND_SAT once
-// k + 1 >= max_weight - 1 -- every stored weight is >= 1, so every true weight fminf(w + k + 1, max) has then reached max_weight
-__device__ __forceinline__ unsigned kf_pend_step(unsigned p, float max_weight) {
-  if (p >= KF_PEND_SAT) return KF_PEND_SAT;
-  const unsigned n = p + 1u;
-  return ((float)n >= max_weight || n >= KF_PEND_SAT) ? KF_PEND_SAT : n;
-}
-
+// pass 1 (cull.h: cull_test): one WAVE per 32^3-voxel macro cell, sixteen per workgroup, ONE queue atomic per workgroup
 #define CULL_WAVES 16
 // DEFER: the deferred-weight words are in use -> whole free-space bricks in a deferred state can be retired here (see below); a separate
 // instantiation because the extra test costs registers the plain cull needs for two workgroups per CU
 template <bool DEFER>
 __global__ void __launch_bounds__(CULL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) k_integrate_cull(IntegrateArgs a) {
-  if (a.track && !a.track->tracked) {                        // HybKinectfu.cpp:123: integrate only when tracking succeeded
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.cnt->frames_lost += 1;
-    return;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.cnt->frames_fused += 1;
+  if (a.track && !a.track->tracked) return;                  // HybKinectfu.cpp:123: integrate only when tracking succeeded (counted by the fusion pass: integrate_maintenance)
   __shared__ unsigned s_cnt[CULL_WAVES], s_noop[CULL_WAVES];
   __shared__ unsigned s_base;
   const KfVolume& v = a.vol;
@@ -158,95 +107,9 @@ __global__ void __launch_bounds__(CULL_WAVES * 64) __attribute__((amdgpu_waves_p
   // 112 registers, one workgroup per CU, and a block barrier pair per group: integrate stage 767 -> 801 / 817 / 889 us at 2, 4, 8 groups, 159 -> 177 us at
   // 1024^3, profiles/r04_deferred_weights.txt.)
   const int wave = blockIdx.x * CULL_WAVES + wid;
-  const int mx = wave % nmxy, my = (wave / nmxy) % nmxy, mz = wave / (nmxy * nmxy) + mz0;
-  const float* m = a.tinv ? a.tinv : a.tinv_val.m;
-  const float cell = v.cell;
-  float px, py, pz;
-  const int bx = mx * 4 + (lane & 3), by = my * 4 + ((lane >> 2) & 3), bz = mz * 4 + (lane >> 4);
-  // macro cell: voxel centres span [(32m+0.5), (32m+31.5)] * cell -> centre (32m+16)*cell, half-diagonal 15.5*sqrt(3)*cell
-  bool keep = wave < n_macro &&
-              cull_sphere_visible(a, m, (float)(mx * 32 + 16) * cell, (float)(my * 32 + 16) * cell, (float)(mz * 32 + 16) * cell,
-                                  27.0f * cell + 1e-4f * v.size, px, py, pz);
-  keep = keep && bx < v.nb && by < v.nb && bz >= v.bz0 && bz < v.bz1;
-  // brick: voxel centres span [(8b+0.5), (8b+7.5)] * cell per axis: an axis-aligned box of half-extent 3.5 cells around
-  // (8b+4)*cell.  Every test below is linear in the voxel position, so its extreme over the box is the value at the centre plus
-  // the box's support h * sum |coefficients| -- up to 42 % tighter than the bounding sphere for planes along the axes, which is
-  // what decides bricks on the frustum's sides and just behind a surface.
-  const float h = 3.5f * cell, eps = 1e-4f * v.size;
-  const float ex = h * (fabsf(m[0]) + fabsf(m[1]) + fabsf(m[2])) + eps, ey = h * (fabsf(m[4]) + fabsf(m[5]) + fabsf(m[6])) + eps;
-  const float ez = h * (fabsf(m[8]) + fabsf(m[9]) + fabsf(m[10])) + eps;
-  if (keep) {
-    const float cx = (float)(bx * 8 + 4) * cell, cy = (float)(by * 8 + 4) * cell, cz = (float)(bz * 8 + 4) * cell;
-    px = m[0] * cx + m[1] * cy + m[2] * cz + m[3];
-    py = m[4] * cx + m[5] * cy + m[6] * cz + m[7];
-    pz = m[8] * cx + m[9] * cy + m[10] * cz + m[11];
-    keep = pz + ez > 0.f && pz - ez < a.max_dist + a.sdf_trunc;         // some voxel with 0 < pf.z < max_dist + trunc
-    // frustum sides (through the eye, one pixel wider): inside means x - tl*z >= 0, tr*z - x >= 0, y - tt*z >= 0, tb*z - y >= 0
-    const float tl = a.fr_slope[0], tr = a.fr_slope[1], tt = a.fr_slope[2], tb = a.fr_slope[3];
-    const float sl = h * (fabsf(m[0] - tl * m[8]) + fabsf(m[1] - tl * m[9]) + fabsf(m[2] - tl * m[10])) + eps * a.fr_norm[0];
-    const float sr = h * (fabsf(tr * m[8] - m[0]) + fabsf(tr * m[9] - m[1]) + fabsf(tr * m[10] - m[2])) + eps * a.fr_norm[1];
-    const float st = h * (fabsf(m[4] - tt * m[8]) + fabsf(m[5] - tt * m[9]) + fabsf(m[6] - tt * m[10])) + eps * a.fr_norm[2];
-    const float sb = h * (fabsf(tb * m[8] - m[4]) + fabsf(tb * m[9] - m[5]) + fabsf(tb * m[10] - m[6])) + eps * a.fr_norm[3];
-    keep = keep && (px - tl * pz) + sl >= 0.f && (tr * pz - px) + sr >= 0.f && (py - tt * pz) + st >= 0.f && (tb * pz - py) + sb >= 0.f;
-  }
-  // depth test against the tile max over the brick's pixel footprint (only when the brick is clear of the eye plane)
-  const float zn = pz - ez, zf = pz + ez;
-  bool noop = false;                                                       // a brick retired here: its 512 voxels are counted, not visited
-  // DEFER: the brick's four deferred-weight words, requested before the depth tests so that they travel together with the tile maxima
-  // (behind them they were one more dependent round trip at the end of every surviving lane's chain)
-  const unsigned cull_slot = keep ? kf_brick_slot(v, bx, by, bz) : 0u;
-  const unsigned long long pp = DEFER ? v.pend[kf_opaque(cull_slot)] : 0ull;
-  if (keep && zn > 4.f * cell) {
-    const float xl = px - ex, xr = px + ex, yl = py - ey, yr = py + ey;
-    float u0 = (xl < 0.f ? xl / zn : xl / zf) * a.dcam.fx + a.dcam.cx, u1 = (xr > 0.f ? xr / zn : xr / zf) * a.dcam.fx + a.dcam.cx;
-    float w0 = (yl < 0.f ? yl / zn : yl / zf) * a.dcam.fy + a.dcam.cy, w1 = (yr > 0.f ? yr / zn : yr / zf) * a.dcam.fy + a.dcam.cy;
-    int ix0 = (int)floorf(u0) - 1, ix1 = (int)ceilf(u1) + 2, iy0 = (int)floorf(w0) - 1, iy1 = (int)ceilf(w1) + 2;
-    // every voxel's pixel lies in [ix0, ix1] x [iy0, iy1]: inside the reference's 1 .. cols-2 / rows-2 window (integrateVolume.cu:43)?
-    const bool all_inside = ix0 >= 1 && iy0 >= 1 && ix1 <= a.dcam.cols - 2 && iy1 <= a.dcam.rows - 2;
-    ix0 = max(ix0, 0); iy0 = max(iy0, 0); ix1 = min(ix1, a.dcam.cols - 1); iy1 = min(iy1, a.dcam.rows - 1);
-    if (ix0 > ix1 || iy0 > iy1) keep = false;
-    else {
-      // 8-pixel tiles when the footprint spans at most 4 x 4 of them (distant bricks: a far tighter maximum), else 16-pixel tiles
-      const int lvl = (!a.fine_tiles || ((ix1 >> 3) - (ix0 >> 3)) >= 4 || ((iy1 >> 3) - (iy0 >> 3)) >= 4) ? 1 : 0;
-      const int sh = 3 + lvl;
-      const int tx0 = ix0 >> sh, tx1 = ix1 >> sh, ty0 = iy0 >> sh, ty1 = iy1 >> sh;
-      if (tx1 - tx0 < 4 && ty1 - ty0 < 4) {
-        // sixteen independent clamped loads instead of a dependent loop
-        const float* tbl = a.tile_max + a.tile_off[lvl];
-        const int tw = a.tile_w[lvl];
-        float dmax = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) dmax = fmaxf(dmax, tbl[min(ty0 + j, ty1) * tw + min(tx0 + i, tx1)]);
-        if (dmax == 0.f) keep = false;                                     // no pixel under the brick can integrate
-        else if (zn >= dmax + a.sdf_trunc) keep = false;                   // every voxel lies behind every surface it can see
-        else if (DEFER && all_inside) {
-          // Free space in a deferred state seen as free space again: all four quarters of the brick carry a deferred-weight word (its 512
-          // voxels hold tsdf 1 and a weight >= 1), every voxel projects inside the image window, every pixel it can land on holds a depth that
-          // integrates (tile minimum > 0 means: all valid, all < max_dist) and that depth is at least one truncation distance behind the
-          // brick's far side -> every voxel passes the reference's predicate (:39-67), observes tsdf min(1, sdf / trunc) = 1, and
-          // (1 * w + 1) / (w + 1) = 1 leaves the tsdf as it is; the weight's min(w + 1, max) is one more pending step of each quarter
-          // (nothing at all once a quarter is saturated).  The brick is counted, not queued: no other wave touches it in this frame.
-          const unsigned slot = cull_slot;
-          const unsigned q0 = (unsigned)(pp & 0xFFFFull), q1 = (unsigned)((pp >> 16) & 0xFFFFull), q2 = (unsigned)((pp >> 32) & 0xFFFFull), q3 = (unsigned)(pp >> 48);
-          if (q0 && q1 && q2 && q3) {
-            const float* tmn = tbl + a.n_tile_floats;
-            float dmin = __builtin_huge_valf();
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) dmin = fminf(dmin, tmn[min(ty0 + j, ty1) * tw + min(tx0 + i, tx1)]);
-            if (dmin > 0.f && dmin - zf >= a.sdf_trunc + eps) {
-              keep = false; noop = true;
-              if (pp != ~0ull) v.pend[slot] = (unsigned long long)kf_pend_step(q0, v.max_weight) | ((unsigned long long)kf_pend_step(q1, v.max_weight) << 16) |
-                                              ((unsigned long long)kf_pend_step(q2, v.max_weight) << 32) | ((unsigned long long)kf_pend_step(q3, v.max_weight) << 48);
-            }
-          }
-        }
-      }                                                                    // larger footprints (bricks close to the eye) are kept
-    }
-  }
+  int bx, by, bz;
+  bool noop;
+  const bool keep = cull_test<DEFER>(a, a.tinv ? a.tinv : a.tinv_val.m, wave, lane, n_macro, nmxy, mz0, bx, by, bz, noop);
   // compaction: ONE atomic per 16 macro cells (an address takes ~11 ns per atomic; per-wave atomics made this pass
   // cost more than the fusion itself at 1024^3)
   const unsigned long long mask = __ballot(keep);
@@ -841,21 +704,15 @@ extern "C" int kf_set_defer(kf_ctx* c, int mode) {
   return 0;
 }
 
-extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weight_color, const kf_mat44* transform,
-                                   const kf_integrate_params* ip, const kf_camera_params* dcam, const kf_camera_params* rcam) {
-  if (!c || !ip || !dcam) return KF_ERR_ARG;
-  if ((int)dcam->cols != c->cols || (int)dcam->rows != c->rows) return KF_ERR_ARG;
-  if (has_color && (!c->vol.color || !c->raw_rgb || !rcam)) return KF_ERR_STATE;
-  IntegrateArgs a;
-  a.vol = c->vol; a.dcam = to_cam(dcam); a.rcam = rcam ? to_cam(rcam) : a.dcam;
-  a.depth = c->trunced_depth; a.normals = c->new_n[0]; a.rgb = c->raw_rgb;
+// What the cull reads of IntegrateArgs, for the context's current depth map and the device-resident pose (shared with the tracking launch's tail, track.hip)
+void kf_fill_cull_args(kf_ctx* c, IntegrateArgs& a, const kf_camera_params* dcam, float sdf_trunc, float max_dist) {
+  memset(&a, 0, sizeof(a));
+  a.vol = c->vol; a.dcam = to_cam(dcam); a.rcam = a.dcam;
+  a.depth = c->trunced_depth;
   a.tile_max = c->tile_max_depth; a.queue = c->active_bricks; a.cnt = c->counters;
   a.queue_cap = (unsigned)c->n_stored_bricks;
   a.queue_pad = c->active_bricks + ((c->n_stored_bricks + 3) & ~(size_t)3);     // 16-byte aligned spare words behind the queue (allocated in ctx.hip)
-  a.sdf_trunc = ip->sdf_truncation; a.max_dist = ip->max_integrate_dist;
-  a.has_color = has_color; a.color_angled = use_angle_weight_color;
-  { static int fs = -1; if (fs < 0) { const char* e = getenv("KF_INTEGRATE_FREESPACE"); fs = e ? atoi(e) : 1; }      // 0: always form the quotients (A/B)
-    a.free_ok = (fs && a.sdf_trunc > 0.f) ? 1 : 0; }
+  a.sdf_trunc = sdf_trunc; a.max_dist = max_dist;
   for (int l = 0, off = 0; l < 2; ++l) {
     a.tile_w[l] = kf_div_up(c->cols, 8 << l); a.tile_h[l] = kf_div_up(c->rows, 8 << l);
     a.tile_off[l] = off; off += a.tile_w[l] * a.tile_h[l];
@@ -866,6 +723,39 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   a.fr_slope[0] = (-1.f - a.dcam.cx) / a.dcam.fx; a.fr_slope[1] = ((float)a.dcam.cols - a.dcam.cx) / a.dcam.fx;
   a.fr_slope[2] = (-1.f - a.dcam.cy) / a.dcam.fy; a.fr_slope[3] = ((float)a.dcam.rows - a.dcam.cy) / a.dcam.fy;
   for (int i = 0; i < 4; ++i) a.fr_norm[i] = sqrtf(1.f + a.fr_slope[i] * a.fr_slope[i]);
+  a.tinv = c->track->pose_inv; a.track = c->track;       // kept current by whoever commits the device-resident pose
+  a.parity = c->int_parity;
+  a.n_tile_floats = c->n_tile_floats;
+}
+bool kf_cull_tail_fits(const kf_ctx* c, int n_wg, int waves) {
+  const int nmxy = (c->vol.nb + 3) >> 2, nmz = ((c->vol.bz1 + 3) >> 2) - (c->vol.bz0 >> 2);
+  return (long long)nmxy * nmxy * nmz <= (long long)n_wg * waves * CULL_TAIL_ROUNDS;
+}
+extern "C" int kf_cull_tail_counts(kf_ctx* c, uint32_t* consumed, uint32_t* undone) {
+  if (!c) return KF_ERR_ARG;
+  if (consumed) *consumed = c->tail_cull.consumed;
+  if (undone) *undone = c->tail_cull.undone;
+  return 0;
+}
+int kf_tail_cull_discard(kf_ctx* c) {
+  if (!c->tail_cull.armed) return 0;
+  c->tail_cull.armed = 0; c->tail_cull.undone++;
+  KF_CHECK(hipMemsetAsync(&c->counters->n_active[c->tail_cull.parity], 0, sizeof(unsigned), c->stream));
+  return 0;
+}
+
+extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weight_color, const kf_mat44* transform,
+                                   const kf_integrate_params* ip, const kf_camera_params* dcam, const kf_camera_params* rcam) {
+  if (!c || !ip || !dcam) return KF_ERR_ARG;
+  if ((int)dcam->cols != c->cols || (int)dcam->rows != c->rows) return KF_ERR_ARG;
+  if (has_color && (!c->vol.color || !c->raw_rgb || !rcam)) return KF_ERR_STATE;
+  IntegrateArgs a;
+  kf_fill_cull_args(c, a, dcam, ip->sdf_truncation, ip->max_integrate_dist);
+  a.rcam = rcam ? to_cam(rcam) : a.dcam;
+  a.normals = c->new_n[0]; a.rgb = c->raw_rgb;
+  a.has_color = has_color; a.color_angled = use_angle_weight_color;
+  { static int fs = -1; if (fs < 0) { const char* e = getenv("KF_INTEGRATE_FREESPACE"); fs = e ? atoi(e) : 1; }      // 0: always form the quotients (A/B)
+    a.free_ok = (fs && a.sdf_trunc > 0.f) ? 1 : 0; }
   { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_INTEGRATE_EXP"); a.exp_mode = em; }
   if (transform) {
     kf_mat44_inverse(transform->m, a.tinv_val.m);        // integrateVolume.cu:84, same arithmetic as on the device
@@ -891,7 +781,19 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   c->fuse_max_dist = a.max_dist;                         // what the next preprocess builds the tables for
   c->tile_serial = 0; c->tiles_clear = 1;                // the fusion pass below clears the tables behind the cull
   c->fp_tiles = 0;                                       // (tables a raycast launch may have built for a prefetched frame are cleared with them)
-  {
+  // The cull may have run already, as the tail of this frame's tracking launch (kf_icp_track, persistent loop): consumed when it saw what this call
+  // would have shown it -- the device-resident pose, the same parameters, depth map, tile tables, slab and counter set; otherwise undone.
+  bool culled = false;
+  if (c->tail_cull.armed) {
+    const auto& t = c->tail_cull;
+    culled = !transform && !defer && tiles_ready && t.parity == a.parity && t.sdf_trunc == a.sdf_trunc && t.max_dist == a.max_dist &&
+             memcmp(&t.dcam, dcam, sizeof(*dcam)) == 0 && t.trunc_serial == c->trunc_serial && t.bz0 == c->vol.bz0 && t.bz1 == c->vol.bz1;
+    if (culled) { c->tail_cull.armed = 0; c->tail_cull.consumed++; }
+    else { const int ds = kf_tail_cull_discard(c); if (ds) return ds; }
+  }
+  c->cull_hint.valid = transform ? 0 : 1;                // what the next tracking launch may cull for
+  c->cull_hint.sdf_trunc = a.sdf_trunc; c->cull_hint.max_dist = a.max_dist; c->cull_hint.dcam = *dcam;
+  if (!culled) {
     const int nmxy = (c->vol.nb + 3) >> 2, nmz = ((c->vol.bz1 + 3) >> 2) - (c->vol.bz0 >> 2);
     const unsigned n_macro = (unsigned)nmxy * nmxy * nmz;                      // one wave per macro cell, sixteen per workgroup
     const unsigned cgrid = (n_macro + CULL_WAVES - 1) / CULL_WAVES;

@@ -196,6 +196,11 @@ struct kf_ctx {
   unsigned long long trunc_serial, tile_serial;   // bumped by every writer of trunced_depth / copied when the tables are built
   float tile_built_dist, fuse_max_dist;
   int tiles_clear, int_parity, last_parity;
+  // The cull as the tail of the tracking launch (track.hip / cull.h): kf_integrate_volume(transform == NULL) leaves its parameters behind as a hint,
+  // the next kf_icp_track that runs the persistent loop arms the tail with them, the next kf_integrate_volume consumes it (same parameters, same depth
+  // map, same slab) or undoes it (kf_tail_cull_discard: the queue counter of that parity back to zero) and culls in a launch of its own.
+  struct { int valid; float sdf_trunc, max_dist; kf_camera_params dcam; } cull_hint;
+  struct { int armed, parity, bz0, bz1; float sdf_trunc, max_dist; kf_camera_params dcam; unsigned long long trunc_serial; unsigned consumed, undone; } tail_cull;
   kf_triangle* triangles; uint32_t max_triangles;
   unsigned* mc_block_counts; size_t mc_blocks_cap;
   unsigned* mc_list; unsigned* mc_nbr_bits; unsigned* mc_partials;   // extraction scratch, allocated by the first kf_marching_cubes
@@ -559,4 +564,5 @@ int kf_live_contexts(int device);
 int kf_device_shared(int device);
 int kf_materialize_raw_depth(kf_ctx* ctx);
 int kf_pending_depth_consumed(kf_ctx* ctx);
+int kf_tail_cull_discard(kf_ctx* ctx);   // a cull that ran as the tail of a tracking launch and will not be consumed: its queue counter back to zero
 int kf_upload_wait_for(kf_ctx* ctx, const uint16_t* dev_mm);   // dev_mm is about to be read on the context's stream: wait for its staged copy, if it is one

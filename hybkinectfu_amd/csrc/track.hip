@@ -21,6 +21,7 @@
 // Sums are fp32 in a fixed (reproducible) association that differs from the reference's tree, so parity for this stage is
 // by tolerance (pose within 1e-4 m / 1e-4 rad), as SURVEY.md section 8a row a6 states.
 #include "kf_internal.h"
+#include "cull.h"
 #include "bilateral_tile.h"
 #include <string.h>
 #include <stdlib.h>
@@ -625,6 +626,11 @@ struct IcpLoopArgs {
   int n_virtual;                                 // workgroups the pixel dealing is defined for (= the workgroups level 0 needs at ICP_PX pixels per lane, what the per-step form
                                                  // launches): n_loop in k_icp_loop; larger in k_icp_loop_batched, whose n_loop resident workgroups each play several of them
   KfBilateralArgs bil; int bil_gx, bil_tiles, bil_fast;
+  // The fusion pass's brick cull as the TAIL of this launch (cull.h): it needs nothing but the committed pose, which every workgroup of the loop holds
+  // once the last step is applied -- so k_integrate_cull and one kernel boundary leave the stream (k_icp_loop only; the host arms it when the previous
+  // kf_integrate_volume left its parameters behind and the volume is small enough: kf_icp_track).
+  int cull_on;
+  IntegrateArgs cull;
 };
 
 // A workgroup gives up waiting for the others' partial sums after ICP_WAIT_LIMIT ticks of the 100 MHz wall clock (s_memrealtime) = 20 ms -- a
@@ -788,8 +794,14 @@ __device__ __forceinline__ void icp_solo_finish(const IcpLoopArgs& L, float (*s_
   }
   if (code != STEP_APPLIED) { if (threadIdx.x == 0) { st->status = code; st->tracked = 0; st->iterations = applied; st->converged = 0; st->rescued = 1; } return; }
   if (threadIdx.x < 16) st->pose[threadIdx.x] = s_cur[threadIdx.x];
-  if (threadIdx.x == 64) kf_mat44_inverse(s_cur, st->pose_inv);
   if (threadIdx.x == 0) { st->status = KF_TRACK_OK; st->tracked = 1; st->iterations = applied + 1; st->converged = 0; st->rescued = 1; }
+  __shared__ float s_tinv[16];
+  __shared__ unsigned s_cull[17];
+  if (threadIdx.x == 64) kf_mat44_inverse(s_cur, s_tinv);
+  __syncthreads();
+  if (threadIdx.x < 16) st->pose_inv[threadIdx.x] = s_tinv[threadIdx.x];
+  if (L.cull_on)                                                               // the launch's tail (cull.h), every workgroup's share in turn: nobody else is left
+    for (int w = 0; w < L.n_loop; ++w) cull_tail(L.cull, s_tinv, w, L.n_loop, s_cull);
 }
 // a fold of the loop timed out (uniform: every lane of the workgroup is here): claim the launch or leave
 #define ICP_ON_ABORT() do { \
@@ -960,12 +972,20 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   if (timed_out || s_abort) ICP_ON_ABORT();
   s_code = apply_step(a, s_tot, s_cur, nullptr, s_pose[cur_buf ^ 1]);
   if (s_code == STEP_APPLIED) { cur_buf ^= 1; s_cur = s_pose[cur_buf]; }
-  if (blockIdx.x != 0) return;
-  if (threadIdx.x < 27 && KF_EXP_MODE(L) != 7) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
-  if (s_code != STEP_APPLIED) { if (threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; st->converged = 0; st->rescued = 0; } return; }
-  if (threadIdx.x < 16) st->pose[threadIdx.x] = s_cur[threadIdx.x];
-  if (threadIdx.x == 64) kf_mat44_inverse(s_cur, st->pose_inv);               // a lane of another wave: the integrate pass reads it (integrateVolume.cu:84)
-  if (threadIdx.x == 0) { st->status = KF_TRACK_OK; st->tracked = 1; st->iterations = applied + 1; st->converged = 0; st->rescued = 0; }    // (the whole verdict: this launch may have run without k_track_begin's reset)
+  const bool tail = L.cull_on && s_code == STEP_APPLIED;                       // (uniform over the launch: every workgroup arrives at the same verdict)
+  if (blockIdx.x != 0 && !tail) return;
+  __shared__ float s_tinv[16];
+  __shared__ unsigned s_cull[17];
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 27 && KF_EXP_MODE(L) != 7) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
+    if (s_code != STEP_APPLIED) { if (threadIdx.x == 0) { st->status = s_code; st->tracked = 0; st->iterations = applied; st->converged = 0; st->rescued = 0; } return; }
+    if (threadIdx.x < 16) st->pose[threadIdx.x] = s_cur[threadIdx.x];
+    if (threadIdx.x == 0) { st->status = KF_TRACK_OK; st->tracked = 1; st->iterations = applied + 1; st->converged = 0; st->rescued = 0; }    // (the whole verdict: this launch may have run without k_track_begin's reset)
+  }
+  if (threadIdx.x == 64) kf_mat44_inverse(s_cur, s_tinv);                      // a lane of another wave: world -> camera (integrateVolume.cu:84), for the fusion pass and the tail
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < 16) st->pose_inv[threadIdx.x] = s_tinv[threadIdx.x];
+  if (tail) cull_tail(L.cull, s_tinv, (int)blockIdx.x, L.n_loop, s_cull);      // every workgroup holds the same pose bits, hence the same inverse
 }
 
 
@@ -1179,6 +1199,7 @@ static inline int icp_grid(int npx) { return kf_div_up(npx, ICP_THREADS * ICP_PX
 
 extern "C" int kf_set_pose(kf_ctx* c, const kf_mat44* pose) {
   if (!c || !pose) return KF_ERR_ARG;
+  { const int ds = kf_tail_cull_discard(c); if (ds) return ds; }   // (a cull that ran for the tracked pose does not describe this one)
   memcpy(c->host_pinned, pose->m, 64);
   const int one = 1;
   memcpy((char*)c->host_pinned + 64, &one, sizeof(one));
@@ -1248,6 +1269,7 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   if (!c || !icp || !cam0) return KF_ERR_ARG;
   if ((int)icp->pyramid_levels != c->levels || (int)cam0->cols != c->cols || (int)cam0->rows != c->rows) return KF_ERR_ARG;
   c->last_track_form = 0;
+  { const int ds = kf_tail_cull_discard(c); if (ds) return ds; }   // (a tail cull of the previous frame that no kf_integrate_volume consumed)
   if (frame_id == 0) {                                       // ICP.cpp:52-55
     hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, 0, c->grid_barrier);
     return (int)hipGetLastError();
@@ -1329,6 +1351,20 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
       n_riders = (unsigned)((L.bil_tiles + 1) / 2);
       c->fp_filtered = 1;
     }
+    // The fusion pass's cull as the tail of this launch: the previous kf_integrate_volume(transform == NULL) left its parameters behind, the tile
+    // tables describe THIS frame's depth map, no deferred-weight words (their cull retires bricks: side effects nobody could undo) and few enough
+    // macro cells for the loop's workgroups.  kf_integrate_volume consumes it, or undoes it when it is asked for something else.
+    static int tail_env = -1;
+    if (tail_env < 0) { const char* e = getenv("KF_CULL_IN_TRACK"); tail_env = e ? atoi(e) : 1; }
+    if (tail_env && !batched && !coop_env && L.exp_mode == 0 && c->cull_hint.valid && !kf_defer_enabled(c) &&
+        c->tile_serial != 0 && c->tile_serial == c->trunc_serial && c->tile_built_dist == c->cull_hint.max_dist &&
+        memcmp(&c->cull_hint.dcam, cam0, sizeof(*cam0)) == 0 && kf_cull_tail_fits(c, grid0, ICP_THREADS / 64)) {
+      kf_fill_cull_args(c, L.cull, &c->cull_hint.dcam, c->cull_hint.sdf_trunc, c->cull_hint.max_dist);
+      L.cull_on = 1;
+      c->tail_cull.armed = 1; c->tail_cull.parity = L.cull.parity; c->tail_cull.bz0 = c->vol.bz0; c->tail_cull.bz1 = c->vol.bz1;
+      c->tail_cull.sdf_trunc = c->cull_hint.sdf_trunc; c->tail_cull.max_dist = c->cull_hint.max_dist; c->tail_cull.dcam = c->cull_hint.dcam;
+      c->tail_cull.trunc_serial = c->trunc_serial;
+    }
     if (coop_env) {
       // a cooperative launch: the runtime itself checks that the whole grid can be resident and refuses otherwise
       void* params[] = {(void*)&L};
@@ -1374,6 +1410,7 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
 // kf_icp_partition_finish) consumes it.  Every rank applies the identical all-reduced system, so the poses agree bitwise.
 extern "C" int kf_icp_partition_begin(kf_ctx* c, uint32_t frame_id) {
   if (!c) return KF_ERR_ARG;
+  { const int ds = kf_tail_cull_discard(c); if (ds) return ds; }
   if (frame_id != 0) kf_evt_begin(c, KF_STAGE_TRACK);       // (the stage timer runs from here to kf_icp_partition_finish: it includes the caller's all-reduces)
   return kf_launch_pyramids_and_begin(c, frame_id == 0 ? 0 : 1);
 }
@@ -1434,6 +1471,7 @@ extern "C" int kf_sdf_track(kf_ctx* c, uint32_t frame_id, const kf_sdf_tracker_p
   if (!c || !sp || !cam) return KF_ERR_ARG;
   if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
   c->last_track_form = 0;
+  { const int ds = kf_tail_cull_discard(c); if (ds) return ds; }
   if (frame_id == 0) {                                       // SDF.cpp:46-49
     hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, 0, c->grid_barrier);
     return (int)hipGetLastError();
@@ -1466,6 +1504,7 @@ extern "C" int kf_sdf_track(kf_ctx* c, uint32_t frame_id, const kf_sdf_tracker_p
 // once), so every rank makes the same collective calls.
 extern "C" int kf_sdf_partition_begin(kf_ctx* c, uint32_t frame_id) {
   if (!c) return KF_ERR_ARG;
+  { const int ds = kf_tail_cull_discard(c); if (ds) return ds; }
   c->last_track_form = 0;
   if (frame_id != 0) kf_evt_begin(c, KF_STAGE_TRACK);       // (ends in kf_sdf_partition_finish: the caller's all-reduces are inside)
   hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, frame_id == 0 ? 0 : 1, c->grid_barrier);

@@ -87,7 +87,7 @@ SYMBOLS = [
     "kf_icp_partition_begin", "kf_icp_partition_steps", "kf_icp_partition_step", "kf_icp_partition_finish",
     "kf_sdf_partition_begin", "kf_sdf_partition_step", "kf_sdf_partition_finish", "kf_set_defer", "kf_inject_track_stall",
     "kf_download_volume_device", "kf_upload_volume_device", "kf_resize_slab", "kf_count_layer_work", "kf_read_layer_work",
-    "kf_upload_depth_mm_next", "kf_take_next_depth",
+    "kf_upload_depth_mm_next", "kf_take_next_depth", "kf_cull_tail_counts",
 ]
 
 
@@ -308,6 +308,12 @@ class Context:
     def inject_track_stall(self, launches=1):
         """fault injection: the next `launches` persistent-loop launches run with one workgroup playing dead (the frame is finished solo)"""
         _chk(self.lib.kf_inject_track_stall(self.h, int(launches)), "kf_inject_track_stall")
+
+    def cull_tail_counts(self):
+        """(consumed, undone): culls that ran as the tail of a tracking launch and were used by / discarded before the fusion pass"""
+        a, b = C.c_uint32(), C.c_uint32()
+        _chk(self.lib.kf_cull_tail_counts(self.h, C.byref(a), C.byref(b)), "kf_cull_tail_counts")
+        return a.value, b.value
 
     def track_result(self):
         r = TrackResult()

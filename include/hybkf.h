@@ -169,9 +169,15 @@ int kf_wait_track_result(kf_ctx* ctx, kf_track_result* out);
  * workgroup that exits at once, as if a foreign process had kept it off the chip.  The others time out after 20 ms and one of them finishes
  * the frame's Gauss-Newton loop alone: same pose bits, launch_form 3, no frame lost. */
 int kf_inject_track_stall(kf_ctx* ctx, int launches);
+/* diagnostics: culls that ran as the tail of a tracking launch and were consumed by kf_integrate_volume / were undone (see kf_integrate_volume) */
+int kf_cull_tail_counts(kf_ctx* ctx, uint32_t* consumed, uint32_t* undone);
 
 /* cudaIntegrateVolume  src/cuda/integrateVolume.cu:78-96.  transform == NULL: use the device-resident pose and
- * integrate only if the last kf_*_track call tracked (src/HybKinectfu.cpp:123-140). */
+ * integrate only if the last kf_*_track call tracked (src/HybKinectfu.cpp:123-140).
+ * Three launches per streamed frame: after a call with transform == NULL the next kf_icp_track (persistent loop, volumes without deferred weights
+ * and of at most ~6400 macro cells of 32^3 voxels) runs this call's brick cull as the tail of its own launch, for the parameters seen here; the
+ * kf_integrate_volume that follows consumes it when it asks for exactly that (pose on the device, same parameters, depth map, slab) and
+ * otherwise undoes it and culls in a launch of its own -- the result never depends on it.  kf_cull_tail_counts: how often either happened. */
 int kf_integrate_volume(kf_ctx* ctx, int has_color, int use_angle_weight_color, const kf_mat44* transform,
                         const kf_integrate_params* integrate_params, const kf_camera_params* depth_camera,
                         const kf_camera_params* rgb_camera);

@@ -176,7 +176,7 @@ def test_a_timed_out_loop_in_the_streamed_pipeline_loses_no_frame():
     frames, _ = S.make_stream(n, cam, size)
     dev = torch.from_numpy(frames.astype(np.int16)).cuda()
     fb = cam[0] * cam[1] * 2
-    poses, forms = [], []
+    poses, forms, vols = [], [], []
     for inject_at in (None, 4):
         pipe = SingleGpuPipeline(K.camera(*cam), res, size, dict(trunc_max=P["depth_trunc_max"], integ_dist=P["integrate_depth_trunc"]))
         out, fo = [], []
@@ -189,8 +189,69 @@ def test_a_timed_out_loop_in_the_streamed_pipeline_loses_no_frame():
             out.append(pose); fo.append(pipe.ctx.last_form)
         st = pipe.stats()
         assert st["frames_lost"] == 0 and st["frames_fused"] == n
-        poses.append(out); forms.append(fo)
+        # (the fusion pass's cull ran as the tail of the loop launches -- also of the one that was finished by a single workgroup)
+        consumed, undone = pipe.ctx.cull_tail_counts()
+        assert undone == 0 and consumed >= (n - 1 if inject_at is None else 2), (consumed, undone)
+        poses.append(out); forms.append(fo); vols.append((pipe.ctx.download_volume(), st["updated_total"]))
         pipe.close()
     assert forms[1][4] == 3 and forms[1][5] == 2 and forms[0][4] == 1
     for a, b in zip(*poses):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    (va, ua), (vb, ub) = vols
+    assert ua == ub and np.array_equal(va[0].view(np.uint32), vb[0].view(np.uint32)) and np.array_equal(va[1], vb[1])
+
+
+def test_the_cull_in_the_tracking_launch_equals_the_cull_launch():
+    """Three launches per streamed frame: the persistent loop's workgroups run the fusion pass's brick cull as their tail once the pose is committed
+    (cull.h), kf_integrate_volume consumes it.  Three runs of one stream fuse the same voxels frame by frame (poses, queue lengths, update counts,
+    voxel bits): every tail consumed; tails undone along the way (the caller supplies the pose itself, sets the pose in between, asks for another
+    integration distance); no tail at all (a second live context: one launch per Gauss-Newton step, cull in a launch of its own)."""
+    import torch
+    from hybkinectfu_amd.pipeline import SingleGpuPipeline
+    cam, res, size = S.vga_camera(), 256, 3.0
+    n = 9
+    frames, _ = S.make_stream(n, cam, size)
+    dev = torch.from_numpy(frames.astype(np.int16)).cuda()
+    fb = cam[0] * cam[1] * 2
+    wl = dict(trunc_max=P["depth_trunc_max"], integ_dist=P["integrate_depth_trunc"])
+    runs = {}
+    for mode in ("tails", "mixed", "no-tails"):
+        other = K.Context(K.camera(64, 48, 31.5, 23.5, 52.5, 52.5), 32, 3.0, levels=3) if mode == "no-tails" else None
+        pipe = SingleGpuPipeline(K.camera(*cam), res, size, wl)
+        c = pipe.ctx
+        log = []
+        for k in range(n):
+            c.set_depth_mm_device(dev.data_ptr() + k * fb)
+            c.preprocess(P["depth_trunc_min"], pipe.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
+            if k + 1 < n:
+                c.prefetch_frame(dev.data_ptr() + (k + 1) * fb, P["depth_trunc_min"], pipe.trunc_max, P["filter_sigma_pixel"], P["filter_sigma_depth"])
+            c.icp_track(k, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+            ok, pose, status, iters = pipe.track_result()
+            assert ok
+            dist = pipe.integ_dist * (0.5 if (k == n - 1 and mode != "tails") else 1.0)   # the last frame of two runs: not what the tail culled for
+            if mode == "mixed" and k == 2:
+                c.integrate(pose, P["integrate_sdf_trunc"], dist)                        # the caller's own copy of the pose: the tail is undone, the cull runs again
+            elif mode == "mixed" and k == 4:
+                c.set_pose(pose)                                                          # (the same pose: the tail is void all the same)
+                c.integrate(None, P["integrate_sdf_trunc"], dist)
+            else:
+                c.integrate(None, P["integrate_sdf_trunc"], dist)
+            st = c.stats()
+            log.append((pose.copy(), st["bricks_active"], st["updated_last"]))
+            c.raycast(None, pipe.inc, P["depth_trunc_min"], pipe.trunc_max)
+        pipe.sync()
+        runs[mode] = (log, c.download_volume(), c.stats()["updated_total"], c.cull_tail_counts(), c.stats()["frames_fused"])
+        pipe.close()
+        if other is not None:
+            other.close()
+    assert runs["tails"][3] == (n - 1, 0)                         # (frame 0 has no tracking launch; its fusion pass leaves the first hint)
+    assert runs["mixed"][3] == (n - 1 - 4, 3)                     # (three undone; and no tail in the frame after the caller's own pose: no hint)
+    assert runs["no-tails"][3] == (0, 0)
+    for mode in ("mixed", "no-tails"):
+        last = n if mode == "no-tails" else n - 1                  # "tails" fused its last frame with the full distance
+        for k in range(last):
+            ra, rb = runs["mixed" if mode == "no-tails" else "tails"][0][k], runs[mode][0][k]
+            assert np.array_equal(ra[0].view(np.uint32), rb[0].view(np.uint32)) and ra[1:] == rb[1:], (mode, k, ra[1:], rb[1:])
+    (_, va, ua, _, fa), (_, vb, ub, _, fb_) = runs["mixed"], runs["no-tails"]
+    assert ua == ub and fa == fb_ == n and np.array_equal(va[0].view(np.uint32), vb[0].view(np.uint32)) and np.array_equal(va[1], vb[1])
+    assert runs["tails"][0][5][2] > 100000 and runs["mixed"][0][n - 1][2] < runs["tails"][0][n - 1][2]
