@@ -64,15 +64,14 @@ __device__ __forceinline__ unsigned kf_pend_step(unsigned p, float max_weight) {
 // the brick was retired here (counted by the caller, its pending counts bumped here).  m = the world -> camera transform (a uniform pointer: kernel
 // arguments, global memory or LDS).  Shared by k_integrate_cull (integrate.hip) and the cull that runs as the tail of the tracking launch (track.hip).
 template <bool DEFER>
-__device__ __forceinline__ bool cull_test(const IntegrateArgs& a, const float* __restrict__ m, int wave, int lane, int n_macro, int nmxy, int mz0,
-                                          int& bx_out, int& by_out, int& bz_out, bool& noop_out) {
+__device__ __forceinline__ bool cull_test_cell(const IntegrateArgs& a, const float* __restrict__ m, int mx, int my, int mz, bool cell_exists, int lane,
+                                               int& bx_out, int& by_out, int& bz_out, bool& noop_out) {
   const KfVolume& v = a.vol;
-  const int mx = wave % nmxy, my = (wave / nmxy) % nmxy, mz = wave / (nmxy * nmxy) + mz0;
   const float cell = v.cell;
   float px, py, pz;
   const int bx = mx * 4 + (lane & 3), by = my * 4 + ((lane >> 2) & 3), bz = mz * 4 + (lane >> 4);
   // macro cell: voxel centres span [(32m+0.5), (32m+31.5)] * cell -> centre (32m+16)*cell, half-diagonal 15.5*sqrt(3)*cell
-  bool keep = wave < n_macro &&
+  bool keep = cell_exists &&
               cull_sphere_visible(a, m, (float)(mx * 32 + 16) * cell, (float)(my * 32 + 16) * cell, (float)(mz * 32 + 16) * cell,
                                   27.0f * cell + 1e-4f * v.size, px, py, pz);
   keep = keep && bx < v.nb && by < v.nb && bz >= v.bz0 && bz < v.bz1;
@@ -157,6 +156,13 @@ __device__ __forceinline__ bool cull_test(const IntegrateArgs& a, const float* _
   }
   bx_out = bx; by_out = by; bz_out = bz; noop_out = noop;
   return keep;
+}
+
+// the same for macro cell number `wave` of the stored volume, counted x-fastest from macro layer mz0 (n_macro cells in all)
+template <bool DEFER>
+__device__ __forceinline__ bool cull_test(const IntegrateArgs& a, const float* __restrict__ m, int wave, int lane, int n_macro, int nmxy, int mz0,
+                                          int& bx_out, int& by_out, int& bz_out, bool& noop_out) {
+  return cull_test_cell<DEFER>(a, m, wave % nmxy, (wave / nmxy) % nmxy, wave / (nmxy * nmxy) + mz0, wave < n_macro, lane, bx_out, by_out, bz_out, noop_out);
 }
 
 // ---- the cull as the TAIL of another launch (the persistent ICP loop, track.hip) -------------------------------------------------------------------

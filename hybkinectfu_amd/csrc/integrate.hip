@@ -130,6 +130,78 @@ __global__ void __launch_bounds__(CULL_WAVES * 64) __attribute__((amdgpu_waves_p
   }
 }
 
+// pass 1 for the LARGEST volumes (2048^3: 262 144 macro cells, of which the frustum meets a few per cent).  k_integrate_cull spends a wave, and a share of a
+// workgroup's start-up chain, on every macro cell just to fail its sphere test.  Here a workgroup SIFTS 64 macro cells first, one per lane -- cells dealt
+// round robin over the workgroups, so each sees the same mix of visible and invisible space -- and only the cells whose bounding sphere meets the frustum and
+// the depth range get a wave's brick tests (cull_test_cell, two cells in flight per wave).  Survivors are staged in LDS and leave with ONE queue atomic per
+// workgroup.  The same conservative tests as k_integrate_cull, hence the same survivors (in another order).  Measured (profiles/r04_cull_forms.txt): the
+// cull's time is mostly the brick tests of the VISIBLE cells, which want every wave the chip has -- 2048^3 198 -> 138 us, but 1024^3 (40 % of the cells
+// visible) 25 -> 33 us, so only volumes of >= 100 000 macro cells take this form; one workgroup per 128^3 super cell that leaves at once when its sphere fails
+// was measured too (1024^3 25 -> 45 us: the visible workgroups walk 64 cells each on a fifth of the chip).
+#define SIFT_THREADS 256
+#ifndef SIFT_CELLS
+#define SIFT_CELLS 64                                       // macro cells sifted per workgroup (one per lane of its first waves)
+#endif
+#define SIFT_STAGE (SIFT_CELLS * 64)                        // staged survivors per workgroup: every brick of every sifted cell fits (16 KiB)
+template <bool DEFER>
+__global__ void __launch_bounds__(SIFT_THREADS) k_integrate_cull_sift(IntegrateArgs a, int n_wg) {
+  if (a.track && !a.track->tracked) return;
+  __shared__ unsigned s_vis[SIFT_CELLS], s_stage[SIFT_STAGE];
+  __shared__ unsigned s_nvis, s_nkept, s_base;
+  const KfVolume& v = a.vol;
+  const int nmxy = (v.nb + 3) >> 2, mz0 = v.bz0 >> 2, mz1 = (v.bz1 + 3) >> 2;
+  const int n_macro = nmxy * nmxy * (mz1 - mz0);
+  const float* m = a.tinv ? a.tinv : a.tinv_val.m;
+  const float cell = v.cell;
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) { s_nvis = 0u; s_nkept = 0u; }
+  __syncthreads();
+  {
+    const int i = (int)threadIdx.x * n_wg + (int)blockIdx.x;               // this lane's macro cell
+    bool vis = false;
+    if ((int)threadIdx.x < SIFT_CELLS && i < n_macro) {
+      const int mx = i % nmxy, my = (i / nmxy) % nmxy, mz = i / (nmxy * nmxy) + mz0;
+      float px, py, pz;
+      vis = cull_sphere_visible(a, m, (float)(mx * 32 + 16) * cell, (float)(my * 32 + 16) * cell, (float)(mz * 32 + 16) * cell, 27.0f * cell + 1e-4f * v.size, px, py, pz);
+    }
+    const unsigned long long vm = __ballot(vis);
+    unsigned base = 0;
+    if (lane == 0 && vm) base = atomicAdd(&s_nvis, (unsigned)__popcll(vm));
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if (vis) s_vis[base + (unsigned)__popcll(vm & ((1ull << lane) - 1ull))] = (unsigned)i;
+  }
+  __syncthreads();
+  const unsigned nvis = s_nvis;
+  unsigned retired = 0;
+  for (unsigned k0 = (unsigned)wid * 2u; k0 < nvis; k0 += (SIFT_THREADS / 64) * 2u) {
+    unsigned packed[2]; unsigned long long mask[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const bool have = k0 + u < nvis;
+      const int i = have ? (int)s_vis[k0 + u] : 0;
+      int bx, by, bz; bool noop;
+      const bool keep = cull_test_cell<DEFER>(a, m, i % nmxy, (i / nmxy) % nmxy, i / (nmxy * nmxy) + mz0, have, lane, bx, by, bz, noop);
+      packed[u] = (unsigned)bx | ((unsigned)by << 10) | ((unsigned)(bz - v.bz0) << 20);
+      mask[u] = __ballot(keep);
+      if (DEFER) retired += (unsigned)__popcll(__ballot(noop));
+    }
+    const unsigned n0 = (unsigned)__popcll(mask[0]), n1 = (unsigned)__popcll(mask[1]);
+    if (n0 + n1) {
+      unsigned pos = 0;
+      if (lane == 0) pos = atomicAdd(&s_nkept, n0 + n1);                      // (cannot overflow: SIFT_CELLS x 64 bricks fit the stage)
+      pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
+      if ((mask[0] >> lane) & 1ull) s_stage[pos + (unsigned)__popcll(mask[0] & ((1ull << lane) - 1ull))] = packed[0];
+      if ((mask[1] >> lane) & 1ull) s_stage[pos + n0 + (unsigned)__popcll(mask[1] & ((1ull << lane) - 1ull))] = packed[1];
+    }
+  }
+  if (DEFER && retired && lane == 0) atomicAdd(&a.cnt->upd_shard[a.parity][((blockIdx.x * 4u + (unsigned)wid) & 63u) * 16], (unsigned long long)retired * KF_BRICK_VOX);   // N_upd stays exact
+  __syncthreads();
+  const unsigned staged = s_nkept;
+  if (threadIdx.x == 0) s_base = staged ? atomicAdd(&a.cnt->n_active[a.parity], staged) : 0u;
+  __syncthreads();
+  for (unsigned p = threadIdx.x; p < staged; p += SIFT_THREADS) a.queue[s_base + p] = s_stage[p];
+}
+
 // pass 2: one workgroup walks the queue BR bricks at a time, one lane per x-adjacent voxel pair (16 contiguous bytes) of
 // each brick.  The phases of the BR bricks are interleaved (all projections, all depth gathers, all predicates, all 16-byte
 // loads, all updates) so a workgroup keeps BR x 4 KiB of HBM requests in flight instead of one dependent chain at a time.
@@ -797,7 +869,14 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
     const int nmxy = (c->vol.nb + 3) >> 2, nmz = ((c->vol.bz1 + 3) >> 2) - (c->vol.bz0 >> 2);
     const unsigned n_macro = (unsigned)nmxy * nmxy * nmz;                      // one wave per macro cell, sixteen per workgroup
     const unsigned cgrid = (n_macro + CULL_WAVES - 1) / CULL_WAVES;
-    if (a.defer_cull) hipLaunchKernelGGL(k_integrate_cull<true>, dim3(cgrid), dim3(CULL_WAVES * 64), 0, c->stream, a);
+    // large volumes: the macro cells are sifted one per lane first (k_integrate_cull_sift); KF_CULL_SIFT=0 / 1 forces either form
+    static int sift_env = -2;
+    if (sift_env == -2) { const char* e = getenv("KF_CULL_SIFT"); sift_env = e ? atoi(e) : -1; }
+    const bool sift = sift_env >= 0 ? sift_env != 0 : n_macro >= 100000u;
+    const int n_wg = (int)((n_macro + SIFT_CELLS - 1) / SIFT_CELLS);
+    if (sift && a.defer_cull) hipLaunchKernelGGL(k_integrate_cull_sift<true>, dim3(n_wg), dim3(SIFT_THREADS), 0, c->stream, a, n_wg);
+    else if (sift) hipLaunchKernelGGL(k_integrate_cull_sift<false>, dim3(n_wg), dim3(SIFT_THREADS), 0, c->stream, a, n_wg);
+    else if (a.defer_cull) hipLaunchKernelGGL(k_integrate_cull<true>, dim3(cgrid), dim3(CULL_WAVES * 64), 0, c->stream, a);
     else hipLaunchKernelGGL(k_integrate_cull<false>, dim3(cgrid), dim3(CULL_WAVES * 64), 0, c->stream, a);
   }
   // Workgroups walking the queue.  Large volumes (>= 2^20 stored bricks: the queue holds >~100k bricks): four bricks in flight per workgroup and
