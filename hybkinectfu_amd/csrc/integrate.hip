@@ -693,6 +693,170 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   if (LAYERS) for (int i = threadIdx.x; i < v.nb; i += 256) { const unsigned n = s_layer[i]; if (n) atomicAdd(&a.layer_work[i], (unsigned long long)n); }
 }
 
+// ---- the one-brick form as a two-stage pipeline ------------------------------------------------------------------------------------------------------
+// k_integrate_pairs<1, DEFER> walks a brick's chain  queue entry -> flags / deferred-weight word -> projection -> depth gather -> predicate -> 16-byte voxel
+// load -> update -> store  once per iteration, and a wave's iteration lasts as long as that chain (~3 us; 32 waves per CU: 1024^3 with deferred weights =
+// 1484 wave iterations per CU = 130 us whatever the bytes).  Here the FRONT of brick i + 1's chain (entry, flags / word, projection, depth gather) is issued
+// behind brick i's voxel load and before the wait for it, so it travels in the shadow of that load: an iteration costs the longer of the two halves.  Loads
+// return in order, and everything of brick i + 1 is younger than brick i's voxel load: the wait for that load leaves them outstanding.  The per-voxel
+// arithmetic, the predicate, the deferred-weight rules and the flag updates are those of k_integrate_pairs, statement for statement: same bits.
+// A brick's flag byte and deferred-weight word are read one iteration early: within a launch nobody but this wave writes them (a brick is queued once; the
+// flag word's other bytes belong to other bricks and only ever gain bits).
+struct PipeFront {                       // what stage A leaves behind for stage B
+  unsigned ent, slot, fold_v, pend_v;
+  kf_f2 pfz, d;
+  bool ok0, ok1;
+};
+template <bool DEFER>
+__global__ void __launch_bounds__(256) k_integrate_pairs_pipe(IntegrateArgs a) {
+  const KfVolume& v = a.vol;
+  const unsigned n_active = a.cnt->n_active[a.parity];
+  if (blockIdx.x == 0) integrate_maintenance(a);
+  const float* m = a.tinv ? a.tinv : a.tinv_val.m;
+  const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8], m9 = m[9], m10 = m[10], m11 = m[11];
+  const float cell = v.cell;
+  const int lx = (threadIdx.x & 3) * 2, ly = (threadIdx.x >> 2) & 7, lz = threadIdx.x >> 5;
+  const KfRecip rt = kf_recip(a.sdf_trunc);
+  KfRecip2 rtrunc; rtrunc.den = f2_splat(rt.den); rtrunc.r = f2_splat(rt.r);
+  const unsigned xlim = (unsigned)(a.dcam.cols - 2), ylim = (unsigned)(a.dcam.rows - 2);
+  const unsigned quarter = threadIdx.x >> 6;
+  const unsigned sat_w = __float_as_uint(v.max_weight), one_f = __float_as_uint(1.0f);
+  unsigned short* const pend16 = reinterpret_cast<unsigned short*>(v.pend);
+  __shared__ unsigned s_upd;
+  unsigned upd_total = 0;
+  if (threadIdx.x == 0) s_upd = 0;
+  __syncthreads();
+  // stage A of one brick: everything up to (and including) the request of its depth values
+  auto front = [&](unsigned packed, bool live) {
+    PipeFront f;
+    f.ent = packed;
+    const int bx = (int)(packed & 1023u), by = (int)((packed >> 10) & 1023u), bz = (int)(packed >> 20) + v.bz0;
+    f.slot = ((unsigned)(bz - v.bz0) * (unsigned)v.nb + (unsigned)by) * (unsigned)v.nb + (unsigned)bx;
+    f.fold_v = v.flags[kf_opaque(f.slot)];
+    f.pend_v = DEFER ? (unsigned)pend16[kf_opaque(f.slot * 4u + quarter)] : 0u;
+    const float x0 = (float)(bx * 8 + lx);
+    kf_f2 xi = {x0, x0 + 1.0f};
+    const kf_f2 wx = (xi + f2_splat(0.5f)) * f2_splat(cell);
+    const float wy = ((float)(by * 8 + ly) + 0.5f) * cell, wz = ((float)(bz * 8 + lz) + 0.5f) * cell;
+    const kf_f2 pfx = ((f2_splat(m0) * wx + f2_splat(m1 * wy)) + f2_splat(m2 * wz)) + f2_splat(m3 * 1.0f);
+    const kf_f2 pfy = ((f2_splat(m4) * wx + f2_splat(m5 * wy)) + f2_splat(m6 * wz)) + f2_splat(m7 * 1.0f);
+    f.pfz = ((f2_splat(m8) * wx + f2_splat(m9 * wy)) + f2_splat(m10 * wz)) + f2_splat(m11 * 1.0f);
+    const bool z0 = live && f.pfz.x > 0.f, z1 = live && f.pfz.y > 0.f;
+    kf_f2 zs = {z0 ? f.pfz.x : 1.0f, z1 ? f.pfz.y : 1.0f};
+    const KfRecip2 rz = kf_recip2(zs);
+    const kf_f2 px = kf_div2(pfx * f2_splat(a.dcam.fx), rz) + f2_splat(a.dcam.cx) + f2_splat(0.5f);
+    const kf_f2 py = kf_div2(pfy * f2_splat(a.dcam.fy), rz) + f2_splat(a.dcam.cy) + f2_splat(0.5f);
+    const int sx0 = (int)floorf(px.x), sx1 = (int)floorf(px.y), sy0 = (int)floorf(py.x), sy1 = (int)floorf(py.y);
+    f.ok0 = z0 && (unsigned)(sx0 - 1) < xlim && (unsigned)(sy0 - 1) < ylim;
+    f.ok1 = z1 && (unsigned)(sx1 - 1) < xlim && (unsigned)(sy1 - 1) < ylim;
+    const int pix0 = f.ok0 ? sy0 * a.dcam.cols + sx0 : 0, pix1 = f.ok1 ? sy1 * a.dcam.cols + sx1 : 0;
+    // no branch around the gathers (a voxel outside the window reads pixel 0; its value is never looked at: the predicate starts with ok0 / ok1) -- behind a
+    // conditional load the compiler parks a wait, and the next brick's front would be waited for before the current brick is updated
+    f.d.x = a.depth[pix0]; f.d.y = a.depth[pix1];
+    return f;
+  };
+  const unsigned stride = gridDim.x;
+  unsigned q0 = blockIdx.x;
+  // start-up: the first two entries are requested without waiting for the queue length (every index below the queue's capacity is readable)
+  unsigned e_cur, ahead;
+  { const unsigned i0 = kf_opaque(q0), i1 = kf_opaque(q0 + stride);
+    e_cur = a.queue[i0 < a.queue_cap ? i0 : 0u]; ahead = a.queue[i1 < a.queue_cap ? i1 : 0u]; }
+  if (q0 >= n_active) return;                                             // (uniform; nothing was counted)
+  PipeFront cur = front((unsigned)__builtin_amdgcn_readfirstlane((int)e_cur), true);
+  // (the first brick's front is waited for here, not at the loop's head: a wait at the head is a wait in EVERY iteration, behind the previous one's stores)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur.d.x), "+v"(cur.d.y), "+v"(cur.fold_v), "+v"(cur.pend_v), "+v"(ahead) :: "memory");
+  for (; q0 < n_active; q0 += stride) {
+    // ---- stage B, first half: the predicate of brick `cur`, its voxel load goes out
+    const unsigned slot = cur.slot, ent = cur.ent;
+    const kf_f2 sdf = cur.d - cur.pfz;
+    const bool upd0 = cur.ok0 && cur.d.x != 0.f && cur.d.x < a.max_dist && sdf.x > -a.sdf_trunc;
+    const bool upd1 = cur.ok1 && cur.d.y != 0.f && cur.d.y < a.max_dist && sdf.y > -a.sdf_trunc;
+    const unsigned fold = (unsigned)__builtin_amdgcn_readfirstlane((int)cur.fold_v);
+    const unsigned pnd = DEFER ? (unsigned)__builtin_amdgcn_readfirstlane((int)cur.pend_v) : 0u;
+    const bool band = (upd0 && sdf.x < a.sdf_trunc) || (upd1 && sdf.y < a.sdf_trunc);
+    const bool no_band = __ballot(band) == 0ull;
+    const bool free_wave = a.free_ok && no_band;
+    bool skip = false, all_lanes = false;
+    if (DEFER) {
+      const bool free_exact = no_band && a.sdf_trunc > 0.f;
+      const bool whole = __ballot(upd0 && upd1) == ~0ull;
+      skip = free_exact && (pnd == KF_PEND_SAT || (pnd != 0u && whole));
+      all_lanes = !skip && pnd >= 2u && __ballot(upd0 || upd1) != 0ull;
+    }
+    float4* const p = reinterpret_cast<float4*>(v.tw + (size_t)slot * KF_BRICK_VOX) + threadIdx.x;
+    const bool touch = upd0 || upd1;
+    const bool rw = (touch || all_lanes) && !skip;
+    const float4 q = *(rw ? p : reinterpret_cast<const float4*>(a.queue_pad));
+    // ---- stage A of the NEXT brick, in the shadow of that load
+    const unsigned qn = q0 + stride;
+    const bool next_live = qn < n_active;
+    const unsigned e_next = next_live ? (unsigned)__builtin_amdgcn_readfirstlane((int)ahead) : 0u;
+    { const unsigned i2 = kf_opaque(qn + stride); ahead = a.queue[i2 < n_active ? i2 : 0u]; }
+    PipeFront nxt = cur;
+    if (next_live) nxt = front(e_next, true);                              // (uniform; the wait below is explicit, so a branch around these loads costs nothing)
+    // ONE wait per iteration, here: brick `cur`'s voxels (requested first, the slowest) and brick `nxt`'s front (requested behind them) have all arrived
+    // when the update below starts, and nothing is outstanding but loads -- the stores and flag atomics below are conditional, and the in-order counter
+    // cannot wait for a load that was issued behind an unknown number of them without waiting for all (which put the store's completion on the chain)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt.d.x), "+v"(nxt.d.y), "+v"(nxt.fold_v), "+v"(nxt.pend_v), "+v"(ahead) :: "memory");
+    // ---- stage B, second half: brick `cur` is updated and stored
+    if (DEFER && skip) {
+      upd_total += (upd0 ? 1u : 0u) + (upd1 ? 1u : 0u);
+      if (pnd != KF_PEND_SAT && (threadIdx.x & 63) == 0) pend16[slot * 4u + quarter] = (unsigned short)kf_pend_step(pnd, v.max_weight);
+    } else {
+      const kf_f2 ot = {q.x, q.z};
+      kf_f2 ow = {q.y, q.w};
+      if (DEFER && all_lanes) { const float k = (float)(pnd - 1u); ow.x = fminf(ow.x + k, v.max_weight); ow.y = fminf(ow.y + k, v.max_weight); }
+      const kf_f2 ow1 = ow + f2_splat(1.f);
+      bool unit = false;
+      if (free_wave) {
+        const bool k0 = !upd0 || (__float_as_uint(ot.x) == one_f && __float_as_uint(ow.x) <= 0x4B800000u);
+        const bool k1 = !upd1 || (__float_as_uint(ot.y) == one_f && __float_as_uint(ow.y) <= 0x4B800000u);
+        unit = __ballot(!(k0 && k1)) == 0ull;
+      }
+      kf_f2 nt = f2_splat(1.0f);
+      if (!unit) {
+        kf_f2 tsdf = f2_splat(1.0f);
+        if (!free_wave) { tsdf = kf_div2(sdf, rtrunc); tsdf.x = fminf(1.0f, tsdf.x); tsdf.y = fminf(1.0f, tsdf.y); }
+        nt = kf_div2(ot * ow + tsdf, kf_recip2(ow1));
+      }
+      const float nw0 = fminf(ow1.x, v.max_weight), nw1 = fminf(ow1.y, v.max_weight);
+      unsigned flags = 0;
+      float4 r = make_float4(ot.x, ow.x, ot.y, ow.y);
+      if (upd0) { r.x = nt.x; r.y = nw0; }
+      if (upd1) { r.z = nt.y; r.w = nw1; }
+      if (rw) *p = r;
+      if (touch) {
+        upd_total += (upd0 ? 1u : 0u) + (upd1 ? 1u : 0u);
+        flags = KF_FLAG_OBSERVED | (((upd0 && nt.x < 0.f) || (upd1 && nt.y < 0.f)) ? KF_FLAG_HASNEG : 0u);
+      }
+      const unsigned long long wrote = __ballot(flags & KF_FLAG_OBSERVED);
+      const unsigned wflags = ((wrote ? KF_FLAG_OBSERVED : 0u) | (__ballot(flags & KF_FLAG_HASNEG) ? KF_FLAG_HASNEG : 0u)) & ~fold;
+      if (wflags && (threadIdx.x & 63) == 0) {
+        atomicOr(reinterpret_cast<unsigned*>(v.flags) + (slot >> 2), wflags << (8u * (slot & 3u)));
+        if (wflags & KF_FLAG_HASNEG) {
+          kf_mark_macro(v, (int)(ent & 1023u), (int)((ent >> 10) & 1023u), (int)(ent >> 20) + v.bz0);
+          atomicOr(&v.negbits[slot >> 5], 1u << (slot & 31u));
+        }
+      }
+      if (DEFER && wrote && (pnd != 0u || __ballot(rw) == ~0ull)) {
+        bool lane_unit = pnd != 0u, lane_sat = false;
+        if (rw) {
+          lane_unit = __float_as_uint(r.x) == one_f && __float_as_uint(r.z) == one_f && r.y >= 1.f && r.w >= 1.f;
+          lane_sat = lane_unit && __float_as_uint(r.y) == sat_w && __float_as_uint(r.w) == sat_w;
+        }
+        const bool all_unit = __ballot(lane_unit) == ~0ull, all_sat = __ballot(lane_sat) == ~0ull;
+        const unsigned np = all_unit ? (all_sat ? KF_PEND_SAT : 1u) : 0u;
+        if (np != pnd && (threadIdx.x & 63) == 0) pend16[slot * 4u + quarter] = (unsigned short)np;
+      }
+    }
+    cur = nxt;
+  }
+  float s = kf_wave_sum((float)upd_total);
+  if ((threadIdx.x & 63) == 0 && s > 0.f) atomicAdd(&s_upd, (unsigned)s);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_upd) atomicAdd(&a.cnt->upd_shard[a.parity][(blockIdx.x & 63) * 16], (unsigned long long)s_upd);
+}
+
 #ifdef KF_EXPERIMENTS
 // experiments 4-7: the memory side of the fusion pass alone -- every queued brick is read and / or written back (16 bytes per
 // lane, all lanes), no arithmetic: what the brick-queue access pattern can reach on this chip (tools/bench_integrate.py).
@@ -922,6 +1086,8 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
     static int br_env = -1;
     if (br_env < 0) { const char* e = getenv("KF_INTEGRATE_BR"); br_env = e ? atoi(e) : 0; if (br_env != 1 && br_env != 2 && br_env != 4) br_env = 0; }
     const int br = br_env ? br_env : ((big && !defer) ? 4 : 1);
+    static int pipe_env = -1;
+    if (pipe_env == -1) { const char* e = getenv("KF_INTEGRATE_PIPE"); pipe_env = e ? atoi(e) : -2; }     // -2: decided per call below
     static int pairs = -1;                               // 1 (default): the packed-pair kernel; 0: the scalar one (A/B and colour path)
     if (pairs < 0) { const char* e = getenv("KF_INTEGRATE_PAIRS"); pairs = e ? atoi(e) : 1; }
 #ifdef KF_EXPERIMENTS
@@ -935,6 +1101,9 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
     if (pairs && a.layer_work) {                           // a sampled frame (kf_count_layer_work): the one-brick form that also counts per brick layer
       if (defer) FUSE_LAUNCH((k_integrate_pairs<1, true, false, true>));
       else FUSE_LAUNCH((k_integrate_pairs<1, false, false, true>));
+    } else if (pairs && br == 1 && (pipe_env < 0 ? defer : pipe_env != 0)) {     // the one-brick form as a two-stage pipeline: by default where workgroups walk many bricks (KF_INTEGRATE_PIPE=0 / 1 forces)
+      if (defer) FUSE_LAUNCH((k_integrate_pairs_pipe<true>));
+      else FUSE_LAUNCH((k_integrate_pairs_pipe<false>));
     } else if (pairs) {
       if (defer) {
         if (br == 1) FUSE_LAUNCH((k_integrate_pairs<1, true>));
