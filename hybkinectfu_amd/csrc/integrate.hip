@@ -445,6 +445,9 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   // entry at or beyond n_active is discarded below -- so the two loads of a workgroup's start-up travel together: at 512^3 a workgroup
   // lives for one or two iterations and its start-up round trips are a visible part of the kernel)
   for (int b = 0; b < BR; ++b) { const unsigned i = kf_opaque(blockIdx.x * BR + b); ahead[b] = a.queue[i < a.queue_cap ? i : 0u]; }
+  // (waited for here rather than at the loop's head, where the wait would be repeated in every iteration -- see the note in front of the stores below)
+#pragma unroll
+  for (int b = 0; b < BR; ++b) asm volatile("" : "+v"(ahead[b]));
 #endif
   for (unsigned q0 = blockIdx.x * BR; q0 < n_active; q0 += gridDim.x * BR) {
     unsigned slot[BR], fold[BR], ent[BR];                        // ent: the packed brick coordinates (decoded where needed: scalar registers are scarce here)
@@ -600,6 +603,13 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
         nz1[b] = a.normals[upd1[b] ? pix1[b] : 0].z;
       }
     }
+#ifndef KF_INT_NO_QPREFETCH
+    // The next iteration's queue entries were requested at the top of this one and are older than the voxel loads above: they have arrived.  They are
+    // "used" HERE, in front of this iteration's stores and flag atomics -- those are conditional, the compiler cannot count them, and its wait for the
+    // entries at the head of the next iteration was a wait for everything outstanding: the stores' completion sat on every iteration's chain.
+#pragma unroll
+    for (int b = 0; b < BR; ++b) asm volatile("" : "+v"(ahead[b]));
+#endif
 #pragma unroll
     for (int b = 0; b < BR; ++b) {
       if (DEFER && skip[b]) {                                               // uniform: counted; one more pending step unless the quarter is saturated

@@ -47,7 +47,7 @@ def hbm(cfg, want, units=None, tail=None):
 # plain read-modify-write form (<BR, false, false>) on the frames of the `roofline` leg that follows the timed region (kf_set_defer(0))
 import re
 def _form(n):                       # k_integrate_pairs<BR, DEFER, COLOR, LAYERS>: the second template argument
-    m = re.search(r"k_integrate_pairs<\d+, (true|false)", n)
+    m = re.search(r"k_integrate_pairs<\d+, (true|false)", n) or re.search(r"k_integrate_pairs_pipe<(true|false)", n)    # (the pipelined one-brick form: <DEFER>)
     return m.group(1) if m else None
 plain = lambda n: _form(n) == "false"
 defer = lambda n: _form(n) == "true"
@@ -65,10 +65,10 @@ for c in ("c2", "c4", "c5"):
             if h:
                 res[c.upper() + "_raycast"] = int(h[2])
                 lines.append("%s raycast launch (k_raycast_prefetch incl. the next frame's riders) per launch: 2 x FETCH %.1f MB + WRITE %.1f MB = %.1f MB" % (c.upper(), 2 * h[0] / 1e6, h[1] / 1e6, h[2] / 1e6))
-            h = hbm(run_name, lambda n: "k_integrate_cull<true>" in n)
+            h = hbm(run_name, lambda n: "k_integrate_cull<true>" in n or "k_integrate_cull_sift<true>" in n)
             if h:
                 res[c.upper() + "_cull"] = int(h[2])
-                lines.append("%s cull (k_integrate_cull<DEFER>) per launch: 2 x FETCH %.2f MB + WRITE %.2f MB = %.2f MB" % (c.upper(), 2 * h[0] / 1e6, h[1] / 1e6, h[2] / 1e6))
+                lines.append("%s cull (k_integrate_cull<DEFER> / k_integrate_cull_sift<DEFER>) per launch: 2 x FETCH %.2f MB + WRITE %.2f MB = %.2f MB" % (c.upper(), 2 * h[0] / 1e6, h[1] / 1e6, h[2] / 1e6))
         st = glob.glob(os.path.join(out, "trace_%s" % run_name, "*", "*kernel_stats.csv"))
         if st:
             lines.append("%s kernel stats (rocprofv3 --kernel-trace --stats, see tools/profile_round.sh for the bench.py command):" % run_name.upper())
