@@ -125,9 +125,13 @@ __device__ __forceinline__ void llt_solve6(const float A[36], const float b[6], 
     float s = A[j * 6 + j];
 #pragma unroll
     for (int k = 0; k < j; ++k) s -= L[j * 6 + k] * L[j * 6 + k];
+#ifndef KF_SOLVE_SQRT_RCP
+    rd[j] = __builtin_amdgcn_rsqf(s);                        // 1 / L_jj in ONE transcendental (L_jj itself is never used: every use divides by it)
+#else
     const float d = __builtin_amdgcn_sqrtf(s);
     L[j * 6 + j] = d;
     rd[j] = __builtin_amdgcn_rcpf(d);
+#endif
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       float t = A[i * 6 + j];
@@ -185,6 +189,47 @@ __device__ __forceinline__ void llt_solve6(const float A[36], const float b[6], 
     x[i] = kf_div(t, rd[i]);
   }
 #endif
+}
+// The same 6x6 system solved by a WAVE: lane i (< 6) holds row i of the symmetric matrix and b_i; a right-looking Cholesky -- column j is scaled by
+// rsq(pivot), then every lane takes l_i * l_k off its trailing entries, l_k by v_readlane -- with the forward substitution carried along as a seventh
+// column, then a column-oriented back substitution on wave-uniform values.  About 110 instructions on a dependent chain of six (readlane, rsq, product,
+// fused update) links instead of ~430 instructions and two transcendentals per pivot on one lane: the Gauss-Newton step's solve phase was that chain.
+// The pivots come for free, and with them the determinant the reference tests (ICP.cpp:138 `determinant() < 1e-10` on the float matrix): for the
+// symmetric positive (semi-)definite J^T J it is the product of the Cholesky pivots, so the second 6x6 factorization (det6: partial-pivot LU on a lane of
+// another wave, the longer of the two chains) is not run at all; a pivot <= 0 means the product has no business being positive: singular.  Same inputs
+// in every workgroup / launch form -> same bits everywhere; against the reference's Eigen chain the increment agrees as before to the asserted 1e-4
+// (1-ulp rsq and fused updates instead of sqrt / divide: DESIGN.md section 2.4).  -DKF_SOLVE_ONE_LANE restores the one-lane solve + LU determinant.
+__device__ __forceinline__ void llt_solve6_wave(const float* s_tot, float x[6], bool& singular, float& det) {
+  const int i = min((int)(threadIdx.x & 63u), 5);
+  float a[6], bb;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) { const int r = i < j ? i : j, c = i < j ? j : i; a[j] = s_tot[7 * r - (r * (r - 1)) / 2 + (c - r)]; }   // the packing of unpack27
+  bb = s_tot[7 * i - (i * (i - 1)) / 2 + (6 - i)];
+  float Lc[6], y[6], rd[6];
+  bool bad = false; float prod = 1.f;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float sj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[j]), j));      // the pivot: row j's diagonal after the earlier columns' updates
+    bad = bad || (sj <= 0.f);
+    prod *= sj;
+    const float r = __builtin_amdgcn_rsqf(sj);
+    rd[j] = r;
+    const float l = a[j] * r;                                                                  // lane i >= j: L[i][j]
+    Lc[j] = l;
+#pragma unroll
+    for (int k = j + 1; k < 6; ++k) a[k] = __builtin_fmaf(-l, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l), k)), a[k]);
+    const float yj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb), j)) * r;     // forward substitution, as column 7
+    y[j] = yj;
+    bb = __builtin_fmaf(-l, yj, bb);
+  }
+#pragma unroll
+  for (int k = 5; k >= 0; --k) {
+    const float xk = y[k] * rd[k];
+    x[k] = xk;
+#pragma unroll
+    for (int r = 0; r < k; ++r) y[r] = __builtin_fmaf(-__int_as_float(__builtin_amdgcn_readlane(__float_as_int(Lc[r]), k)), xk, y[r]);   // L[k][r] lives in lane k
+  }
+  singular = bad; det = prod;
 }
 __device__ __forceinline__ void mat3_mul(const float a[9], const float b[9], float o[9]) {
 #pragma unroll
@@ -333,6 +378,7 @@ __device__ __forceinline__ int apply_step(const TrackArgs& a, const float* s_tot
 #else
 #define KF_SOLVE_STAMP(i) do { } while (0)
 #endif
+#ifdef KF_SOLVE_ONE_LANE
     if (threadIdx.x == det_lane) {
       float A[36], b[6];
       unpack27(s_tot, A, b);
@@ -342,6 +388,9 @@ __device__ __forceinline__ int apply_step(const TrackArgs& a, const float* s_tot
       scratch[17] = ((double)det6(A) < 1E-10) ? 1.f : 0.f;
       KF_SOLVE_STAMP(6);                                                     // determinant lane: entry -> done
     }
+#else
+    (void)det_lane;
+#endif
     // wave 0 runs the solve, the trigonometry and the increment as ONE chain without touching LDS in between: lane 0 solves; the increment
     // goes to the whole wave as scalars (v_readfirstlane: lane 0 is the wave's first lane); lanes 0-2 take the sine / cosine of one angle
     // each and hand them back the same way (v_readlane); then EVERY lane forms the rotation and the shake verdict from those scalars -- the
@@ -353,6 +402,7 @@ __device__ __forceinline__ int apply_step(const TrackArgs& a, const float* s_tot
     if (threadIdx.x < 64) {
       float* vs = scratch;
       float x[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifdef KF_SOLVE_ONE_LANE
       if (threadIdx.x == 0) {
         float A[36], b[6];
         unpack27(s_tot, A, b);
@@ -361,6 +411,16 @@ __device__ __forceinline__ int apply_step(const TrackArgs& a, const float* s_tot
       }
 #pragma unroll
       for (int i = 0; i < 6; ++i) x[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x[i])));
+#else
+      {
+        bool singular; float det;
+        llt_solve6_wave(s_tot, x, singular, det);                            // the whole wave: the increment is wave-uniform, the pivots give the determinant
+        if (threadIdx.x == 0) { vs[17] = (singular || (double)det < 1E-10) ? 1.f : 0.f; KF_SOLVE_STAMP(0); }
+#ifdef KF_EXPERIMENTS
+        if (a.exp_nodet && threadIdx.x == 0) vs[17] = 0.f;
+#endif
+      }
+#endif
       const float ang = threadIdx.x == 0 ? x[0] : (threadIdx.x == 1 ? x[1] : x[2]);
       float sn, cs; kf_sincos_small(ang, &sn, &cs);
       const int sni = __float_as_int(sn), csi = __float_as_int(cs);
