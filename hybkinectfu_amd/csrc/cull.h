@@ -3,6 +3,7 @@
 // Reference: the update predicate of integrateKernel, src/cuda/integrateVolume.cu:39-67 -- a brick is dropped only when no voxel of it can pass it.
 #pragma once
 #include "kf_internal.h"
+#define KF_CULL_PX_SLACK 0.0625f          // pixels: see cull_test_cell
 
 struct IntegrateArgs {
   KfVolume vol;
@@ -107,7 +108,17 @@ __device__ __forceinline__ bool cull_test_cell(const IntegrateArgs& a, const flo
     const float xl = px - ex, xr = px + ex, yl = py - ey, yr = py + ey;
     float u0 = (xl < 0.f ? xl / zn : xl / zf) * a.dcam.fx + a.dcam.cx, u1 = (xr > 0.f ? xr / zn : xr / zf) * a.dcam.fx + a.dcam.cx;
     float w0 = (yl < 0.f ? yl / zn : yl / zf) * a.dcam.fy + a.dcam.cy, w1 = (yr > 0.f ? yr / zn : yr / zf) * a.dcam.fy + a.dcam.cy;
+#ifndef KF_CULL_WIDE_MARGIN
+    // A voxel's pixel is (int)(u + 0.5) of ITS projection u (DepthCamera.h:30-43), and u0 .. u1 bound the projections of all the brick's voxels (the box's
+    // support, widened by eps = 1e-4 of the volume, ~0.1 pixel): the pixels lie in [floor(u0 + 0.5), floor(u1 + 0.5)].  KF_CULL_PX_SLACK more on either side
+    // covers the last-bit differences between these expressions and the fusion kernel's own (a few 1e-4 of a pixel).  (Rounds 1-4 used floor(u0) - 1 ..
+    // ceil(u1) + 2: three pixels wider than needed, on footprints of 4-8 pixels -- a fifth of the queued bricks of a 1024^3 volume were free space that the
+    // tile minima of those extra pixels did not vouch for: profiles/r04_cull_margin.txt.)
+    int ix0 = (int)floorf(u0 + (0.5f - KF_CULL_PX_SLACK)), ix1 = (int)floorf(u1 + (0.5f + KF_CULL_PX_SLACK));
+    int iy0 = (int)floorf(w0 + (0.5f - KF_CULL_PX_SLACK)), iy1 = (int)floorf(w1 + (0.5f + KF_CULL_PX_SLACK));
+#else
     int ix0 = (int)floorf(u0) - 1, ix1 = (int)ceilf(u1) + 2, iy0 = (int)floorf(w0) - 1, iy1 = (int)ceilf(w1) + 2;
+#endif
     // every voxel's pixel lies in [ix0, ix1] x [iy0, iy1]: inside the reference's 1 .. cols-2 / rows-2 window (integrateVolume.cu:43)?
     const bool all_inside = ix0 >= 1 && iy0 >= 1 && ix1 <= a.dcam.cols - 2 && iy1 <= a.dcam.rows - 2;
     ix0 = max(ix0, 0); iy0 = max(iy0, 0); ix1 = min(ix1, a.dcam.cols - 1); iy1 = min(iy1, a.dcam.rows - 1);
@@ -154,6 +165,40 @@ __device__ __forceinline__ bool cull_test_cell(const IntegrateArgs& a, const flo
       }                                                                    // larger footprints (bricks close to the eye) are kept
     }
   }
+#ifdef KF_EXPERIMENTS
+  // KF_INTEGRATE_EXP=16 (tools/exp_cull_deferred.py): why are bricks whose quarters are in a deferred state still queued?  Counted per kept brick.
+  if (DEFER && KF_EXP_MODE(a) == 16 && keep) {
+    const unsigned q0 = (unsigned)(pp & 0xFFFFull), q1 = (unsigned)((pp >> 16) & 0xFFFFull), q2 = (unsigned)((pp >> 32) & 0xFFFFull), q3 = (unsigned)(pp >> 48);
+    const int nq = (q0 != 0) + (q1 != 0) + (q2 != 0) + (q3 != 0);
+    const unsigned sh = (unsigned)(lane & 63) * 16u;
+    if (nq == 4) {
+      atomicAdd(&a.cnt->rc_steps[sh], 1ull);                                              // all four quarters deferred, queued all the same
+      bool near_eye = !(zn > 4.f * cell), outside = false, large = false, invalid = false, close = false;
+      if (!near_eye) {
+        const float xl = px - ex, xr = px + ex, yl = py - ey, yr = py + ey;
+        float u0 = (xl < 0.f ? xl / zn : xl / zf) * a.dcam.fx + a.dcam.cx, u1 = (xr > 0.f ? xr / zn : xr / zf) * a.dcam.fx + a.dcam.cx;
+        float w0 = (yl < 0.f ? yl / zn : yl / zf) * a.dcam.fy + a.dcam.cy, w1 = (yr > 0.f ? yr / zn : yr / zf) * a.dcam.fy + a.dcam.cy;
+        int ix0 = (int)floorf(u0) - 1, ix1 = (int)ceilf(u1) + 2, iy0 = (int)floorf(w0) - 1, iy1 = (int)ceilf(w1) + 2;
+        outside = !(ix0 >= 1 && iy0 >= 1 && ix1 <= a.dcam.cols - 2 && iy1 <= a.dcam.rows - 2);
+        ix0 = max(ix0, 0); iy0 = max(iy0, 0); ix1 = min(ix1, a.dcam.cols - 1); iy1 = min(iy1, a.dcam.rows - 1);
+        const int lvl = (!a.fine_tiles || ((ix1 >> 3) - (ix0 >> 3)) >= 4 || ((iy1 >> 3) - (iy0 >> 3)) >= 4) ? 1 : 0;
+        const int sh2 = 3 + lvl, tx0 = ix0 >> sh2, tx1 = ix1 >> sh2, ty0 = iy0 >> sh2, ty1 = iy1 >> sh2;
+        large = !(tx1 - tx0 < 4 && ty1 - ty0 < 4);
+        if (!outside && !large) {
+          const float* tmn = a.tile_max + a.tile_off[lvl] + a.n_tile_floats;
+          float dmin = __builtin_huge_valf();
+          for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) dmin = fminf(dmin, tmn[min(ty0 + j, ty1) * a.tile_w[lvl] + min(tx0 + i, tx1)]);
+          invalid = !(dmin > 0.f);
+          close = !invalid;                                                                // (what is left: the minimum depth is within a truncation distance of the brick)
+        }
+      }
+      if (near_eye || large) atomicAdd(&a.cnt->rc_steps[sh], 1ull << 32);               // no tile test possible (next to the eye / a footprint beyond 4 x 4 tiles)
+      else if (outside) atomicAdd(&a.cnt->rc_hits[sh], 1ull);                            // some voxel may project outside the image window
+      else if (invalid) atomicAdd(&a.cnt->rc_hits[sh], 1ull << 32);                      // a pixel under the footprint's tiles holds no depth that integrates
+      else if (close) atomicAdd(&a.cnt->mc_blocks[sh], 1ull);                            // the tiles' minimum depth is not a truncation distance behind the brick
+    } else if (nq > 0) atomicAdd(&a.cnt->mc_blocks[sh], 1ull << 32);                     // one to three quarters deferred
+  }
+#endif
   bx_out = bx; by_out = by; bz_out = bz; noop_out = noop;
   return keep;
 }
