@@ -966,6 +966,7 @@ void kf_fill_cull_args(kf_ctx* c, IntegrateArgs& a, const kf_camera_params* dcam
   // The 8-pixel table is four times larger and colder in the cull's caches (+2 us per launch at VGA); it pays when bricks are
   // small on screen -- 1024^3 @ 6 m: 4 px at the far end, queue -7 %, fusion -10 us -- not at 512^3 @ 4 m (16 px, -3 %, -0.4 us).
   a.fine_tiles = (8.f * c->vol.cell * a.dcam.fx / (a.max_dist > 0.f ? a.max_dist : 1.f)) < 12.f ? 1 : 0;
+  { static int fe = -2; if (fe == -2) { const char* e = getenv("KF_CULL_FINE"); fe = e ? atoi(e) : -1; } if (fe >= 0) a.fine_tiles = fe; }      // A/B
   a.fr_slope[0] = (-1.f - a.dcam.cx) / a.dcam.fx; a.fr_slope[1] = ((float)a.dcam.cols - a.dcam.cx) / a.dcam.fx;
   a.fr_slope[2] = (-1.f - a.dcam.cy) / a.dcam.fy; a.fr_slope[3] = ((float)a.dcam.rows - a.dcam.cy) / a.dcam.fy;
   for (int i = 0; i < 4; ++i) a.fr_norm[i] = sqrtf(1.f + a.fr_slope[i] * a.fr_slope[i]);
