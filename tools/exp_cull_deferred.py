@@ -26,6 +26,10 @@ for lo, hi in ((0, 2), (2, 10), (10, n)):
     a, b, m = a - a0, b - b0, m - m0
     f = float(hi - lo)
     lo32, hi32 = (lambda x: (x & 0xFFFFFFFF) / f), (lambda x: (x >> 32) / f)
+    if os.environ.get("KF_INTEGRATE_EXP") == "17":
+        print("%s frames %3d..%3d: queued %7d bricks (last frame) | per frame: kept by the cull %7.0f | an EXACT footprint would drop %6.0f and retire %6.0f | a 4-pixel table level would drop %6.0f and retire %6.0f" % (
+            cfg, lo, hi, c.stats()["bricks_active"], lo32(a), hi32(a), lo32(b), hi32(b), lo32(m)))
+        continue
     print("%s frames %3d..%3d: queued %7d bricks (last frame) | per frame: all four quarters deferred yet queued %7.0f = no tile test %6.0f + may leave the image %6.0f + "
           "a pixel without depth %6.0f + surface within a truncation distance of the tiles' minimum %6.0f | one to three quarters deferred %7.0f" % (
               cfg, lo, hi, c.stats()["bricks_active"], lo32(a), hi32(a), lo32(b), hi32(b), lo32(m), hi32(m)))
