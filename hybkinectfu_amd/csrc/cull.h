@@ -166,6 +166,39 @@ __device__ __forceinline__ bool cull_test_cell(const IntegrateArgs& a, const flo
     }
   }
 #ifdef KF_EXPERIMENTS
+  // KF_INTEGRATE_EXP=17 (tools/exp_cull_deferred.py): what would an EXACT maximum / minimum of the depth image over the brick's pixel footprint drop or
+  // retire (the upper bound of what finer tile tables can give), and what a 4-pixel table level?  rc_steps lo: kept bricks; hi: dropped by the exact
+  // maximum; rc_hits lo: of the rest, retired by the exact minimum (all four quarters deferred); hi: dropped with 4-pixel tiles; mc_blocks lo: retired with them
+  if (KF_EXP_MODE(a) == 17 && keep) {
+    const unsigned sh = (unsigned)(lane & 63) * 16u;
+    atomicAdd(&a.cnt->rc_steps[sh], 1ull);
+    if (zn > 4.f * cell) {
+      const float xl = px - ex, xr = px + ex, yl = py - ey, yr = py + ey;
+      float u0 = (xl < 0.f ? xl / zn : xl / zf) * a.dcam.fx + a.dcam.cx, u1 = (xr > 0.f ? xr / zn : xr / zf) * a.dcam.fx + a.dcam.cx;
+      float w0 = (yl < 0.f ? yl / zn : yl / zf) * a.dcam.fy + a.dcam.cy, w1 = (yr > 0.f ? yr / zn : yr / zf) * a.dcam.fy + a.dcam.cy;
+      int ix0 = (int)floorf(u0 + (0.5f - KF_CULL_PX_SLACK)), ix1 = (int)floorf(u1 + (0.5f + KF_CULL_PX_SLACK));
+      int iy0 = (int)floorf(w0 + (0.5f - KF_CULL_PX_SLACK)), iy1 = (int)floorf(w1 + (0.5f + KF_CULL_PX_SLACK));
+      const bool all_inside = ix0 >= 1 && iy0 >= 1 && ix1 <= a.dcam.cols - 2 && iy1 <= a.dcam.rows - 2;
+      ix0 = max(ix0, 0); iy0 = max(iy0, 0); ix1 = min(ix1, a.dcam.cols - 1); iy1 = min(iy1, a.dcam.rows - 1);
+      if (ix0 <= ix1 && iy0 <= iy1 && (ix1 - ix0) < 64 && (iy1 - iy0) < 64) {
+        float dmax = 0.f, dmin = __builtin_huge_valf(), dmax4 = 0.f, dmin4 = __builtin_huge_valf();
+        for (int y = iy0; y <= iy1; ++y) for (int x = ix0; x <= ix1; ++x) {
+          const float dv = a.depth[y * a.dcam.cols + x]; const float g = dv < a.max_dist ? dv : 0.f;
+          dmax = fmaxf(dmax, g); dmin = fminf(dmin, g);
+        }
+        for (int y = iy0 & ~3; y <= min(iy1 | 3, a.dcam.rows - 1); ++y) for (int x = ix0 & ~3; x <= min(ix1 | 3, a.dcam.cols - 1); ++x) {
+          const float dv = a.depth[y * a.dcam.cols + x]; const float g = dv < a.max_dist ? dv : 0.f;
+          dmax4 = fmaxf(dmax4, g); dmin4 = fminf(dmin4, g);
+        }
+        const unsigned q0 = (unsigned)(pp & 0xFFFFull), q1 = (unsigned)((pp >> 16) & 0xFFFFull), q2 = (unsigned)((pp >> 32) & 0xFFFFull), q3 = (unsigned)(pp >> 48);
+        const bool alldef = DEFER && q0 && q1 && q2 && q3 && all_inside;
+        if (dmax == 0.f || zn >= dmax + a.sdf_trunc) atomicAdd(&a.cnt->rc_steps[sh], 1ull << 32);
+        else if (alldef && dmin > 0.f && dmin - zf >= a.sdf_trunc + eps) atomicAdd(&a.cnt->rc_hits[sh], 1ull);
+        if (dmax4 == 0.f || zn >= dmax4 + a.sdf_trunc) atomicAdd(&a.cnt->rc_hits[sh], 1ull << 32);
+        else if (alldef && dmin4 > 0.f && dmin4 - zf >= a.sdf_trunc + eps) atomicAdd(&a.cnt->mc_blocks[sh], 1ull);
+      }
+    }
+  }
   // KF_INTEGRATE_EXP=16 (tools/exp_cull_deferred.py): why are bricks whose quarters are in a deferred state still queued?  Counted per kept brick.
   if (DEFER && KF_EXP_MODE(a) == 16 && keep) {
     const unsigned q0 = (unsigned)(pp & 0xFFFFull), q1 = (unsigned)((pp >> 16) & 0xFFFFull), q2 = (unsigned)((pp >> 32) & 0xFFFFull), q3 = (unsigned)(pp >> 48);
