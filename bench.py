@@ -793,6 +793,8 @@ def main():
         out["per_rank"] = per_rank_leg(pipe, run, barrier, dist, world, rank, after_roofline, 20)
         out["lockstep"] = pipe.verify_lockstep()
         out["slab_migrations"] = [dict(frame=f, old=[list(r) for r in o], new=[list(r) for r in n], voxel_layers_moved_by_rank0=m) for f, o, n, m in pipe.migrations]
+        # plans that promised the gain threshold but would not have paid for their wire time before the next decision (pipeline.migration_pays)
+        out["slab_migrations_declined"] = [dict(frame=f, gain_ms=round(g * 1e3, 3), cost_ms=round(c * 1e3, 3)) for f, g, c in pipe.declined]
         if world > 1 and args.config == "auto" and not args.no_c5:
             # the north star quotes 1024^3 AND 2048^3 for 1/2/4/8 GPUs: a short C5 block (2048^3 @ 8 m, 1280x960 depth, mesh extraction) on the same ranks
             pipe.close()

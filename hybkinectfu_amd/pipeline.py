@@ -270,6 +270,23 @@ def plan_migration(old_ranges, new_ranges, halo, res):
     return sorted(plan, key=lambda t: (t[2], t[1], t[0]))
 
 
+def migration_pays(old_ranges, new_ranges, work, halo, res, frame_s, horizon_frames, shard_share=0.5, link_gbps=40.0):
+    """Does moving the slab boundaries pay for itself before the next decision?  Gain: the busiest rank's work drops from W_old to W_new, and
+    `shard_share` of a frame (fusion + slab raycast; the replicated tracker and the merge do not shrink) lasts as long as the busiest rank needs:
+    (1 - W_new / W_old) * shard_share * frame_s per frame, for `horizon_frames` frames.  Cost: the rank that receives the most voxel layers waits
+    for them -- res^2 voxels x 8 bytes per layer over one xGMI link (`link_gbps`; point-to-point, ~48 GB/s each way on MI355X, less in practice).
+    Returns (pays, gain_s, cost_s).  Pure: every rank computes the same verdict from the same (pooled) inputs."""
+    w_old, w_new = busiest_rank_work(old_ranges, work, halo), busiest_rank_work(new_ranges, work, halo)
+    if w_old <= 0.0 or w_new >= w_old:
+        return False, 0.0, 0.0
+    gain_s = (1.0 - w_new / w_old) * shard_share * frame_s * horizon_frames
+    received = [0] * len(old_ranges)
+    for (_, dst, z0, z1) in plan_migration(old_ranges, new_ranges, halo, res):
+        received[dst] += z1 - z0
+    cost_s = max(received) * float(res) * float(res) * 8.0 / (link_gbps * 1e9)
+    return gain_s > cost_s, gain_s, cost_s
+
+
 class SlabMigrator:
     """Moves voxel layers between ranks when the slab boundaries change (the xGMI exchange of boundary slabs the design needs: a long sequence
     that turns the camera shifts the work along z, and a frame lasts as long as the busiest rank needs).
@@ -317,7 +334,7 @@ class SlabPipeline:
     """
 
     def __init__(self, kcam, res, size, wl=None, rank=0, world=1, device=0, max_triangles=0, icp_mode="replicated", tracker="icp", ranges=None,
-                 rebalance_every=0, rebalance_gain=0.10, rebalance_sample=4):
+                 rebalance_every=0, rebalance_gain=0.10, rebalance_sample=4, link_gbps=40.0, shard_share=0.5):
         import torch
         import torch.distributed as dist
         self.icp_mode = icp_mode            # "replicated" (default, faster at VGA) or "allreduce" (pixels split over the ranks)
@@ -346,6 +363,7 @@ class SlabPipeline:
                                normals=lambda ta, cand: c.slab_ray_normals(None, self.inc, P["depth_trunc_min"], self.trunc_max, ta.data_ptr(), cand.data_ptr()),
                                unpack=lambda ta, cand: c.set_model_maps_rays(None, ta.data_ptr(), cand.data_ptr()))
         self.sums = torch.zeros(32, dtype=torch.float32, device=dev)
+        self._frame_ns, self._pooled_frame_s = 0, 0.0
         self._merge_events = None           # time_merge(True): (start, end) torch event pairs around every frame's merge
         # dynamic re-balancing of the slab boundaries: every `rebalance_every` frames the ranks pool the work per brick layer that the fusion pass
         # counted over the last `rebalance_sample` frames, re-run slab_ranges (deterministic: every rank computes the same boundaries) and, when the
@@ -353,6 +371,9 @@ class SlabPipeline:
         self.res, self.size, self.dev = int(res), float(size), dev
         self.rebalance_every, self.rebalance_gain, self.rebalance_sample = int(rebalance_every), float(rebalance_gain), max(1, int(rebalance_sample))
         self.migrations = []                # [(frame, old ranges, new ranges, voxel layers this rank sent or received)]
+        self.link_gbps, self.shard_share = float(link_gbps), float(shard_share)      # the cost side of a migration (migration_pays)
+        self._last_decision = None          # (wall clock, frame) of the previous re-balance decision: the frame time comes from there
+        self.declined = []                  # [(frame, gain_s, cost_s)] plans that would not have paid for themselves
         cpu_wire = world > 1 and dist.is_initialized() and dist.get_backend() == "gloo"       # rehearsals: gloo carries CPU tensors only
         self.migrator = SlabMigrator(dist, rank, world, self.res, self.halo, export=self._export_layers, import_=self._import_layers,
                                      resize=lambda z0, z1: c.resize_slab(z0, z1, self.halo),
@@ -384,23 +405,34 @@ class SlabPipeline:
         """work per brick layer of the WHOLE volume: every layer's count comes from the rank that owns it (a collective)"""
         import numpy as np
         torch, dist = self.torch, self.dist
-        mine = torch.from_numpy(self.ctx.read_layer_work(reset=True).astype(np.int64))
+        mine = torch.from_numpy(np.concatenate([self.ctx.read_layer_work(reset=True).astype(np.int64), [int(self._frame_ns)]]))    # (+ this rank's frame time: pooled too)
         if self.world == 1:
-            return mine.numpy().astype(np.float64)
+            self._pooled_frame_s = float(mine[-1]) * 1e-9
+            return mine.numpy()[:-1].astype(np.float64)
         on_dev = dist.get_backend() != "gloo"
         mine = mine.to(self.dev) if on_dev else mine
         every = [torch.zeros_like(mine) for _ in range(self.world)]
         dist.all_gather(every, mine)
         work = np.zeros(self.res // 8, np.float64)
+        every = [e.cpu().numpy() for e in every]
         for r, (a, b) in enumerate(self.ranges):
-            work[a // 8:b // 8] = every[r].cpu().numpy()[a // 8:b // 8]
+            work[a // 8:b // 8] = every[r][a // 8:b // 8]
+        self._pooled_frame_s = max(float(e[-1]) for e in every) * 1e-9           # the slowest rank's: the same number on every rank
         return work
 
     def rebalance(self, frame_id=-1, force_ranges=None):
         """A collective: pool the sampled work per brick layer, compute the boundaries that minimise the busiest rank and migrate when that
         pays (or to `force_ranges`, tests).  Returns the new ranges when layers moved, else None."""
+        import time
         with self.torch.cuda.stream(self.stream):
+            # the frame time since the previous decision (wall clock between two synchronised points), pooled with the work: the slowest rank's counts
+            self.sync()
+            now = time.perf_counter()
+            self._frame_ns = 0
+            if self._last_decision is not None and frame_id > self._last_decision[1]:
+                self._frame_ns = int((now - self._last_decision[0]) / (frame_id - self._last_decision[1]) * 1e9)
             work = self.pooled_layer_work()
+            self._last_decision = (time.perf_counter(), frame_id)
             old = list(self.ranges)
             if force_ranges is not None:
                 new = [tuple(r) for r in force_ranges]
@@ -410,6 +442,12 @@ class SlabPipeline:
                 new = slab_ranges(self.res, self.world, work.tolist(), halo=self.halo)
                 if busiest_rank_work(new, work.tolist(), self.halo) > (1.0 - self.rebalance_gain) * busiest_rank_work(old, work.tolist(), self.halo):
                     return None
+                if self._pooled_frame_s > 0.0 and self.rebalance_every > 0:          # (no frame time yet -- the first decision -- : the gain threshold alone decides)
+                    pays, gain_s, cost_s = migration_pays(old, new, work.tolist(), self.halo, self.res, self._pooled_frame_s, self.rebalance_every,
+                                                          self.shard_share, self.link_gbps)
+                    if not pays:
+                        self.declined.append((frame_id, gain_s, cost_s))
+                        return None
             if new == old:
                 return None
             self.sync()

@@ -174,6 +174,30 @@ def test_balanced_slab_ranges_minimise_the_busiest_rank():
         PL.slab_ranges(64, 9)
 
 
+def test_a_migration_must_pay_for_itself():
+    """pipeline.migration_pays: moving the boundaries costs the wire time of the layers the busiest receiver waits for and gains the busiest rank's
+    work reduction on the part of a frame that shards, over the frames until the next decision.  The 1024^3 oscillation seen in a 4-rank rehearsal
+    (88 layers of 8 MiB each for a 20 % gain over 20 frames of 0.35 ms) must be declined; the same plan over a long horizon, or on a volume whose
+    layers are small, goes through; a plan that gains nothing never pays."""
+    from hybkinectfu_amd import pipeline as PL
+    res, halo = 1024, 8
+    a = [(0, 320), (320, 448), (448, 592), (592, 1024)]
+    b = [(0, 408), (408, 544), (544, 672), (672, 1024)]
+    nb = res // 8
+    work = [0.0] * nb
+    for L in range(0, 84):                       # the work sits in layers 0 .. 84 x 8: plan b spreads it better than plan a would for a shifted camera
+        work[L] = 1.0
+    for L in range(40, 70):
+        work[L] = 3.0
+    better, worse = (a, b) if PL.busiest_rank_work(a, work, halo) < PL.busiest_rank_work(b, work, halo) else (b, a)
+    pays, gain_s, cost_s = PL.migration_pays(worse, better, work, halo, res, frame_s=0.35e-3, horizon_frames=20)
+    assert gain_s > 0 and cost_s > 10e-3 and not pays                       # ~0.7 GB over one link: tens of milliseconds against a millisecond of gain
+    assert PL.migration_pays(worse, better, work, halo, res, frame_s=0.35e-3, horizon_frames=200000)[0]
+    assert PL.migration_pays([(0, 96), (96, 128)], [(0, 64), (64, 128)], [4.0] * 4 + [1.0] * 12, 0, 128, frame_s=0.2e-3, horizon_frames=50)[0]   # 128^3: 128 KiB per layer
+    assert PL.migration_pays(better, worse, work, halo, res, frame_s=0.35e-3, horizon_frames=10**9) == (False, 0.0, 0.0)
+    assert PL.migration_pays(a, a, work, halo, res, frame_s=1.0, horizon_frames=100) == (False, 0.0, 0.0)
+
+
 # ---- dynamic slab boundaries: layers change their owner over the wire ---------------------------------------------------------------------------
 def test_migration_plan_covers_exactly_what_a_rank_lacks():
     """plan_migration: every layer of a rank's NEW stored range (own + halo) that it did not store before arrives exactly once, from the rank that
