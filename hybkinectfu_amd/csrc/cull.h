@@ -3,7 +3,9 @@
 // Reference: the update predicate of integrateKernel, src/cuda/integrateVolume.cu:39-67 -- a brick is dropped only when no voxel of it can pass it.
 #pragma once
 #include "kf_internal.h"
+#ifndef KF_CULL_PX_SLACK
 #define KF_CULL_PX_SLACK 0.0625f          // pixels: see cull_test_cell
+#endif
 
 struct IntegrateArgs {
   KfVolume vol;

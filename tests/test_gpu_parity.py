@@ -146,6 +146,43 @@ def test_integrate_raycast_mc_bit_exact(res, size, cam, trunc):
     ctx.close()
 
 
+@pytest.mark.parametrize("res,px_per_voxel,z_plane", [(64, 1.0, 1.0), (64, 2.0, 1.5), (96, 0.5, 1.0), (128, 4.0, 2.0)])
+def test_integrate_with_voxels_projecting_onto_pixel_boundaries(res, px_per_voxel, z_plane):
+    """The cull keeps a brick for the pixels floor(u0 + 0.5 - 1/16) .. floor(u1 + 0.5 + 1/16) its voxels can land on -- no spare pixel on either side
+    (cull.h).  Adversarial geometry for that: a camera looking straight down +z whose focal length makes voxel centres of one depth plane project
+    EXACTLY onto pixel boundaries (u + 0.5 an integer: the fusion kernel's floor and the cull's bound meet at a tie), a depth image that changes from
+    pixel to pixel (so a wrong pixel changes the verdict), several truncation distances and integration distances.  N_upd and every voxel bit must
+    equal the oracle's, which visits every voxel."""
+    size = 2.0
+    cell = size / res
+    cols, rows = 96, 80
+    f = px_per_voxel * z_plane / cell                      # a voxel step at depth z_plane is px_per_voxel pixels: centres at (i + 0.5) steps -> half-pixel positions
+    cam = (cols, rows, cols / 2.0, rows / 2.0, f, f)       # integer principal point: u + 0.5 = (i + 0.5) * px_per_voxel + cx + 0.5
+    ocam, kcam = O.Cam.make(*cam), K.camera(*cam)
+    rng = np.random.default_rng(res)
+    pose = np.eye(4, dtype=np.float32)
+    pose[0, 3] = size / 2; pose[1, 3] = size / 2; pose[2, 3] = -(z_plane - size / 2)      # the plane z_plane in front of the camera is the volume's mid plane
+    # depth: constant over each 8 x 8 pixel tile (the cull's table granularity), unrelated from tile to tile -- no depth at all, in front of the mid
+    # plane, behind it, out of reach -- so a brick whose last pixel column is missed reads the wrong tile and decides wrongly; + pixel noise
+    tiles = rng.integers(0, 4, (rows // 8, cols // 8))
+    per_tile = np.choose(tiles, [0.0, z_plane - 3.3 * cell, z_plane + 2.7 * cell, z_plane + 40.0 * cell]).astype(np.float32)
+    depth = np.kron(per_tile, np.ones((8, 8), np.float32))
+    depth = np.where(depth > 0, depth + rng.uniform(-0.4, 0.4, (rows, cols)).astype(np.float32) * cell, 0.0).astype(np.float32)
+    normals = np.zeros((rows, cols, 4), np.float32); normals[..., 2] = -1.0
+    for trunc, dist in ((2.5 * cell, 10.0), (5.0 * cell, z_plane + 1.1 * cell), (1.01 * cell, 10.0)):
+        ctx = K.Context(kcam, res, size, P["volume_max_weight"], levels=3)
+        ovol = O.OVolume(res, size, P["volume_max_weight"])
+        ctx.upload_map(K.MAP_TRUNCED_DEPTH, 0, depth)
+        for shift in (0.0, 0.25 * cell, -0.5 * cell):      # the tie itself, and poses a fraction of a voxel off it
+            p2 = pose.copy(); p2[0, 3] += shift; p2[1, 3] -= shift
+            n_o = O.integrate(ovol, depth, normals, None, False, False, p2, trunc, dist, ocam, ocam)
+            ctx.integrate(p2, trunc, dist)
+            assert ctx.stats()["updated_last"] == n_o and n_o > 1000, (res, px_per_voxel, trunc, dist, shift, n_o)
+        t, w = ctx.download_volume()
+        assert np.array_equal(bits(t), bits(ovol.tsdf)) and np.array_equal(bits(w), bits(ovol.weight))
+        ctx.close()
+
+
 def test_triangle_cap():
     ctx, ovol, pose, ocam = _fuse_sequence(32, 3.0, small_cam(), 2, 0.2, 2.5)
     thr = 300 * 3.0 / 32
