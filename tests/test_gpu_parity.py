@@ -326,6 +326,39 @@ def test_icp_lost_keeps_pose():
     ctx.close()
 
 
+@pytest.mark.parametrize("cam", [mid_cam(), S.vga_camera()])
+def test_icp_on_a_single_plane_is_lost_by_the_determinant_test_on_both_sides(cam):
+    """A frame that sees nothing but one fronto-parallel plane constrains three of the six degrees of freedom: every row of the system is
+    (-y, x, 0, 0, 0, -1) . (rotation, translation), so three rows and columns of J^T J are EXACTLY zero.  The reference gives the frame up at its
+    determinant test (ICP.cpp:138, determinant 0 < 1e-10); here the determinant is the product of the Cholesky pivots and a pivot <= 0 counts as
+    singular (llt_solve6_wave): the same verdict, status 1, no Gauss-Newton step applied, pose untouched -- in the persistent loop and, with a
+    second context alive, in the per-step form."""
+    cols, rows = cam[0], cam[1]
+    ocam = O.Cam.make(*cam)
+    yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
+    z = np.float32(1.5)
+    v = np.zeros((rows, cols, 4), np.float32)
+    v[..., 0] = (xx - cam[2]) / cam[4] * z; v[..., 1] = (yy - cam[3]) / cam[5] * z; v[..., 2] = z; v[..., 3] = 1.0
+    n = np.zeros((rows, cols, 4), np.float32); n[..., 2] = -1.0
+    pose = np.eye(4, dtype=np.float32)
+    nv, nn = O.pyramid(v, 3), O.pyramid(n, 3, normals=True)
+    ok_o, pose_o = O.icp_estimate(nv, nn, nv, nn, ocam, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"], pose)
+    assert not ok_o and np.array_equal(pose_o, pose)
+    for second_context in (False, True):
+        other = K.Context(K.camera(*small_cam()), 32, 3.0, levels=3) if second_context else None
+        ctx = K.Context(K.camera(*cam), 64, 3.0, levels=3)
+        ctx.set_pose(pose)
+        for m_v, m_n in ((K.MAP_NEW_VERTICES, K.MAP_NEW_NORMALS), (K.MAP_MODEL_VERTICES, K.MAP_MODEL_NORMALS)):
+            ctx.upload_map(m_v, 0, v); ctx.upload_map(m_n, 0, n)
+        ctx.icp_track(1, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
+        ok_g, pose_g, status, iters = ctx.track_result()
+        assert not ok_g and status == 1 and iters == 0 and np.array_equal(pose_g, pose), (second_context, ok_g, status, iters)
+        assert ctx.last_form == (2 if second_context else 1)
+        ctx.close()
+        if other is not None:
+            other.close()
+
+
 def test_sdf_system_and_track():
     size, res, cam, trunc = 3.0, 64, mid_cam(), 5 * 3.0 / 64
     ctx, ovol, pose, nxt, ocam, (v, n, ov, on, tr) = _tracking_case(res, size, cam, trunc, n_warm=3)
