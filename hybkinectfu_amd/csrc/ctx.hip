@@ -322,7 +322,13 @@ static int upload_into_next_slot(kf_ctx* c, const uint16_t* host_mm, uint32_t co
 // a kernel that reads `dev_mm` is about to be enqueued on the context's stream: if that is an upload slot whose copy the stream has not waited for, it does now
 int kf_upload_wait_for(kf_ctx* c, const uint16_t* dev_mm) {
   for (int i = 0; i < KF_UP_SLOTS; ++i)
-    if (c->up_unwaited[i] && dev_mm == c->up_dev[i]) { KF_CHECK(hipStreamWaitEvent(c->stream, c->up_copied[i], 0)); c->up_unwaited[i] = 0; }
+    if (c->up_unwaited[i] && dev_mm == c->up_dev[i]) {
+      // a frame staged two ahead has usually crossed PCIe by now: then there is nothing for the stream to wait for, and no barrier packet goes into it
+      const hipError_t q = hipEventQuery(c->up_copied[i]);
+      if (q == hipErrorNotReady) KF_CHECK(hipStreamWaitEvent(c->stream, c->up_copied[i], 0));
+      else if (q != hipSuccess) return (int)q;
+      c->up_unwaited[i] = 0;
+    }
   return 0;
 }
 extern "C" int kf_upload_depth_mm(kf_ctx* c, const uint16_t* host_mm, uint32_t cols, uint32_t rows) {
