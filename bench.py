@@ -99,14 +99,18 @@ def cpu_baseline(wl, frames_mm, n_sample=150, witness=None):
     wit = None
     if witness is not None:
         gpu_pose, gpu_n_upd, gpu_tracked = witness
+        from hybkinectfu_amd import posemath as PM
         gp, op = np.asarray(gpu_pose, np.float64).reshape(4, 4), np.asarray(pose, np.float64).reshape(4, 4)
-        dr = gp[:3, :3].T @ op[:3, :3]
-        ang = float(np.arccos(np.clip((np.trace(dr) - 1.0) / 2.0, -1.0, 1.0)))
+        # angle from the skew part of Rg^T Ro after projecting both blocks onto SO(3) (posemath.rotation_angle): the composed fp32 poses sit
+        # ~1e-6 off orthonormal, which arccos of the trace reads as ~2e-3 "rad" (VERDICT r4 / BENCH_r04's false `false`)
+        d_t, ang, d_el = PM.pose_difference(gp, op)
         n_o = O.integrate(vol, tr, n, None, False, False, np.asarray(gpu_pose, np.float32), P["integrate_sdf_trunc"], wl["integ_dist"], ocam, ocam)
-        d_t = float(np.linalg.norm(gp[:3, 3] - op[:3, 3]))
         wit = dict(frame=n_sample - 1, frames_tracked_by_both=n_sample - 1, oracle_tracked=bool(ok), gpu_tracked=bool(gpu_tracked),
-                   pose_translation_diff_m=d_t, pose_rotation_diff_rad=ang, tolerance="1e-4 m / 1e-4 rad (BASELINE.json north_star)",
-                   pose_within_tolerance=bool(ok and gpu_tracked and d_t <= 1e-4 and ang <= 1e-4),
+                   pose_translation_diff_m=d_t, pose_rotation_diff_rad=ang, pose_rotation_max_element_diff=d_el,
+                   rotation_metric="atan2(|vee(D - D^T)|/2, (tr D - 1)/2), D = Rg^T Ro, both blocks projected to SO(3) (hybkinectfu_amd/posemath.py)",
+                   orthonormality_defect_gpu=PM.orthonormality_defect(gp[:3, :3]), orthonormality_defect_oracle=PM.orthonormality_defect(op[:3, :3]),
+                   tolerance="1e-4 m / 1e-4 rad (BASELINE.json north_star)",
+                   pose_within_tolerance=bool(ok and gpu_tracked and d_t <= 1e-4 and ang <= 1e-4 and d_el <= 1e-4),
                    n_upd_gpu=int(gpu_n_upd), n_upd_oracle_with_gpu_pose=int(n_o), n_upd_equal=bool(int(gpu_n_upd) == int(n_o)),
                    note="the HIP path and the oracle each tracked and fused the same %d frames on their own (the cpu_baseline leg); poses compared at the "
                         "last frame, and the oracle's count of voxels passing the update predicate for that frame under the GPU's pose against the GPU's "
@@ -379,7 +383,11 @@ def profiled_traffic(key):
     """HBM-side bytes per launch from the builder's rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, profiles/integrate_traffic.json), or None"""
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "integrate_traffic.json")))
-        return tj.get(key), tj.get("source")
+        src = tj.get("source") or ""
+        cited = src.split(":", 1)[0].strip()
+        if cited.startswith("profiles/") and not os.path.exists(os.path.join(ROOT, cited)):
+            src = "(cited file %s is missing from the tree) %s" % (cited, src)       # a provenance pointer must resolve (ADVICE r4)
+        return tj.get(key), src
     except Exception:
         return None, None
 
@@ -841,6 +849,8 @@ def main():
         pipe.close()
         n_sample = 150 if wl["res"] <= 512 else 40                                    # 10-20 s of CPU work either way
         out["cpu_baseline"], out["parity_witness"] = cpu_baseline(wl, frames, n_sample=n_sample, witness=gpu_witness_run(wl, frames, n_sample))
+        # top level, so that a failing witness cannot hide in a nested block (BENCH_r04 said `false` and nobody noticed)
+        out["parity_witness_ok"] = bool(out["parity_witness"]["pose_within_tolerance"] and out["parity_witness"]["n_upd_equal"])
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
