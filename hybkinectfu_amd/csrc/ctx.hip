@@ -32,10 +32,13 @@ int kf_live_contexts(int device) { return (device >= 0 && device < 64) ? __atomi
 #include <mutex>
 #define KF_SHM_SLOTS 16
 static std::mutex g_reg_mutex;
-static int g_slot_fd[64];                     // this process's slot file per device (0: none; fds are > 2)
+// (slot fd + 1 per device, so that the zero-initialised array means "none" and fd 0 -- a daemon with stdin closed -- is a valid slot)
+static int g_slot_fd1[64];
 static int g_slot_idx[64];
 static int g_shared_cached[64];
 static unsigned g_shared_calls[64];
+static pid_t g_reg_pid;                       // the process the slots were taken in: a fork()ed child inherits the open file descriptions -- and with them
+                                              // the PARENT's locks, which are not its own to hold: it drops them on first use and registers for itself
 static bool slot_path(int device, int slot, char* out, size_t n) {
   char bus[64] = {0};
   if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, device) != hipSuccess) return false;
@@ -43,27 +46,40 @@ static bool slot_path(int device, int slot, char* out, size_t n) {
   snprintf(out, n, "/dev/shm/hybkf_%u_%s.%d", (unsigned)getuid(), bus, slot);
   return true;
 }
+static void shm_after_fork_check() {                         // (under g_reg_mutex)
+  const pid_t me = getpid();
+  if (g_reg_pid == me) return;
+  if (g_reg_pid != 0)                                        // a child of the registering process: the inherited descriptors share the parent's lock -- only close them
+    for (int d = 0; d < 64; ++d) if (g_slot_fd1[d] > 0) { close(g_slot_fd1[d] - 1); g_slot_fd1[d] = 0; g_shared_cached[d] = 0; }
+  g_reg_pid = me;
+}
 static void shm_register(int device) {                       // (under g_reg_mutex)
-  if (device < 0 || device >= 64 || g_slot_fd[device] > 0) return;
+  shm_after_fork_check();
+  if (device < 0 || device >= 64 || g_slot_fd1[device] > 0) return;
   char path[160];
   for (int s = 0; s < KF_SHM_SLOTS; ++s) {
     if (!slot_path(device, s, path, sizeof(path))) return;
     const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0600);
     if (fd < 0) return;
-    if (flock(fd, LOCK_EX | LOCK_NB) == 0) { g_slot_fd[device] = fd; g_slot_idx[device] = s; g_shared_calls[device] = 0; return; }
+    if (flock(fd, LOCK_EX | LOCK_NB) == 0) { g_slot_fd1[device] = fd + 1; g_slot_idx[device] = s; g_shared_calls[device] = 0; return; }
     close(fd);
   }
 }
 static void shm_unregister(int device) {                     // (under g_reg_mutex)
-  if (device < 0 || device >= 64 || g_slot_fd[device] <= 0) return;
-  flock(g_slot_fd[device], LOCK_UN); close(g_slot_fd[device]);
-  g_slot_fd[device] = 0; g_shared_cached[device] = 0;
+  shm_after_fork_check();
+  if (device < 0 || device >= 64 || g_slot_fd1[device] <= 0) return;
+  flock(g_slot_fd1[device] - 1, LOCK_UN); close(g_slot_fd1[device] - 1);
+  g_slot_fd1[device] = 0; g_shared_cached[device] = 0;
 }
 // does another live process of this library hold a context on `device`?
 int kf_device_shared(int device) {
   if (device < 0 || device >= 64) return 0;
   std::lock_guard<std::mutex> lock(g_reg_mutex);
-  if (g_slot_fd[device] <= 0) return 0;
+  if (g_reg_pid != 0 && g_reg_pid != getpid()) {             // first question after a fork(): this process holds no slot of its own yet
+    shm_after_fork_check();
+    if (__atomic_load_n(&g_live_ctx[device], __ATOMIC_RELAXED) > 0) shm_register(device);
+  }
+  if (g_slot_fd1[device] <= 0) return 0;
   if ((g_shared_calls[device]++ & 255u) != 0u) return g_shared_cached[device];
   int others = 0;
   char path[160];
@@ -287,6 +303,19 @@ int kf_materialize_raw_depth(kf_ctx* c) {
   return st ? st : kf_pending_depth_consumed(c);
 }
 
+// An upload slot is given up without its frame ever having been taken and preprocessed (frames staged ahead that a kf_upload_depth_mm drops; a slot that comes
+// round again while a kf_prefetch_frame request still names it): up_consumed[slot] -- which the next DMA into the slot waits for -- was last recorded when the
+// slot's PREVIOUS frame was consumed, but a reader of THIS frame (the prefetch's filter riding in a tracking or raycast launch) may still be queued on the
+// context's stream.  Record the event where the stream stands now (everything enqueued so far precedes the refill) and void what was derived from the frame.
+static int up_slot_abandon(kf_ctx* c, int slot) {
+  if (slot < 0 || slot >= KF_UP_SLOTS || !c->up_used[slot]) return 0;
+  KF_CHECK(hipEventRecord(c->up_consumed[slot], c->stream));
+  const uint16_t* dev = c->up_dev[slot];
+  if (c->fp_src == dev) { c->fp_pending = 0; c->fp_filtered = 0; c->fp_done = 0; }
+  if (c->prefetch_src == dev) c->prefetch_valid = 0;
+  c->up_unwaited[slot] = 0;
+  return 0;
+}
 // pinned staging -> DMA on the copy stream -> device slot `*slot_out`.  Three slots in rotation: the current frame and up to two staged ahead.
 // wait_now: the context's stream waits for the copy at once (the frame is used next); otherwise whoever first reads the slot on that stream
 // asks for the wait (kf_upload_wait_for) -- a frame staged two ahead has crossed PCIe long before anything reads it.
@@ -305,6 +334,10 @@ static int upload_into_next_slot(kf_ctx* c, const uint16_t* host_mm, uint32_t co
   }
   const int p = c->up_next; c->up_next = (p + 1) % KF_UP_SLOTS;
   if (c->pending_slot == p) c->pending_slot = -1;            // the frame uploaded three calls ago was never consumed: it is being replaced
+  if (c->up_used[p] && (c->up_unwaited[p] || (c->fp_pending && c->fp_src == c->up_dev[p]) || (c->prefetch_valid && c->prefetch_src == c->up_dev[p]))) {
+    const int st = up_slot_abandon(c, p);                    // still referenced by a staged copy / a prefetch nobody picked up: its readers first
+    if (st) return st;
+  }
   if (c->up_used[p]) {
     KF_CHECK(hipEventSynchronize(c->up_copied[p]));           // the pinned buffer's previous DMA (three uploads ago: long finished)
     KF_CHECK(hipStreamWaitEvent(c->up_stream, c->up_consumed[p], 0));   // the device buffer's last reader
@@ -335,7 +368,8 @@ extern "C" int kf_upload_depth_mm(kf_ctx* c, const uint16_t* host_mm, uint32_t c
   int p = -1;
   const int st = upload_into_next_slot(c, host_mm, cols, rows, true, &p);
   if (st) return st;
-  c->n_staged = 0;                                           // frames staged behind the one this call replaces are dropped with it
+  for (int i = 0; i < c->n_staged; ++i) { const int ds = up_slot_abandon(c, c->staged[i]); if (ds) return ds; }   // frames staged behind the one this call replaces are dropped with it
+  c->n_staged = 0;
   c->pending_mm = c->up_dev[p]; c->pending_slot = p;
   return 0;
 }

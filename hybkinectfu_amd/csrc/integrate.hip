@@ -577,6 +577,22 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
       }
     }
 #endif
+#ifdef KF_EXPERIMENTS
+    // lane census (KF_INTEGRATE_EXP=17, tools/exp_lane_census.py): of a queued brick's 256 pair lanes, how many load their 16 bytes, how many of those update
+    // ONE voxel of the pair and how many both -- what the fetched bytes are made of (FETCH 1.7 x the algorithmic read bytes at C2)
+    if (KF_EXP_MODE(a) == 17) {
+#pragma unroll
+      for (int b = 0; b < BR; ++b) {
+        const unsigned long long m_any = __ballot(upd0[b] || upd1[b]), m_both = __ballot(upd0[b] && upd1[b]);
+        if (q0 + b < n_active && (threadIdx.x & 63) == 0) {
+          const unsigned sh = (blockIdx.x & 63) * 16;
+          atomicAdd(&a.cnt->rc_steps[sh], (unsigned long long)__popcll(m_any) | (1ull << 32));                        // low: lanes that load; high: waves
+          atomicAdd(&a.cnt->rc_hits[sh], (unsigned long long)__popcll(m_both) | ((m_any ? 1ull : 0ull) << 32));     // low: lanes with both voxels; high: waves that load anything
+          atomicAdd(&a.cnt->mc_blocks[sh], (m_any == ~0ull ? 1ull : 0ull) | ((m_any && m_any != ~0ull ? 1ull : 0ull) << 32));   // low: waves whose 64 lanes all load; high: partial waves
+        }
+      }
+    }
+#endif
     // one 16-byte read-modify-write per lane and brick, only where a voxel of the pair passed; the loads go out together
     float4* p[BR]; float4 q[BR]; bool rw[BR];
 #pragma unroll

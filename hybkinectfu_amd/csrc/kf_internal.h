@@ -94,6 +94,10 @@ struct KfTrackState {
   int      rescued;      // the committed verdict of the last tracking call comes from that solo finish (kf_track_result::launch_form 3)
   unsigned pad_[1];
   float pose_inv[16];    // pose.getInverse(), written wherever pose is committed: integrate reads it (integrateVolume.cu:84)
+  // who ends a persistent tracking launch (track.hip: k_sdf_loop): tag_base | 1 the launch's own workgroups (workgroup 0 commits, each runs its share of the
+  // tail), tag_base | 2 ONE workgroup that claimed the launch after a time-out (it commits and runs every share); any other upper bits: an older launch's
+  // word, i.e. open.  Set by compare-and-swap, so exactly one of the two parties ends a launch.
+  unsigned commit_word;
 };
 
 // software grid barrier of the persistent ICP loop: every word on its own 128-byte line
@@ -179,6 +183,7 @@ struct kf_ctx {
   int loop_refused;                   // the device cannot hold the loop's workgroups at once (occupancy check / cooperative launch refused): never tried again
   int loop_occupancy;                 // workgroups of k_icp_loop one CU can hold (0: not asked yet)
   int loop_occupancy_batched;         // the same for k_icp_loop_batched
+  int sdf_loop_occupancy;             // the same for k_sdf_loop (the addressing variant this volume uses)
   int last_track_form;                // kf_track_result::launch_form of the last tracking call
   KfTrackState* track;                // device
   KfCounters* counters;               // device

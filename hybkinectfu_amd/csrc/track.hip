@@ -23,11 +23,12 @@
 #include "kf_internal.h"
 #include "cull.h"
 #include "bilateral_tile.h"
+#include "sdf_rows.h"
 #include <string.h>
 #include <stdlib.h>
 
 #define TRK_THREADS 256
-#define TRK_PX 4                   // pixels per lane of the SDF step (grid-stride beyond that): 13 dependent lookups per pixel want many waves, not long lanes
+#define TRK_PX 2                   // 8x8 tiles per wave of the SDF step (grid-stride beyond that): the lookups want many waves, not long lanes
 
 struct TrackArgs {
   const float4* new_v; const float4* new_n; const float4* model_v; const float4* model_n;
@@ -1132,14 +1133,8 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop_batched(IcpLoopArgs L)
 }
 
 // ---- SDF tracker ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(TRK_THREADS) k_sdf_step(TrackArgs a) {
-  __shared__ float s_m[7][16];                 // cur, then delta*cur for +w1,-w1,+w2,-w2,+w3,-w3 (CalSDFErrSolverParams.cu:118-133)
-  __shared__ float s_linv[16];
-  __shared__ float s_wave[27 * (TRK_THREADS / 16)], s_tot[32 * 32];
-  __shared__ int s_code;
-  if (!step_prologue(a, s_m[0], s_linv, s_tot, &s_code)) return;
-  const float w_h = 0.001f;                                               // :119 `float w_h = 0.001;`
-  const float v_h = a.vol.size / (float)a.vol.res;                        // :120
+// the six perturbed transforms delta * cur for +w1, -w1, +w2, -w2, +w3, -w3 (CalSDFErrSolverParams.cu:118-133) into s_m[1..6]; s_m[0] = cur.  96 lanes.
+__device__ __forceinline__ void sdf_perturbed_transforms(float (*s_m)[16], float w_h) {
   if (threadIdx.x < 96) {
     const int mi = threadIdx.x >> 4, e = threadIdx.x & 15, r = e >> 2, cidx = e & 3;
     const int axis = mi >> 1; const float sg = (mi & 1) ? -1.f : 1.f;     // second matrix of a pair flips the sign
@@ -1149,60 +1144,279 @@ __global__ void __launch_bounds__(TRK_THREADS) k_sdf_step(TrackArgs a) {
     else { if (r == 0) d[1] = -sg * w_h; if (r == 1) d[0] = sg * w_h; }                    // m12 = -w, m21 = +w
     s_m[1 + mi][e] = d[0] * s_m[0][cidx] + d[1] * s_m[0][4 + cidx] + d[2] * s_m[0][8 + cidx] + d[3] * s_m[0][12 + cidx];
   }
+}
+// one pixel into the 27 running sums (computeSDFSolverbufKernel, CalSDFErrSolverParams.cu:68-108: row[i] * row[j], i <= j); d = 0: no depth, no row
+template <typename AD>
+__device__ __forceinline__ void sdf_accumulate_pixel(const KfVolume& vol, const AD& S, const float (*s_m)[16], const KfCam& cam, int i, float d, float w_h, float v_h,
+                                                     const KfRecip& rS, float rcell, bool slab, float acc[27]) {
+  const float3 p = kf_depth_to_skeleton((unsigned)(i % cam.cols), (unsigned)(i / cam.cols), d, cam);
+  float row[7];
+  const bool ok = sdf_pixel_row<AD>(vol, S, s_m, p, w_h, v_h, rS, rcell, slab, row) && d != 0.f;
+  if (!ok) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) row[k] = 0.f;                            // (a rejected pixel adds +0.0 twenty-seven times: the sums keep their bits)
+  }
+  int s = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = r; c < 7; ++c) { acc[s] = __builtin_fmaf(row[r], row[c], acc[s]); ++s; }
+}
+template <typename AD>
+__global__ void __launch_bounds__(TRK_THREADS) k_sdf_step(TrackArgs a) {
+  __shared__ float s_m[7][16];                 // cur, then delta*cur for +w1,-w1,+w2,-w2,+w3,-w3 (CalSDFErrSolverParams.cu:118-133)
+  __shared__ float s_linv[16];
+  __shared__ float s_wave[27 * (TRK_THREADS / 16)], s_tot[32 * 32];
+  __shared__ int s_code;
+  if (!step_prologue(a, s_m[0], s_linv, s_tot, &s_code)) return;
+  const float w_h = 0.001f;                                               // :119 `float w_h = 0.001;`
+  const float v_h = a.vol.size / (float)a.vol.res;                        // :120
+  sdf_perturbed_transforms(s_m, w_h);
   __syncthreads();
   float acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.f;
-  const int npx = a.cam.cols * a.cam.rows;
-  const KfRecip rS = kf_recip(a.vol.size), rcell = kf_recip(a.vol.cell);
-  for (int i = blockIdx.x * TRK_THREADS + threadIdx.x; i < npx; i += gridDim.x * TRK_THREADS) {
-    const float d = a.depth[i];
-    if (d == 0.f) continue;
-    const float3 p = kf_depth_to_skeleton((unsigned)(i % a.cam.cols), (unsigned)(i / a.cam.cols), d, a.cam);
-    const float4 p4 = make_float4(p.x, p.y, p.z, 1.0f);
-    // buildSDFSolverRows (:7-66): all 13 lookups must succeed
-    // The reference's early-outs are pure, so looking two positions up together (16 gathers in flight instead of 8) and
-    // testing their verdicts in the reference's order is equivalent: 7 dependent round trips per pixel instead of 13.
-    float sdf0, sw[6], sv[6];
-    const float4 pw0 = kf_mat_vec(s_m[0], p4);
-    if (a.slab_pixels) {
-      // z-slabs: a pixel belongs to the slab that owns the voxel of its world point; every rank sums its own
-      // pixels and the 27-float systems are all-reduced.  The 13 lookups reach at most the halo (kf_sdf_partition_step checks it).
-      const int gz = kf_world_to_voxel(a.vol, kf3(pw0.x, pw0.y, pw0.z)).z;
-      if (gz < a.vol.own_z0 || gz >= a.vol.own_z1) continue;
-    }
-    bool ok = kf_interpolate_sdf(a.vol, kf3(pw0.x, pw0.y, pw0.z), sdf0);
-#pragma unroll
-    for (int k = 0; k < 6; k += 2) {
-      if (!ok) break;
-      const float4 pa = kf_mat_vec(s_m[1 + k], p4), pb = kf_mat_vec(s_m[2 + k], p4);
-      bool oa, ob;
-      kf_interpolate_sdf_pair(a.vol, kf3(pa.x, pa.y, pa.z), kf3(pb.x, pb.y, pb.z), rS, rcell, oa, sw[k], ob, sw[k + 1]);
-      ok = oa && ob;
-    }
-#pragma unroll
-    for (int k = 0; k < 6; k += 2) {
-      if (!ok) break;
-      float3 qa = kf3(pw0.x, pw0.y, pw0.z), qb = qa;
-      if ((k >> 1) == 0) { qa.x = pw0.x + v_h; qb.x = pw0.x - v_h; }
-      else if ((k >> 1) == 1) { qa.y = pw0.y + v_h; qb.y = pw0.y - v_h; }
-      else { qa.z = pw0.z + v_h; qb.z = pw0.z - v_h; }
-      bool oa, ob;
-      kf_interpolate_sdf_pair(a.vol, qa, qb, rS, rcell, oa, sv[k], ob, sv[k + 1]);
-      ok = oa && ob;
-    }
-    if (!ok) continue;
-    float row[7];
-    row[0] = (sw[0] - sw[1]) / (2 * w_h); row[1] = (sw[2] - sw[3]) / (2 * w_h); row[2] = (sw[4] - sw[5]) / (2 * w_h);
-    row[3] = (sv[0] - sv[1]) / (2 * v_h); row[4] = (sv[2] - sv[3]) / (2 * v_h); row[5] = (sv[4] - sv[5]) / (2 * v_h);
-    row[6] = sdf0;
-    int s = 0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int c = r; c < 7; ++c) { acc[s] = __builtin_fmaf(row[r], row[c], acc[s]); ++s; }
+  const KfRecip rS = kf_recip(a.vol.size);
+  const float rcell = 1.0f / a.vol.cell;
+  const AD S(a.vol);
+  // a wave takes 8x8 pixel tiles (see k_sdf_loop: a compact footprint in the volume = few cache lines per gather instruction), grid-stride over the tiles
+  const int tiles_x = (a.cam.cols + 7) >> 3, n_tiles = tiles_x * ((a.cam.rows + 7) >> 3);
+  for (int tile = (int)blockIdx.x * (TRK_THREADS / 64) + (int)(threadIdx.x >> 6); tile < n_tiles; tile += (int)gridDim.x * (TRK_THREADS / 64)) {
+    const int x = (tile % tiles_x) * 8 + (int)(threadIdx.x & 7), y = (tile / tiles_x) * 8 + (int)((threadIdx.x >> 3) & 7);
+    const bool in = x < a.cam.cols && y < a.cam.rows;
+    const int i = in ? y * a.cam.cols + x : 0;
+    const float d = in ? a.depth[i] : 0.f;
+    if (__ballot(d != 0.f) == 0ull) continue;                             // a wave without a single depth value: nothing to look up
+    // z-slabs: a pixel belongs to the slab that owns the voxel of its world point; every rank sums its own pixels and the
+    // 27-float systems are all-reduced.  The 13 lookups reach at most the halo (kf_sdf_partition_step checks it).
+    sdf_accumulate_pixel<AD>(a.vol, S, s_m, a.cam, i, d, w_h, v_h, rS, rcell, a.slab_pixels != 0, acc);
   }
   store_partial(acc, a.partials + (size_t)(a.step & 1) * KF_ICP_MAX_WG * 32, s_wave);
+}
+// volumes whose stored voxels fill less than 4 GB are addressed through a raw buffer descriptor (sdf_rows.h)
+static inline bool sdf_buffer_addressing(const KfVolume& v) {
+  return (unsigned long long)(v.bz1 - v.bz0) * v.nb * v.nb * KF_BRICK_VOX * sizeof(float2) < 0xFFFFFFFFull && v.nb <= 1024;
+}
+static inline void launch_sdf_step(kf_ctx* c, int grid, const TrackArgs& a) {
+  if (sdf_buffer_addressing(a.vol)) hipLaunchKernelGGL(k_sdf_step<SdfBufAddr>, dim3(grid), dim3(TRK_THREADS), 0, c->stream, a);
+  else hipLaunchKernelGGL(k_sdf_step<SdfFlatAddr>, dim3(grid), dim3(TRK_THREADS), 0, c->stream, a);
+}
+
+// ---- SDF tracker, persistent: the whole Gauss-Newton loop of CameraPoseFinderSDF::estimateCameraPose (SDF.cpp:57-103) in ONE launch ---------------
+// Round 4 launched one k_sdf_step per iteration (+ begin + finish): at VGA 300 workgroups of 4 waves -- about one wave per SIMD -- each walking 4 pixels x 13
+// dependent lookups, 60 us per executed iteration (profiles/r05_c3_before_kernel_stats.csv), three of them per frame on Scene S.  Here the iterations share a
+// launch the way the ICP loop's do: n_loop co-resident 512-lane workgroups, pixels dealt in 64-pixel chunks round robin (icp_dealt_pixel_of: every workgroup
+// sees the same mix of surface and background), the 27 sums per workgroup by DPP + LDS, published as tagged 64-bit words and folded by everybody in one fixed
+// order (fold_partials_tagged), the 6x6 system solved by a wave (llt_solve6_wave), the shake / convergence tests and the fp64 exponential map on that wave,
+// and the loop leaves as soon as the increment's norm drops below 1e-3 (SDF.cpp:87-90) -- no launches that find `converged` and return.
+// A fold that times out is finished by ONE workgroup playing every workgroup in turn (as icp_solo_finish, but the same code: `first` / `stride`), and
+// exactly one party ends the launch (KfTrackState::commit_word).
+#define SDF_THREADS ICP_THREADS
+struct SdfLoopArgs {
+  KfVolume vol; const float* depth; KfCam cam;
+  int max_iter;
+  float dist_shake, angle_shake, cos_shake, dist_shake2;
+  unsigned long long* slots; unsigned tag_base; KfTrackState* track; unsigned* stall_word;
+  int n_loop;                                    // workgroups of the launch = publishers of a step
+  int px_l;                                      // pixels per lane = 8x8 tiles per wave: ceil(tiles / (waves per workgroup * n_loop))
+  int slab_pixels;
+  int play_dead;                                 // fault injection (kf_inject_track_stall)
+  int cull_on; IntegrateArgs cull;               // the fusion pass's brick cull as the launch's tail (cull.h), as in k_icp_loop
+};
+// direct_exponential_map (eigen_utils.cpp:84-127) + SDF.cpp:92-100 with the three even series in t = theta^2 instead of sqrt / sin / cos / five fp64 divisions
+// on the one-lane chain of every iteration: sinc = sum (-t)^k / (2k+1)!, mcosc = sum (-t)^k / (2k+2)!, msinc = sum (-t)^k / (2k+3)!, cos = 1 - t mcosc.
+// Nine terms: below 1e-19 for theta <= 0.5 (the shake test admits 0.3 rad with the stock parameters); larger increments take the library routines.  The
+// reference's small-angle constants (sinc = 1 below 1e-8, mcosc = 1/2 and msinc = 1/6 below 2.5e-4) are kept.  Tolerance side (pose within 1e-4).
+__device__ __forceinline__ void sdf_apply_increment_series(const float x[6], const float* cur, float ncur[16]) {
+  const double u0 = (double)x[0], u1 = (double)x[1], u2 = (double)x[2];
+  const double t = u0 * u0 + u1 * u1 + u2 * u2;
+  if (!(t <= 0.25)) { sdf_apply_increment(x, cur, ncur); return; }
+  // three independent Horner chains in -t (they interleave on the one lane that runs them)
+  double a = 1.0 / 355687428096000.0, b = 1.0 / 6402373705728000.0, c = 1.0 / 121645100408832000.0;                    // 1/17!, 1/18!, 1/19!
+  a = 1.0 / 1307674368000.0 - t * a;  b = 1.0 / 20922789888000.0 - t * b;  c = 1.0 / 355687428096000.0 - t * c;        // 1/15!, 1/16!, 1/17!
+  a = 1.0 / 6227020800.0 - t * a;     b = 1.0 / 87178291200.0 - t * b;     c = 1.0 / 1307674368000.0 - t * c;          // 1/13!, 1/14!, 1/15!
+  a = 1.0 / 39916800.0 - t * a;       b = 1.0 / 479001600.0 - t * b;       c = 1.0 / 6227020800.0 - t * c;             // 1/11!, 1/12!, 1/13!
+  a = 1.0 / 362880.0 - t * a;         b = 1.0 / 3628800.0 - t * b;         c = 1.0 / 39916800.0 - t * c;               // 1/9!, 1/10!, 1/11!
+  a = 1.0 / 5040.0 - t * a;           b = 1.0 / 40320.0 - t * b;           c = 1.0 / 362880.0 - t * c;                 // 1/7!, 1/8!, 1/9!
+  a = 1.0 / 120.0 - t * a;            b = 1.0 / 720.0 - t * b;             c = 1.0 / 5040.0 - t * c;                   // 1/5!, 1/6!, 1/7!
+  a = 1.0 / 6.0 - t * a;              b = 1.0 / 24.0 - t * b;              c = 1.0 / 120.0 - t * c;                    // 1/3!, 1/4!, 1/5!
+  a = 1.0 - t * a;                    b = 0.5 - t * b;                     c = 1.0 / 6.0 - t * c;
+  const double co = 1.0 - t * b;                                          // cos(theta), from the un-thresholded series
+  const double sinc = t < 1.0e-16 ? 1.0 : a;                                           // fabs(theta) < 1e-8
+  const double mcosc = t < 6.25e-8 ? 0.5 : b;                                          // fabs(theta) < 2.5e-4
+  const double msinc = t < 6.25e-8 ? (1. / 6.0) : c;
+  const double t3 = (double)x[3], t4 = (double)x[4], t5 = (double)x[5];
+  double R[9];
+  R[0] = co + mcosc * u0 * u0;         R[1] = -sinc * u2 + mcosc * u0 * u1; R[2] = sinc * u1 + mcosc * u0 * u2;
+  R[3] = sinc * u2 + mcosc * u1 * u0;  R[4] = co + mcosc * u1 * u1;         R[5] = -sinc * u0 + mcosc * u1 * u2;
+  R[6] = -sinc * u1 + mcosc * u2 * u0; R[7] = sinc * u0 + mcosc * u2 * u1;  R[8] = co + mcosc * u2 * u2;
+  double dt[3];
+  dt[0] = t3 * (sinc + u0 * u0 * msinc) + t4 * (u0 * u1 * msinc - u2 * mcosc) + t5 * (u0 * u2 * msinc + u1 * mcosc);
+  dt[1] = t3 * (u0 * u1 * msinc + u2 * mcosc) + t4 * (sinc + u1 * u1 * msinc) + t5 * (u1 * u2 * msinc - u0 * mcosc);
+  dt[2] = t3 * (u0 * u2 * msinc - u1 * mcosc) + t4 * (u1 * u2 * msinc + u0 * mcosc) + t5 * (sinc + u2 * u2 * msinc);
+  float Rt[9], tf[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) Rt[r * 3 + cc] = (float)R[cc * 3 + r];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) tf[k] = (float)dt[k];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) ncur[r * 4 + cc] = Rt[r * 3] * cur[cc] + Rt[r * 3 + 1] * cur[4 + cc] + Rt[r * 3 + 2] * cur[8 + cc];
+    ncur[r * 4 + 3] = cur[r * 4 + 3] - (Rt[r * 3] * tf[0] + Rt[r * 3 + 1] * tf[1] + Rt[r * 3 + 2] * tf[2]);
+  }
+  ncur[12] = 0.f; ncur[13] = 0.f; ncur[14] = 0.f; ncur[15] = 1.f;
+}
+// One iteration's update (SDF.cpp:79-100) by wave 0 from the folded sums: solve, shake test, convergence test, exponential map.  Every workgroup runs it on
+// identical inputs -> identical transforms.  On STEP_APPLIED s_cur holds the new transform when the function returns (all lanes, after its barrier).
+__device__ __forceinline__ int sdf_apply_step_wave(const float* s_tot, float* s_cur, float dist_shake2, float cos_shake, int* s_code) {
+  if (threadIdx.x < 64) {
+    float x[6]; bool singular; float det;
+    llt_solve6_wave(s_tot, x, singular, det);                                // (A.llt().solve(b): no pivot test in the reference -- a non-positive pivot yields NaN there and here)
+    const float ang = threadIdx.x == 0 ? x[0] : (threadIdx.x == 1 ? x[1] : x[2]);
+    float sn, cs; kf_sincos_small(ang, &sn, &cs);
+    const int sni = __float_as_int(sn), csi = __float_as_int(cs);
+    const float c0 = __int_as_float(__builtin_amdgcn_readlane(csi, 0)), s0 = __int_as_float(__builtin_amdgcn_readlane(sni, 0));
+    const float c1 = __int_as_float(__builtin_amdgcn_readlane(csi, 1)), s1 = __int_as_float(__builtin_amdgcn_readlane(sni, 1));
+    const float c2 = __int_as_float(__builtin_amdgcn_readlane(csi, 2)), s2 = __int_as_float(__builtin_amdgcn_readlane(sni, 2));
+    float T[16];
+    const bool still = transform_from_sincos(x, c0, s0, c1, s1, c2, s2, dist_shake2, cos_shake, T);      // SDF.cpp:25-43 (only its verdict is used, :81-85)
+    int code = STEP_APPLIED;
+    if (!still) code = STEP_LOST_SHAKE;
+    else {
+      const float nx = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
+      if (nx < 0.001f) code = STEP_CONVERGED;                                // SDF.cpp:87-90: stop before applying x
+    }
+    if (threadIdx.x == 0) {
+      if (code == STEP_APPLIED) {
+        float ncur[16];
+        sdf_apply_increment_series(x, s_cur, ncur);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s_cur[i] = ncur[i];
+      }
+      *s_code = code;
+    }
+  }
+  __syncthreads();
+  return *s_code;
+}
+template <typename AD>
+__global__ void __launch_bounds__(SDF_THREADS) k_sdf_loop(SdfLoopArgs L) {
+  __shared__ float s_m[7][16];
+  __shared__ float s_wave[27 * (SDF_THREADS / 16)], s_tot[(SDF_THREADS / 32) * 32];
+  __shared__ int s_abort, s_code, s_role;
+  __shared__ float s_tinv[16];
+  __shared__ unsigned s_cull[17];
+  KfTrackState* st = L.track;
+  // (the claim word and the commit word are requested together with the pose: one round trip)
+  const unsigned commit_seen0 = __hip_atomic_load(&st->commit_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__hip_atomic_load(&st->rescue_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == L.tag_base) return;     // the launch was given to one workgroup before this one arrived
+  if (L.play_dead && (int)blockIdx.x == L.n_loop - 1) return;
+  const float w_h = 0.001f;                                               // CalSDFErrSolverParams.cu:119
+  const float v_h = L.vol.size / (float)L.vol.res;                        // :120
+  const int grid_l = L.n_loop;
+  const int tiles_x = (L.cam.cols + 7) >> 3, tiles_y = (L.cam.rows + 7) >> 3;
+  const KfRecip rS = kf_recip(L.vol.size);
+  const float rcell = 1.0f / L.vol.cell;
+  const AD S(L.vol);
+  int first = (int)blockIdx.x, stride = L.n_loop;                         // the workgroups of the dealing this one plays: its own -- or all of them, once it finishes alone
+  bool solo = false;
+  int code = STEP_APPLIED, applied = 0;
+  for (int attempt = 0; ; ++attempt) {
+    if (threadIdx.x < 16) s_m[0][threadIdx.x] = st->pose[threadIdx.x];    // SDF.cpp:56 cur_transform = _pose (again from the committed pose: nothing of an attempt is kept)
+    if (threadIdx.x == 0) s_abort = 0;
+    __syncthreads();
+    code = STEP_APPLIED; applied = 0;
+    bool timed_out = false;
+    for (int it = 0; it < L.max_iter; ++it) {                             // SDF.cpp:57
+      sdf_perturbed_transforms(s_m, w_h);
+      __syncthreads();
+#pragma unroll 1
+      for (int w = first; w < grid_l; w += stride) {
+        float acc[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+#pragma unroll 1
+        for (int j = 0; j < L.px_l; ++j) {
+          // a wave takes an 8x8 pixel TILE, not 64 pixels of a row: its 64 world points then fall into a few bricks' worth of cache lines (a scanline
+          // of 64 pixels crosses ~30 voxel columns and, on a slanted surface, as many layers: ~22 lines per gather instruction, which is what
+          // bounded the pixel phase -- profiles/r05_c3_*); tiles are dealt to the waves round robin like the ICP loop's 64-pixel chunks
+          const int tile = ((int)(threadIdx.x >> 6) * grid_l + w) + j * ((SDF_THREADS / 64) * grid_l);
+          const int tx = tile % tiles_x, ty = tile / tiles_x;
+          const int x = tx * 8 + (int)(threadIdx.x & 7), y = ty * 8 + (int)((threadIdx.x >> 3) & 7);
+          const bool in = ty < tiles_y && x < L.cam.cols && y < L.cam.rows;
+          const int i = in ? y * L.cam.cols + x : 0;
+          const float d = in ? L.depth[i] : 0.f;
+          if (__ballot(d != 0.f) == 0ull) continue;                       // a wave without a single depth value
+          sdf_accumulate_pixel<AD>(L.vol, S, s_m, L.cam, i, d, w_h, v_h, rS, rcell, L.slab_pixels != 0, acc);
+        }
+        int k; float sw;
+        if (icp_wg_reduce(acc, s_wave, k, sw))
+          __hip_atomic_store(L.slots + (size_t)it * KF_ICP_LOOP_MAX_WG * 32 + w * 32 + k,
+                             ((unsigned long long)(L.tag_base + (unsigned)it) << 32) | (unsigned long long)__float_as_uint(sw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                                   // s_wave is reused by the next turn
+      }
+      fold_partials_tagged(L.slots + (size_t)it * KF_ICP_LOOP_MAX_WG * 32, grid_l, L.tag_base + (unsigned)it, s_tot, &s_abort, 0, solo ? nullptr : &st->rescue_tag, L.tag_base);
+      if (s_abort) { timed_out = true; break; }
+      code = sdf_apply_step_wave(s_tot, s_m[0], L.dist_shake2, L.cos_shake, &s_code);      // SDF.cpp:79-100
+      if (code != STEP_APPLIED) break;
+      ++applied;
+    }
+    // Who ends the launch?  role 0: leave; 1: the ordinary end (one of the launch's workgroups); 2: finish the launch alone (run the loop again, playing every
+    // workgroup); 3: the others went through after all (every sum is published by now): run the loop again in step with them; 4: the solo finisher's end
+    if (threadIdx.x == 0) {
+      int role;
+      if (solo) role = timed_out ? 0 : 4;
+      else {
+        const unsigned want = L.tag_base | (timed_out ? 2u : 1u);
+        unsigned expect = commit_seen0, seen;
+        for (;;) {
+          if ((expect & ~63u) == L.tag_base) { seen = expect; break; }     // this launch's word is set: somebody decided
+          seen = atomicCAS(&st->commit_word, expect, want);
+          if (seen == expect) { seen = want; break; }
+          expect = seen;                                                   // (an older word replaced by this launch's, or -- never on one stream -- by another's)
+        }
+        const unsigned who = seen & 63u;
+        if (!timed_out) role = who == 1u ? 1 : 0;
+        else if (seen == want && expect != want) {                         // this workgroup's compare-and-swap took the word: it finishes the launch alone
+          __hip_atomic_store(&st->rescue_tag, L.tag_base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);       // whoever still polls leaves
+          __hip_atomic_store(L.stall_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          role = 2;
+        } else role = who == 1u ? 3 : 0;
+      }
+      s_role = role;
+    }
+    __syncthreads();
+    const int role = s_role;
+    if (role == 1 || role == 4) break;
+    if (role == 2) { solo = true; first = 0; stride = 1; continue; }
+    if (role == 3 && attempt < 3) continue;
+    if (solo && threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; st->iterations = applied; st->converged = 0; st->rescued = 1; }   // (a solo fold waits for nobody: unreachable)
+    return;
+  }
+  // ---- the launch's end: SDF.cpp:103 _pose = cur_transform (a lost frame keeps the old pose: `return false` at :84), then the tail --------------------
+  const bool writer = solo || blockIdx.x == 0;
+  const bool good = code != STEP_LOST_SHAKE && code != STEP_LOST_DET;
+  if (writer) {
+    if (threadIdx.x < 27) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
+    if (good && threadIdx.x < 16) st->pose[threadIdx.x] = s_m[0][threadIdx.x];
+    if (threadIdx.x == 0) {
+      st->status = good ? KF_TRACK_OK : code; st->tracked = good ? 1 : 0; st->iterations = applied;
+      st->converged = code == STEP_CONVERGED ? 1 : 0; st->rescued = solo ? 1 : 0;
+    }
+  }
+  if (!good) return;
+  const bool tail = L.cull_on != 0;
+  if (!writer && !tail) return;
+  if (threadIdx.x == 64) kf_mat44_inverse(s_m[0], s_tinv);                // world -> camera (integrateVolume.cu:84), for the fusion pass and the tail
+  __syncthreads();
+  if (writer && threadIdx.x < 16) st->pose_inv[threadIdx.x] = s_tinv[threadIdx.x];
+  if (tail) {
+    if (solo) { for (int w = 0; w < L.n_loop; ++w) cull_tail(L.cull, s_tinv, w, L.n_loop, s_cull); }
+    else cull_tail(L.cull, s_tinv, (int)blockIdx.x, L.n_loop, s_cull);
+  }
 }
 
 // ---- loop control ---------------------------------------------------------------------------------------------------
@@ -1298,7 +1512,7 @@ extern "C" int kf_cal_sdf_solver_params(kf_ctx* c, const kf_camera_params* cam, 
   for (int i = 0; i < 16; ++i) a.cur_val.m[i] = cur->m[i];
   a.partials = c->icp_partials; a.track = c->track;
   const int grid = track_grid(c->cols * c->rows);
-  hipLaunchKernelGGL(k_sdf_step, dim3(grid), dim3(TRK_THREADS), 0, c->stream, a);
+  launch_sdf_step(c, grid, a);
   a.step = 1; a.n_prev_wg = grid;
   hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, a);
   return (int)hipGetLastError();
@@ -1323,6 +1537,22 @@ static void kf_note_loop_stall(kf_ctx* c) {
   c->persistent_backoff_len = c->persistent_backoff_len ? (c->persistent_backoff_len >= 2048 ? 4096 : c->persistent_backoff_len * 2) : 64;
   c->persistent_backoff = c->persistent_backoff_len;
   c->loop_clean_frames = 0;
+}
+
+// The fusion pass's cull as the tail of a persistent tracking launch (k_icp_loop, k_sdf_loop): the previous kf_integrate_volume(transform == NULL) left its
+// parameters behind, the tile tables describe THIS frame's depth map, no deferred-weight words (their cull retires bricks: side effects nobody could undo) and
+// few enough macro cells for the launch's workgroups.  kf_integrate_volume consumes it, or undoes it when it is asked for something else.
+static bool kf_arm_tail_cull(kf_ctx* c, const kf_camera_params* cam0, int n_wg, int waves, IntegrateArgs& out) {
+  static int tail_env = -1;
+  if (tail_env < 0) { const char* e = getenv("KF_CULL_IN_TRACK"); tail_env = e ? atoi(e) : 1; }
+  if (!(tail_env && c->cull_hint.valid && !kf_defer_enabled(c) &&
+        c->tile_serial != 0 && c->tile_serial == c->trunc_serial && c->tile_built_dist == c->cull_hint.max_dist &&
+        memcmp(&c->cull_hint.dcam, cam0, sizeof(*cam0)) == 0 && kf_cull_tail_fits(c, n_wg, waves))) return false;
+  kf_fill_cull_args(c, out, &c->cull_hint.dcam, c->cull_hint.sdf_trunc, c->cull_hint.max_dist);
+  c->tail_cull.armed = 1; c->tail_cull.parity = out.parity; c->tail_cull.bz0 = c->vol.bz0; c->tail_cull.bz1 = c->vol.bz1;
+  c->tail_cull.sdf_trunc = c->cull_hint.sdf_trunc; c->tail_cull.max_dist = c->cull_hint.max_dist; c->tail_cull.dcam = c->cull_hint.dcam;
+  c->tail_cull.trunc_serial = c->trunc_serial;
+  return true;
 }
 
 extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* icp, const kf_camera_params* cam0) {
@@ -1411,20 +1641,7 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
       n_riders = (unsigned)((L.bil_tiles + 1) / 2);
       c->fp_filtered = 1;
     }
-    // The fusion pass's cull as the tail of this launch: the previous kf_integrate_volume(transform == NULL) left its parameters behind, the tile
-    // tables describe THIS frame's depth map, no deferred-weight words (their cull retires bricks: side effects nobody could undo) and few enough
-    // macro cells for the loop's workgroups.  kf_integrate_volume consumes it, or undoes it when it is asked for something else.
-    static int tail_env = -1;
-    if (tail_env < 0) { const char* e = getenv("KF_CULL_IN_TRACK"); tail_env = e ? atoi(e) : 1; }
-    if (tail_env && !batched && !coop_env && L.exp_mode == 0 && c->cull_hint.valid && !kf_defer_enabled(c) &&
-        c->tile_serial != 0 && c->tile_serial == c->trunc_serial && c->tile_built_dist == c->cull_hint.max_dist &&
-        memcmp(&c->cull_hint.dcam, cam0, sizeof(*cam0)) == 0 && kf_cull_tail_fits(c, grid0, ICP_THREADS / 64)) {
-      kf_fill_cull_args(c, L.cull, &c->cull_hint.dcam, c->cull_hint.sdf_trunc, c->cull_hint.max_dist);
-      L.cull_on = 1;
-      c->tail_cull.armed = 1; c->tail_cull.parity = L.cull.parity; c->tail_cull.bz0 = c->vol.bz0; c->tail_cull.bz1 = c->vol.bz1;
-      c->tail_cull.sdf_trunc = c->cull_hint.sdf_trunc; c->tail_cull.max_dist = c->cull_hint.max_dist; c->tail_cull.dcam = c->cull_hint.dcam;
-      c->tail_cull.trunc_serial = c->trunc_serial;
-    }
+    if (!batched && !coop_env && L.exp_mode == 0 && kf_arm_tail_cull(c, cam0, grid0, ICP_THREADS / 64, L.cull)) L.cull_on = 1;
     if (coop_env) {
       // a cooperative launch: the runtime itself checks that the whole grid can be resident and refuses otherwise
       void* params[] = {(void*)&L};
@@ -1537,6 +1754,51 @@ extern "C" int kf_sdf_track(kf_ctx* c, uint32_t frame_id, const kf_sdf_tracker_p
     return (int)hipGetLastError();
   }
   kf_evt_begin(c, KF_STAGE_TRACK);
+  // The whole loop in one launch (k_sdf_loop) under the conditions of the persistent ICP loop: this context alone on the device, no back-off after a
+  // time-out, every workgroup resident.  KF_SDF_PERSISTENT=0 (or KF_ICP_PERSISTENT=0): one launch per iteration, as the z-slab partition runs it.
+  {
+    static int loop_env = -1;
+    if (loop_env < 0) { const char* e = getenv("KF_SDF_PERSISTENT"); const char* e2 = getenv("KF_ICP_PERSISTENT"); loop_env = (e ? atoi(e) : 1) && (e2 ? atoi(e2) : 1); }
+    unsigned* stall_word = (unsigned*)((char*)c->host_pinned + KF_PINNED_STALL_WORD);
+    if (__atomic_load_n(stall_word, __ATOMIC_RELAXED)) { __atomic_store_n(stall_word, 0u, __ATOMIC_RELAXED); kf_note_loop_stall(c); }
+    else if (c->persistent_backoff == 0 && c->persistent_backoff_len && ++c->loop_clean_frames >= 1024) { c->persistent_backoff_len = 0; c->loop_clean_frames = 0; }
+    const bool buf = sdf_buffer_addressing(c->vol);
+    bool use_loop = loop_env && !c->loop_refused && sp->max_iter_nums >= 1 && sp->max_iter_nums <= KF_ICP_LOOP_STEPS &&
+                    kf_live_contexts(c->cfg.device) == 1 && !kf_device_shared(c->cfg.device);
+    if (use_loop && c->sdf_loop_occupancy == 0) {
+      int per_cu = 0;
+      const hipError_t e = buf ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sdf_loop<SdfBufAddr>, SDF_THREADS, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sdf_loop<SdfFlatAddr>, SDF_THREADS, 0);
+      c->sdf_loop_occupancy = (e == hipSuccess && per_cu >= 1) ? per_cu : -1;
+    }
+    if (use_loop && c->sdf_loop_occupancy < 1) use_loop = false;
+    if (use_loop && c->persistent_backoff > 0) { --c->persistent_backoff; use_loop = false; }
+    if (use_loop) {
+      const int npx = c->cols * c->rows;
+      static int wg_env = -1;
+      if (wg_env < 0) { const char* e = getenv("KF_SDF_LOOP_WG"); wg_env = e ? atoi(e) : 0; }
+      int n_loop = wg_env > 0 ? wg_env : c->num_cus;                           // one workgroup per CU
+      n_loop = n_loop > c->num_cus * c->sdf_loop_occupancy ? c->num_cus * c->sdf_loop_occupancy : n_loop;
+      n_loop = n_loop > KF_ICP_LOOP_MAX_WG ? KF_ICP_LOOP_MAX_WG : n_loop;
+      const int need = kf_div_up(kf_div_up(c->cols, 8) * kf_div_up(c->rows, 8), SDF_THREADS / 64);
+      if (n_loop > need) n_loop = need;
+      SdfLoopArgs L; memset(&L, 0, sizeof(L));
+      L.vol = c->vol; L.depth = c->trunced_depth; L.cam = to_cam(cam); L.max_iter = (int)sp->max_iter_nums;
+      { TrackArgs th; set_thresholds(th, 0.f, 0.f, sp->dist_shake, sp->angle_shake);
+        L.dist_shake = th.dist_shake; L.angle_shake = th.angle_shake; L.cos_shake = th.cos_shake; L.dist_shake2 = th.dist_shake2; }
+      c->icp_loop_seq += 64u;
+      L.slots = c->icp_loop_slots; L.tag_base = c->icp_loop_seq; L.track = c->track; L.stall_word = stall_word;
+      const int n_tiles = kf_div_up(c->cols, 8) * kf_div_up(c->rows, 8);      // 8x8 pixel tiles, one per wave and round
+      L.n_loop = n_loop; L.px_l = kf_div_up(n_tiles, (SDF_THREADS / 64) * n_loop);
+      if (c->inject_stall > 0) { L.play_dead = 1; --c->inject_stall; }
+      if (kf_arm_tail_cull(c, cam, n_loop, SDF_THREADS / 64, L.cull)) L.cull_on = 1;
+      if (buf) hipLaunchKernelGGL(k_sdf_loop<SdfBufAddr>, dim3((unsigned)n_loop), dim3(SDF_THREADS), 0, c->stream, L);
+      else hipLaunchKernelGGL(k_sdf_loop<SdfFlatAddr>, dim3((unsigned)n_loop), dim3(SDF_THREADS), 0, c->stream, L);
+      c->last_track_form = 1;
+      kf_evt_end(c, KF_STAGE_TRACK);
+      return (int)hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, c->stream, c->track, 1, c->grid_barrier);
   TrackArgs a; memset(&a, 0, sizeof(a));
   a.use_state = 1; a.sdf = 1;
@@ -1547,11 +1809,12 @@ extern "C" int kf_sdf_track(kf_ctx* c, uint32_t frame_id, const kf_sdf_tracker_p
   int step = 0;
   for (uint32_t it = 0; it < sp->max_iter_nums; ++it) {
     a.step = step; a.consume = step > 0; a.n_prev_wg = grid;
-    hipLaunchKernelGGL(k_sdf_step, dim3(grid), dim3(TRK_THREADS), 0, c->stream, a);
+    launch_sdf_step(c, grid, a);
     ++step;
   }
   a.step = step; a.consume = step > 0; a.n_prev_wg = grid;
   hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, a);
+  c->last_track_form = 2;
   kf_evt_end(c, KF_STAGE_TRACK);
   return (int)hipGetLastError();
 }
@@ -1591,7 +1854,7 @@ extern "C" int kf_sdf_partition_step(kf_ctx* c, uint32_t step, const kf_sdf_trac
   if (st) return st;
   const int grid = track_grid(c->cols * c->rows);
   a.step = (int)step; a.consume = step > 0; a.n_prev_wg = grid; a.ext_prev = step > 0 ? dev_sums : nullptr;
-  hipLaunchKernelGGL(k_sdf_step, dim3(grid), dim3(TRK_THREADS), 0, c->stream, a);
+  launch_sdf_step(c, grid, a);
   TrackArgs f = a; f.step = (int)step + 1; f.n_prev_wg = grid; f.fold_out = dev_sums; f.ext_prev = nullptr;
   hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(ICP_THREADS), 0, c->stream, f);
   return (int)hipGetLastError();

@@ -255,3 +255,76 @@ def test_the_cull_in_the_tracking_launch_equals_the_cull_launch():
     (_, va, ua, _, fa), (_, vb, ub, _, fb_) = runs["mixed"], runs["no-tails"]
     assert ua == ub and fa == fb_ == n and np.array_equal(va[0].view(np.uint32), vb[0].view(np.uint32)) and np.array_equal(va[1], vb[1])
     assert runs["tails"][0][5][2] > 100000 and runs["mixed"][0][n - 1][2] < runs["tails"][0][n - 1][2]
+
+
+# ---- the SDF tracker's launch forms (CameraPoseFinderSDF, src/CameraPoseFinderSDF.cpp:45-105) ---------------------------------------------
+SDF = (P["sdf_max_iter_nums"], P["camera_shake_dist"], P["camera_shake_angle"])
+
+
+def _track_sdf(ctx, pose, sdf=SDF):
+    ctx.set_pose(pose)
+    ctx.sdf_track(1, *sdf)
+    ok, p, status, iters = ctx.track_result()
+    return ok, p, status, iters, ctx.last_form, ctx.read_solver_params()
+
+
+@pytest.mark.parametrize("res,cam", [(128, S.vga_camera()), (64, mid_cam()), (96, ragged_cam())])
+def test_sdf_persistent_loop_against_the_oracle_and_the_per_iteration_form(res, cam):
+    """kf_sdf_track alone on the device runs ONE launch for the whole Gauss-Newton loop (k_sdf_loop: tagged partial sums, wave solve, exit on convergence);
+    with a second live context one launch per iteration (k_sdf_step).  The two deal pixels to workgroups differently (fp32 sums in another order), so
+    they agree to tolerance, each within 1e-4 of the oracle's CameraPoseFinderSDF loop, with the same iteration count and verdict."""
+    size, trunc = 3.0, 5 * 3.0 / res
+    ctx, ovol, pose, nxt, ocam, (v, n, ov, on, tr) = _tracking_case(res, size, cam, trunc, n_warm=3)
+    ok_o, pose_o, it_o = O.sdf_estimate(ovol, tr, ocam, *SDF, pose)
+    ok1, p1, st1, it1, form1, sums1 = _track_sdf(ctx, pose)
+    assert form1 == 1
+    other = K.Context(K.camera(*mid_cam()), 32, 3.0, levels=3)
+    ok2, p2, st2, it2, form2, sums2 = _track_sdf(ctx, pose)
+    other.close()
+    assert form2 == 2
+    assert ok_o and ok1 and ok2 and st1 == st2 == 0 and it1 == it2 == it_o, (it1, it2, it_o)
+    for p in (p1, p2):
+        assert np.max(np.abs(p - pose_o)) < 1e-4
+    assert np.max(np.abs(sums1 - sums2)) <= 2e-5 * np.max(np.abs(sums2))     # the last iteration's system, two summation orders
+    ok3, p3, _, it3, form3, sums3 = _track_sdf(ctx, pose)                      # the loop again: reproducible to the bit
+    assert form3 == 1 and np.array_equal(p3.view(np.uint32), p1.view(np.uint32)) and np.array_equal(sums3.view(np.uint32), sums1.view(np.uint32))
+    # the lost verdict: a shake threshold of 0 rejects the first increment, the pose stays, no iteration counts (SDF.cpp:81-85)
+    for second in (False, True):
+        other = K.Context(K.camera(*mid_cam()), 32, 3.0, levels=3) if second else None
+        ok_l, p_l, st_l, it_l, form_l, _ = _track_sdf(ctx, pose, (SDF[0], 0.0, 0.0))
+        assert form_l == (2 if second else 1) and not ok_l and st_l == 2 and it_l == 0 and np.array_equal(p_l, pose)
+        if other is not None:
+            other.close()
+    ctx.close()
+
+
+def test_sdf_loop_at_1280x960_and_with_a_single_iteration():
+    """BASELINE config C5's image through the SDF loop (every lane walks ten pixels per iteration), and max_iter_nums = 1 (one pixel phase, one update)."""
+    cam, res, size = S.vga_camera(2), 128, 3.0
+    trunc = 5 * size / res
+    ctx, ovol, pose, nxt, ocam, (v, n, ov, on, tr) = _tracking_case(res, size, cam, trunc, n_warm=3)
+    for sdf in (SDF, (1, SDF[1], SDF[2])):
+        ok_o, pose_o, it_o = O.sdf_estimate(ovol, tr, ocam, *sdf, pose)
+        ok, p, status, iters, form, _ = _track_sdf(ctx, pose, sdf)
+        assert form == 1 and ok and ok_o and status == 0 and iters == it_o
+        assert np.max(np.abs(p - pose_o)) < 1e-4
+    ctx.close()
+
+
+@pytest.mark.parametrize("res,cam", [(128, S.vga_camera()), (96, ragged_cam())])
+def test_an_sdf_loop_that_times_out_is_finished_by_one_workgroup_with_the_same_bits(res, cam):
+    """kf_inject_track_stall on the SDF loop: one workgroup plays dead, the others time out, exactly one claims the launch (KfTrackState::commit_word) and
+    runs the loop again alone, playing every workgroup of the dealing in turn: the same pose bits and final sums as the undisturbed loop,
+    launch_form 3, the frame is kept; then the context backs off to one launch per iteration."""
+    size, trunc = 3.0, 5 * 3.0 / res
+    ctx, ovol, pose, nxt, ocam, maps = _tracking_case(res, size, cam, trunc, n_warm=3)
+    ok1, p1, st1, it1, form1, sums1 = _track_sdf(ctx, pose)
+    assert form1 == 1 and ok1 and st1 == 0
+    ctx.inject_track_stall(1)
+    ok2, p2, st2, it2, form2, sums2 = _track_sdf(ctx, pose)
+    assert form2 == 3, form2
+    assert ok2 and st2 == 0 and it2 == it1
+    assert np.array_equal(p1.view(np.uint32), p2.view(np.uint32)) and np.array_equal(sums1.view(np.uint32), sums2.view(np.uint32))
+    ok3, p3, st3, it3, form3, _ = _track_sdf(ctx, pose)
+    assert form3 == 2 and ok3 and it3 == it1 and np.max(np.abs(p3 - p1)) < 1e-5
+    ctx.close()
