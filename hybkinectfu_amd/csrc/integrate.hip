@@ -407,7 +407,10 @@ __device__ __forceinline__ uint2 integrate_color_update2(uint2 oc, unsigned col0
 // the running average of tsdfVolume.h:68-70 keeps the reference's double-precision weight expression and its IEEE quotients.  Colour
 // changes even where (tsdf, weight) no longer do and blends with the weight, so COLOR excludes DEFER (pending counts are flushed before a
 // colour frame and the words cleared behind it: kf_integrate_volume).
-template <int BR, bool DEFER, bool COLOR = false, bool LAYERS = false>
+// COUNT: the launch also counts the voxels it observes for the FIRST time (weight 0 -> > 0, owned layers) into KfCounters::wgt0_shard -- the running count behind
+// kf_get_volume_stats.  An instantiation of its own, launched only while a host keeps asking for the count (kf_ctx::wgt0_tracking): two compares and two
+// ballots per brick turn out to cost the kernel 3.6 us at 512^3 and 9 us at 1024^3 (profiles/r05_observed_count.txt) -- not something every frame should pay.
+template <int BR, bool DEFER, bool COLOR = false, bool LAYERS = false, bool COUNT = false>
 __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   static_assert(!(DEFER && COLOR), "colour changes where (tsdf, weight) do not, and blends with the weight: no deferral");
   const KfVolume& v = a.vol;
@@ -424,10 +427,10 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   const unsigned sat_w = __float_as_uint(v.max_weight), one_f = __float_as_uint(1.0f);
   unsigned short* const pend16 = reinterpret_cast<unsigned short*>(v.pend);      // quarter q of brick slot s: pend16[4 s + q]
   const KfRecip2 r075 = kf_recip2(f2_splat(0.75f));                     // COLOR: the angle weight's |nz| / 0.75
-  __shared__ unsigned s_upd;
+  __shared__ unsigned s_upd, s_new;
   __shared__ unsigned s_layer[LAYERS ? 1024 : 1];                        // LAYERS (sampled frames: a launch of its own instantiation): this workgroup's update counts per brick layer (kf_create: <= 1024 brick layers)
-  unsigned upd_total = 0;
-  if (threadIdx.x == 0) s_upd = 0;
+  unsigned upd_total = 0, new_wave = 0;
+  if (threadIdx.x == 0) { s_upd = 0; s_new = 0; }
   if (LAYERS) for (int i = threadIdx.x; i < v.nb; i += 256) s_layer[i] = 0u;
   __syncthreads();
   // The queue entries of an iteration are requested one iteration ahead.  On gfx9-family hardware loads and stores share one in-order
@@ -638,6 +641,8 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
       kf_f2 ow = {q[b].y, q[b].w};
       if (DEFER && all_lanes[b]) { const float k = (float)(pnd[b] - 1u); ow.x = fminf(ow.x + k, v.max_weight); ow.y = fminf(ow.y + k, v.max_weight); }   // the quarter's pending steps, applied
       const kf_f2 ow1 = ow + f2_splat(1.f);
+      if (COUNT) { const int bzv = ((int)(ent[b] >> 20) + v.bz0) * KF_BRICK;  // voxels observed for the first time (owned layers): the running count of kf_get_volume_stats
+        new_wave += kf_new_voxels(bzv >= v.own_z0 && bzv < v.own_z1 && v.max_weight > 0.f, upd0[b], ow.x, upd1[b], ow.y); }
       // A free-space wave whose updating voxels all hold tsdf 1 already (weight any value in [0, 2^24]): (1 * w + 1) / (w + 1) has the
       // SAME rounded sum RN(w + 1) above and below the line (1 * w is exact), a finite non-zero number divided by itself: nt = 1
       // exactly -- neither the reciprocal nor the second quotient is formed, only the weight moves.  Wave-uniform branch.
@@ -714,8 +719,10 @@ __global__ void __launch_bounds__(256) k_integrate_pairs(IntegrateArgs a) {
   }
   float s = kf_wave_sum((float)upd_total);          // < 2^24 per wave: exact
   if ((threadIdx.x & 63) == 0 && s > 0.f) atomicAdd(&s_upd, (unsigned)s);
+  if (COUNT && (threadIdx.x & 63) == 0 && new_wave) atomicAdd(&s_new, new_wave);
   __syncthreads();
   if (threadIdx.x == 0 && s_upd) atomicAdd(&a.cnt->upd_shard[a.parity][(blockIdx.x & 63) * 16], (unsigned long long)s_upd);
+  if (COUNT && threadIdx.x == 0 && s_new) atomicAdd(&a.cnt->wgt0_shard[(blockIdx.x & 63) * 16], (unsigned long long)s_new);
   if (LAYERS) for (int i = threadIdx.x; i < v.nb; i += 256) { const unsigned n = s_layer[i]; if (n) atomicAdd(&a.layer_work[i], (unsigned long long)n); }
 }
 
@@ -733,7 +740,7 @@ struct PipeFront {                       // what stage A leaves behind for stage
   kf_f2 pfz, d;
   bool ok0, ok1;
 };
-template <bool DEFER>
+template <bool DEFER, bool COUNT = false>
 __global__ void __launch_bounds__(256) k_integrate_pairs_pipe(IntegrateArgs a) {
   const KfVolume& v = a.vol;
   const unsigned n_active = a.cnt->n_active[a.parity];
@@ -748,9 +755,9 @@ __global__ void __launch_bounds__(256) k_integrate_pairs_pipe(IntegrateArgs a) {
   const unsigned quarter = threadIdx.x >> 6;
   const unsigned sat_w = __float_as_uint(v.max_weight), one_f = __float_as_uint(1.0f);
   unsigned short* const pend16 = reinterpret_cast<unsigned short*>(v.pend);
-  __shared__ unsigned s_upd;
-  unsigned upd_total = 0;
-  if (threadIdx.x == 0) s_upd = 0;
+  __shared__ unsigned s_upd, s_new;
+  unsigned upd_total = 0, new_wave = 0;
+  if (threadIdx.x == 0) { s_upd = 0; s_new = 0; }
   __syncthreads();
   // stage A of one brick: everything up to (and including) the request of its depth values
   auto front = [&](unsigned packed, bool live) {
@@ -833,6 +840,8 @@ __global__ void __launch_bounds__(256) k_integrate_pairs_pipe(IntegrateArgs a) {
       kf_f2 ow = {q.y, q.w};
       if (DEFER && all_lanes) { const float k = (float)(pnd - 1u); ow.x = fminf(ow.x + k, v.max_weight); ow.y = fminf(ow.y + k, v.max_weight); }
       const kf_f2 ow1 = ow + f2_splat(1.f);
+      if (COUNT) { const int bzv = ((int)(ent >> 20) + v.bz0) * KF_BRICK;     // voxels observed for the first time (owned layers): kf_get_volume_stats' running count
+        new_wave += kf_new_voxels(bzv >= v.own_z0 && bzv < v.own_z1 && v.max_weight > 0.f, upd0, ow.x, upd1, ow.y); }
       bool unit = false;
       if (free_wave) {
         const bool k0 = !upd0 || (__float_as_uint(ot.x) == one_f && __float_as_uint(ow.x) <= 0x4B800000u);
@@ -879,8 +888,10 @@ __global__ void __launch_bounds__(256) k_integrate_pairs_pipe(IntegrateArgs a) {
   }
   float s = kf_wave_sum((float)upd_total);
   if ((threadIdx.x & 63) == 0 && s > 0.f) atomicAdd(&s_upd, (unsigned)s);
+  if (COUNT && (threadIdx.x & 63) == 0 && new_wave) atomicAdd(&s_new, new_wave);
   __syncthreads();
   if (threadIdx.x == 0 && s_upd) atomicAdd(&a.cnt->upd_shard[a.parity][(blockIdx.x & 63) * 16], (unsigned long long)s_upd);
+  if (COUNT && threadIdx.x == 0 && s_new) atomicAdd(&a.cnt->wgt0_shard[(blockIdx.x & 63) * 16], (unsigned long long)s_new);
 }
 
 #ifdef KF_EXPERIMENTS
@@ -1096,6 +1107,8 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
   // the roofline kernel's live timer: the event pair rides on the dispatch itself (kf_evt_attach), so what is measured is the kernel, as rocprofv3 sees it
   hipEvent_t ke0 = nullptr, ke1 = nullptr;
   const bool timed = kf_evt_attach(c, KF_STAGE_INTEGRATE_KERNEL, &ke0, &ke1);
+  const bool count = c->wgt0_tracking && c->wgt0_valid;   // the COUNT instantiations, while a host keeps asking kf_get_volume_stats for the observed-voxel count
+  bool counted = false;
 #define FUSE_LAUNCH(K) do { if (timed) hipExtLaunchKernelGGL(K, dim3(grid), dim3(256), 0, c->stream, ke0, ke1, 0, a); \
                             else hipLaunchKernelGGL(K, dim3(grid), dim3(256), 0, c->stream, a); } while (0)
   static int color_pairs = -1;                            // 1 (default): colour through the packed-pair kernel; 0: the scalar kernel (A/B)
@@ -1129,21 +1142,30 @@ extern "C" int kf_integrate_volume(kf_ctx* c, int has_color, int use_angle_weigh
       if (defer) FUSE_LAUNCH((k_integrate_pairs<1, true, false, true>));
       else FUSE_LAUNCH((k_integrate_pairs<1, false, false, true>));
     } else if (pairs && br == 1 && (pipe_env < 0 ? defer : pipe_env != 0)) {     // the one-brick form as a two-stage pipeline: by default where workgroups walk many bricks (KF_INTEGRATE_PIPE=0 / 1 forces)
-      if (defer) FUSE_LAUNCH((k_integrate_pairs_pipe<true>));
+      if (defer && count) { FUSE_LAUNCH((k_integrate_pairs_pipe<true, true>)); counted = true; }
+      else if (defer) FUSE_LAUNCH((k_integrate_pairs_pipe<true>));
+      else if (count) { FUSE_LAUNCH((k_integrate_pairs_pipe<false, true>)); counted = true; }
       else FUSE_LAUNCH((k_integrate_pairs_pipe<false>));
     } else if (pairs) {
       if (defer) {
-        if (br == 1) FUSE_LAUNCH((k_integrate_pairs<1, true>));
+        if (br == 1 && count) { FUSE_LAUNCH((k_integrate_pairs<1, true, false, false, true>)); counted = true; }
+        else if (br == 1) FUSE_LAUNCH((k_integrate_pairs<1, true>));
         else if (br == 2) FUSE_LAUNCH((k_integrate_pairs<2, true>));
         else FUSE_LAUNCH((k_integrate_pairs<4, true>));
-      } else if (br == 1) FUSE_LAUNCH((k_integrate_pairs<1, false>));
+      } else if (br == 1 && count) { FUSE_LAUNCH((k_integrate_pairs<1, false, false, false, true>)); counted = true; }
+      else if (br == 1) FUSE_LAUNCH((k_integrate_pairs<1, false>));
       else if (br == 2) FUSE_LAUNCH((k_integrate_pairs<2, false>));
+      else if (count) { FUSE_LAUNCH((k_integrate_pairs<4, false, false, false, true>)); counted = true; }
       else FUSE_LAUNCH((k_integrate_pairs<4, false>));
     } else if (br == 1) FUSE_LAUNCH((k_integrate_bricks<false, 1>));
     else if (br == 2) FUSE_LAUNCH((k_integrate_bricks<false, 2>));
     else FUSE_LAUNCH((k_integrate_bricks<false, 4>));
   }
 #undef FUSE_LAUNCH
+  // the running count of observed voxels (kf_get_volume_stats): a fusion launch that did not count leaves it behind the volume
+  if (!counted) c->wgt0_valid = 0;
+  if (c->wgt0_frames_unasked < (1 << 30)) ++c->wgt0_frames_unasked;
+  if (c->wgt0_tracking && c->wgt0_frames_unasked > 64) c->wgt0_tracking = 0;        // nobody has asked for 64 frames: the plain kernels again
   if (timed) kf_evt_attached_done(c, KF_STAGE_INTEGRATE_KERNEL);
   kf_evt_end(c, KF_STAGE_INTEGRATE);
   if (defer) c->pend_live = 1;

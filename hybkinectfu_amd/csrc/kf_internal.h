@@ -128,7 +128,18 @@ struct KfCounters {
   unsigned long long rc_steps[64 * 16];      // raycast: samples the reference's march takes (per ray: up to its first crossing or t_max)
   unsigned long long rc_hits[64 * 16];       // raycast: rays whose crossing was evaluated (trilinear + gradient taps)
   unsigned long long mc_blocks[64 * 16];     // marching cubes: 4-KiB bricks the extraction reads (those with a negative voxel in their 3x3x3 brick neighbourhood)
+  // voxels of the OWNED layers whose weight went from 0 to > 0 since the count was last based (kf_ctx::wgt0_base): every fusion kernel adds its own,
+  // sharded like the update counts -- kf_get_volume_stats then needs no sweep of the volume (the reference prints the count every frame: integrateVolume.cu:91-94)
+  unsigned long long wgt0_shard[64 * 16];
 };
+// this wave's 0 -> > 0 weight transitions for one pair per lane (w0 / w1: the weights the update starts from); `count` is wave-uniform: owned layers, max_weight > 0
+__device__ __forceinline__ unsigned kf_new_voxels(bool count, bool u0, float w0, bool u1, float w1) {
+#ifdef KF_NO_OBSERVED_COUNT                      // A/B variant only (tools/build_variant.sh): what the running count costs the fusion kernels
+  return 0u;
+#endif
+  const unsigned long long a = __ballot(u0 && w0 == 0.f), b = __ballot(u1 && w1 == 0.f);
+  return count ? (unsigned)__popcll(a) + (unsigned)__popcll(b) : 0u;
+}
 
 #define KF_UP_SLOTS 3                  // host-upload slots: the current frame and up to two staged ahead of it
 struct kf_ctx {
@@ -184,6 +195,11 @@ struct kf_ctx {
   int loop_occupancy;                 // workgroups of k_icp_loop one CU can hold (0: not asked yet)
   int loop_occupancy_batched;         // the same for k_icp_loop_batched
   int sdf_loop_occupancy;             // the same for k_sdf_loop (the addressing variant this volume uses)
+  unsigned long long wgt0_base;       // observed voxels (weight > 0, owned layers) when the running count KfCounters::wgt0_shard was last zeroed
+  int wgt0_valid;                     // base + shards IS the count (0: something else wrote weights -- upload, resize, a fusion launch that did not count -- : the next kf_get_volume_stats sweeps and re-bases)
+  int wgt0_tracking;                  // the fusion launches use their COUNT instantiations: switched on when kf_get_volume_stats is asked twice within 8 fused frames, off after 64 frames without a question
+  int wgt0_frames_unasked;            // fusion launches since the last kf_get_volume_stats
+  int wgt0_asked_before;              // kf_get_volume_stats has been called at least once
   int last_track_form;                // kf_track_result::launch_form of the last tracking call
   KfTrackState* track;                // device
   KfCounters* counters;               // device

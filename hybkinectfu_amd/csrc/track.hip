@@ -43,6 +43,7 @@ struct TrackArgs {
   int step;                                      // index of this Gauss-Newton step within the frame (buffer parity)
   int consume;                                   // 1: first fold + apply the previous step's system
   int n_prev_wg;                                 // workgroups that wrote the previous step's partials
+  int fold_group;                                // > 0: fold them in groups g, g + fold_group, ... first (fold_partials: the batched loop's publishers)
   int sdf;                                       // consume with the SDF tracker's update rule (exp map, convergence test)
   // pixel-partitioned ICP (multi-GPU): this context sums only pixels [px_begin, px_end) (0,0 = all); the previous step's
   // system arrives all-reduced in ext_prev (27 floats) instead of workgroup partials; fold_out receives this step's 27 sums
@@ -308,16 +309,25 @@ __device__ __forceinline__ void fold_combine_parts(float* s_tot, int parts) {
 // s_tot must hold 8 x 32 floats; on return s_tot[0..26] are the totals (all threads, after the barrier)
 // (blockDim/32 interleaved chains per sum; the loads of a chain are issued four at a time so the chain costs
 // ceil(n/4) memory round trips instead of n; the additions keep their fixed order.)  s_tot: 32 x 32 floats.
-__device__ __forceinline__ void fold_partials(const float* __restrict__ partials, int n_wg, float* s_tot) {
+// n_group (0: none): workgroups g, g + n_group, g + 2 n_group, ... are first added up in that order and count as ONE publisher g -- what the batched
+// persistent loop's resident workgroup g publishes after playing exactly those workgroups of the dealing (k_icp_loop_batched): the same numbers in the same order
+__device__ __forceinline__ float fold_group_sum(const float* __restrict__ partials, int w, int n_wg, int n_group, int k) {
+  float v = partials[w * 32 + k];
+  if (n_group > 0) for (int u = w + n_group; u < n_wg; u += n_group) v += partials[u * 32 + k];
+  return v;
+}
+__device__ __forceinline__ void fold_partials(const float* __restrict__ partials, int n_wg, float* s_tot, int n_group = 0) {
   const int k = threadIdx.x & 31, part = threadIdx.x >> 5, parts = blockDim.x >> 5;
+  const int n_pub = (n_group > 0 && n_group < n_wg) ? n_group : n_wg;
+  if (n_pub == n_wg) n_group = 0;
   float s = 0.f;
   if (k < 27) {
-    for (int w = part; w < n_wg; w += 4 * parts) {
+    for (int w = part; w < n_pub; w += 4 * parts) {
       const int w1 = w + parts, w2 = w + 2 * parts, w3 = w + 3 * parts;
-      const float v0 = partials[w * 32 + k];
-      const float v1 = (w1 < n_wg) ? partials[w1 * 32 + k] : 0.f;
-      const float v2 = (w2 < n_wg) ? partials[w2 * 32 + k] : 0.f;
-      const float v3 = (w3 < n_wg) ? partials[w3 * 32 + k] : 0.f;
+      const float v0 = fold_group_sum(partials, w, n_wg, n_group, k);
+      const float v1 = (w1 < n_pub) ? fold_group_sum(partials, w1, n_wg, n_group, k) : 0.f;
+      const float v2 = (w2 < n_pub) ? fold_group_sum(partials, w2, n_wg, n_group, k) : 0.f;
+      const float v3 = (w3 < n_pub) ? fold_group_sum(partials, w3, n_wg, n_group, k) : 0.f;
       s += v0; s += v1; s += v2; s += v3;
     }
   }
@@ -491,7 +501,7 @@ __device__ __forceinline__ bool step_prologue(const TrackArgs& a, float* s_cur, 
     return true;
   }
   if (a.ext_prev) fold_partials(a.ext_prev, 1, s_tot);
-  else fold_partials(a.partials + (size_t)((a.step + 1) & 1) * KF_ICP_MAX_WG * 32, a.n_prev_wg, s_tot);
+  else fold_partials(a.partials + (size_t)((a.step + 1) & 1) * KF_ICP_MAX_WG * 32, a.n_prev_wg, s_tot, a.fold_group);
   apply_step(a, s_tot, s_cur, s_code);
   const int code = *s_code;
   if (blockIdx.x == 0) {
@@ -826,25 +836,31 @@ __device__ __forceinline__ void icp_solo_finish(const IcpLoopArgs& L, float (*s_
         cur_buf ^= 1; s_cur = s_pose[cur_buf];
         ++applied;
       }
-      for (int w = 0; w < grid_l; ++w) {                                       // every workgroup of the launch, one after the other
-        float4 iv[ICP_PX], in_[ICP_PX];
+      const int n_pub = grid_l < L.n_loop ? grid_l : L.n_loop;                 // publishers: the launch's workgroups (k_icp_loop: one per workgroup of the dealing)
+      for (int g = 0; g < n_pub; ++g) {                                        // every workgroup of the launch, one after the other
+        float gsum = 0.f;
+        for (int w = g; w < grid_l; w += L.n_loop) {                           // ... each with the workgroups of the dealing it plays (k_icp_loop_batched), summed in its order
+          float4 iv[ICP_PX], in_[ICP_PX];
 #pragma unroll
-        for (int j = 0; j < ICP_PX; ++j) {
-          const int i = icp_dealt_pixel_of(j, grid_l, w);
-          iv[j] = make_float4(0.f, 0.f, 0.f, 0.f); in_[j] = iv[j];
-          if (j < px_l && i < npx) { iv[j] = new_v[i]; in_[j] = new_n[i]; }
+          for (int j = 0; j < ICP_PX; ++j) {
+            const int i = icp_dealt_pixel_of(j, grid_l, w);
+            iv[j] = make_float4(0.f, 0.f, 0.f, 0.f); in_[j] = iv[j];
+            if (j < px_l && i < npx) { iv[j] = new_v[i]; in_[j] = new_n[i]; }
+          }
+          float acc[27];
+#pragma unroll
+          for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+          icp_accumulate(a, s_cur, s_linv, iv, in_, L.model_v[l], L.model_n[l], acc);
+          int k; float sw;
+          const bool holder = icp_wg_reduce(acc, s_wave, k, sw);
+          if (holder) gsum = (w == g) ? sw : gsum + sw;
+          __syncthreads();                                                     // s_wave is reused by the next turn
+          if (holder && w + L.n_loop >= grid_l)
+            __hip_atomic_store(L.slots + (size_t)step * KF_ICP_LOOP_MAX_WG * 32 + g * 32 + k,
+                               ((unsigned long long)(L.tag_base + (unsigned)step) << 32) | (unsigned long long)__float_as_uint(gsum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        float acc[27];
-#pragma unroll
-        for (int k = 0; k < 27; ++k) acc[k] = 0.f;
-        icp_accumulate(a, s_cur, s_linv, iv, in_, L.model_v[l], L.model_n[l], acc);
-        int k; float sw;
-        if (icp_wg_reduce(acc, s_wave, k, sw))
-          __hip_atomic_store(L.slots + (size_t)step * KF_ICP_LOOP_MAX_WG * 32 + w * 32 + k,
-                             ((unsigned long long)(L.tag_base + (unsigned)step) << 32) | (unsigned long long)__float_as_uint(sw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();                                                       // s_wave is reused by the next turn
       }
-      n_prev = grid_l;
+      n_prev = n_pub;
     }
   }
   if (code == STEP_APPLIED) {                                                  // the last step's system, then commit _pose (ICP.cpp:84)
@@ -1098,7 +1114,11 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop_batched(IcpLoopArgs L)
         cur_buf ^= 1; s_cur = s_pose[cur_buf];
         ++applied;
       }
-      for (int w = (int)blockIdx.x; w < grid_l; w += L.n_loop) {                 // this workgroup's turns
+      // this workgroup's turns: the workgroups blockIdx.x, blockIdx.x + n_loop, ... of the dealing; their partial sums are added up HERE, in that order, and
+      // published as ONE set of 27 words -- a step's fold then walks n_loop x 27 tagged words (205 at 1280x960), not grid_l x 27 (800): round 4's batched
+      // loop spent four polling passes per step on them.  The per-step form folds its 800 partials in the same groups (fold_partials, TrackArgs::fold_group).
+      float gsum = 0.f;
+      for (int w = (int)blockIdx.x; w < grid_l; w += L.n_loop) {
         float4 iv[ICP_PX], in_[ICP_PX];
 #pragma unroll
         for (int j = 0; j < ICP_PX; ++j) {
@@ -1111,12 +1131,14 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop_batched(IcpLoopArgs L)
         for (int k = 0; k < 27; ++k) acc[k] = 0.f;
         icp_accumulate(a, s_cur, s_linv, iv, in_, L.model_v[l], L.model_n[l], acc);
         int k; float sw;
-        if (icp_wg_reduce(acc, s_wave, k, sw))
-          __hip_atomic_store(L.slots + (size_t)step * KF_ICP_LOOP_MAX_WG * 32 + w * 32 + k,
-                             ((unsigned long long)(L.tag_base + (unsigned)step) << 32) | (unsigned long long)__float_as_uint(sw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool holder = icp_wg_reduce(acc, s_wave, k, sw);
+        if (holder) gsum = (w == (int)blockIdx.x) ? sw : gsum + sw;
         __syncthreads();                                                         // s_wave is reused by the next turn
+        if (holder && w + L.n_loop >= grid_l)                                    // the last turn: publish
+          __hip_atomic_store(L.slots + (size_t)step * KF_ICP_LOOP_MAX_WG * 32 + blockIdx.x * 32 + k,
+                             ((unsigned long long)(L.tag_base + (unsigned)step) << 32) | (unsigned long long)__float_as_uint(gsum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      n_prev = grid_l;
+      n_prev = grid_l < L.n_loop ? grid_l : L.n_loop;
     }
     if (timed_out) break;
   }
@@ -1585,7 +1607,7 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   else if (c->persistent_backoff == 0 && c->persistent_backoff_len && ++c->loop_clean_frames >= 1024) { c->persistent_backoff_len = 0; c->loop_clean_frames = 0; }
   bool use_loop = persistent_env && !c->loop_refused && grid0 <= KF_ICP_LOOP_MAX_WG && iters[0] + iters[1] + iters[2] <= KF_ICP_LOOP_STEPS &&
                   kf_live_contexts(c->cfg.device) == 1 && !kf_device_shared(c->cfg.device);
-  if (use_loop && c->loop_occupancy == 0) {
+  if (c->loop_occupancy == 0) {                              // (asked once, whatever form this call takes: the per-step form folds in the batched loop's groups)
     // every workgroup must be resident at once (they wait for each other's tagged partial sums): ask the runtime how many 512-lane
     // workgroups of THESE kernels a CU holds (registers, LDS) instead of assuming one
     int per_cu = 0, per_cu_b = 0;
@@ -1599,10 +1621,18 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   if (batched_env < 0) { const char* e = getenv("KF_ICP_BATCHED"); batched_env = e ? atoi(e) : 1; }
   int n_resident = grid0;                                    // workgroups of the loop launch
   bool batched = false;
-  if (use_loop && (c->loop_occupancy < 1 || (long long)grid0 > (long long)c->loop_occupancy * c->num_cus)) {
+  // fold_group: the publishers of a batched launch.  Every launch form of such an image adds the partial sums of the workgroups g, g + fold_group, ... first
+  // (the batched loop's resident workgroup g plays exactly those): the forms stay bitwise equal
+  int fold_group = 0;
+  {
+    const bool beyond = c->loop_occupancy < 1 || (long long)grid0 > (long long)c->loop_occupancy * c->num_cus;
     const int room = c->loop_occupancy_batched >= 1 ? c->num_cus - c->num_cus / 5 : 0;      // 256 CUs: 205 resident workgroups, 51 CUs left to the riders
-    if (batched_env && !coop_env && room >= 16) { batched = true; n_resident = room; }
-    else use_loop = false;
+    const bool can_batch = beyond && batched_env && !coop_env && room >= 16 && grid0 <= KF_ICP_LOOP_MAX_WG;
+    if (can_batch) fold_group = room;
+    if (use_loop && beyond) {
+      if (can_batch) { batched = true; n_resident = room; }
+      else use_loop = false;
+    }
   }
   if (use_loop && c->persistent_backoff > 0) { --c->persistent_backoff; use_loop = false; }
   // ICP.cpp:57-63: the four pyramids + the loop's set-up, one launch -- unless every pyramid describes its level 0 already (the raycast launch
@@ -1662,6 +1692,7 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   a.use_state = 1;
   set_thresholds(a, icp->dist_thres, icp->norm_sin_thres, icp->dist_shake, icp->angle_shake);
   a.partials = c->icp_partials; a.track = c->track;
+  a.fold_group = fold_group;
   int step = 0, prev_grid = 0;
   for (int l = c->levels - 1; l >= 0; --l)                   // coarse -> fine, ICP.cpp:65
     for (int it = 0; it < iters[l]; ++it) {

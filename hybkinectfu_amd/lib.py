@@ -87,7 +87,7 @@ SYMBOLS = [
     "kf_icp_partition_begin", "kf_icp_partition_steps", "kf_icp_partition_step", "kf_icp_partition_finish",
     "kf_sdf_partition_begin", "kf_sdf_partition_step", "kf_sdf_partition_finish", "kf_set_defer", "kf_inject_track_stall",
     "kf_download_volume_device", "kf_upload_volume_device", "kf_resize_slab", "kf_count_layer_work", "kf_read_layer_work",
-    "kf_upload_depth_mm_next", "kf_take_next_depth", "kf_cull_tail_counts",
+    "kf_upload_depth_mm_next", "kf_take_next_depth", "kf_cull_tail_counts", "kf_count_observed_voxels",
 ]
 
 
@@ -429,8 +429,18 @@ class Context:
     def stats(self):
         s = VolumeStats()
         _chk(self.lib.kf_get_volume_stats(self.h, C.byref(s)), "kf_get_volume_stats")
+        if os.environ.get("KF_STATS_CROSSCHECK") == "1":       # tests/conftest.py: every stats() call checks the running count against a sweep of the volume
+            swept = self.count_observed_voxels()
+            if swept != s.weight_gt0:
+                raise AssertionError("kf_get_volume_stats: running count of observed voxels %d != swept count %d" % (s.weight_gt0, swept))
         return dict(updated_last=s.updated_last, weight_gt0=s.weight_gt0, bricks_active=s.bricks_active, bricks_total=s.bricks_total,
                     updated_total=s.updated_total, frames_fused=s.frames_fused, frames_lost=s.frames_lost)
+
+    def count_observed_voxels(self):
+        """voxels of the owned layers with weight > 0, by a sweep of the volume (kf_get_volume_stats keeps the same number as a running count)"""
+        n = C.c_uint64()
+        _chk(self.lib.kf_count_observed_voxels(self.h, C.byref(n)), "kf_count_observed_voxels")
+        return int(n.value)
 
     def stage_timers(self, mask):
         _chk(self.lib.kf_stage_timers(self.h, int(mask)), "kf_stage_timers")

@@ -253,7 +253,11 @@ int kf_upload_map(kf_ctx* ctx, int map_id, uint32_t level, const void* src, size
  * colour (3 bytes/voxel, may be NULL).  Blocking. */
 int kf_download_volume(kf_ctx* ctx, uint32_t z_begin, uint32_t z_end, float* tsdf, float* weight, uint8_t* color);
 int kf_upload_volume(kf_ctx* ctx, uint32_t z_begin, uint32_t z_end, const float* tsdf, const float* weight, const uint8_t* color);
-int kf_get_volume_stats(kf_ctx* ctx, kf_volume_stats* out);                /* blocking */
+int kf_get_volume_stats(kf_ctx* ctx, kf_volume_stats* out);                /* blocking (a read-back; weight_gt0 is a running count kept by the fusion kernels:
+                                                                              no sweep of the volume unless an upload / slab resize came in between).
+                                                                              Reference: the per-frame count integrateVolume.cu:91-94 prints */
+int kf_count_observed_voxels(kf_ctx* ctx, uint64_t* out);                  /* the same number by a sweep of the owned layers (blocking): the tests' cross-check
+                                                                              of the running count; src/cuda/integrateVolume.cu:78-96 counts the same way */
 int kf_stored_z_range(kf_ctx* ctx, uint32_t* z_begin, uint32_t* z_end);
 
 /* z-slab re-balancing (BASELINE.json north_star "xGMI ... exchange of boundary slabs").  No reference counterpart: the reference

@@ -11,6 +11,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # every Context.stats() call of the test-suite also sweeps the volume (kf_count_observed_voxels) and compares it with the running count that
+    # kf_get_volume_stats reports: each weight_gt0 assertion against the oracle thereby checks both
+    os.environ.setdefault("KF_STATS_CROSSCHECK", "1")
 
 
 def _has_gpu():

@@ -800,3 +800,35 @@ def test_noisy_scene_parity():
     assert np.max(np.abs(pose_g[:3, 3] - pose_o[:3, 3])) < 1e-4 and np.max(np.abs(pose_g[:3, :3] - pose_o[:3, :3])) < 1e-4
     assert np.linalg.norm(pose_g[:3, 3] - poses[3][:3, 3]) < 0.01
     ctx.close()
+
+
+def test_observed_voxel_count_is_kept_running_and_rebased():
+    """kf_get_volume_stats.weight_gt0 (the reference prints the count per frame, integrateVolume.cu:91-94): asked every frame, the fusion launches switch to
+    their COUNT instantiations and the call becomes a read-back; an upload, a reset, a colour-less scalar launch or 64 frames without a question send it back
+    to a sweep.  Every answer equals the sweep (kf_count_observed_voxels) and the oracle's count."""
+    size, res, cam = 3.0, 96, mid_cam()
+    ocam, kcam = O.Cam.make(*cam), K.camera(*cam)
+    ctx = K.Context(kcam, res, size, P["volume_max_weight"], levels=3)
+    ovol = O.OVolume(res, size, P["volume_max_weight"])
+    trunc = 5 * size / res
+    for k in range(12):
+        pose = S.trajectory_pose(3 * k, size).astype(np.float32)
+        mm = S.render_depth_mm(pose, cam, size)
+        d, tr, fl, v, n = oracle_preprocess(mm, ocam)
+        O.integrate(ovol, tr, n, None, False, False, pose, trunc, 2.5, ocam, ocam)
+        ctx.upload_depth_mm(mm)
+        ctx.preprocess(P["depth_trunc_min"], P["depth_trunc_max"], P["filter_sigma_pixel"], P["filter_sigma_depth"])
+        ctx.integrate(pose, trunc, 2.5)
+        if k in (5, 6):
+            continue                                            # two frames nobody asks about: the running count must still be right afterwards
+        st = ctx.stats()                                        # (conftest: every stats() call is cross-checked against the sweep)
+        assert st["weight_gt0"] == O.count_weight_gt0(ovol) == ctx.count_observed_voxels(), k
+        if k == 8:                                              # an upload writes weights behind the count's back: re-based by the next question
+            t, w = ctx.download_volume()
+            w[:4] = 0.0; t[:4] = 0.0
+            ctx.upload_volume(t, w)
+            ovol.tsdf[:4] = 0.0; ovol.weight[:4] = 0.0
+            assert ctx.stats()["weight_gt0"] == O.count_weight_gt0(ovol)
+    ctx.reset_volume()
+    assert ctx.stats()["weight_gt0"] == 0
+    ctx.close()
