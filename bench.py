@@ -793,7 +793,7 @@ def main():
                            partition="none" if not slab else
                            "z-slab x%d (boundaries: %s); %d halo layers per side RE-INTEGRATED by both neighbours (recomputed, not exchanged per frame; when the boundaries move -- "
                            "--rebalance-every -- whole brick layers travel rank to rank: SlabMigrator); "
-                           "raycast merge = MIN all-reduce (crossing parameter + vertex parameter as one 64-bit word, 2.5 MB at VGA) + integer SUM all-reduce (normal from the vertex's owner, 4.9 MB); ICP %s"
+                           "raycast merge = MIN all-reduce (crossing parameter + vertex parameter as one 64-bit word, 2.5 MB at VGA) + integer SUM all-reduce (normal from the vertex's owner as three words, 3.7 MB); ICP %s"
                            % (world, "balanced from a one-frame 256^3 probe of the work per z-layer" if (world > 1 and args.slab_balance == "probe") else "equal thickness",
                               pipe.halo, args.icp_mode),
                            slab_ranges=([list(r) for r in pipe.ranges] if slab else None)),

@@ -722,6 +722,25 @@ extern "C" int kf_count_observed_voxels(kf_ctx* c, uint64_t* out) {
 // something other than a fusion kernel has written weights (upload, slab resize): the running count no longer describes the volume
 void kf_observed_count_invalidate(kf_ctx* c) { c->wgt0_valid = 0; }
 
+// everything kf_get_volume_stats reports EXCEPT the observed-voxel count (weight_gt0 = 0): the fusion passes' update counters, read back -- no sweep, and not
+// a "question" for the count's bookkeeping (a measurement harness that brackets its regions with this call does not switch the COUNT kernels on)
+static int read_fusion_counters(kf_ctx* c, kf_volume_stats* out, unsigned long long* fresh_out) {
+  KfCounters h;
+  KF_CHECK(hipMemcpyAsync(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  KF_CHECK(hipStreamSynchronize(c->stream));
+  unsigned long long last = 0, total = 0, fresh = 0;
+  for (int i = 0; i < 64; ++i) { last += h.upd_shard[c->last_parity][i * 16]; total += h.upd_shard[c->last_parity ^ 1][i * 16] + h.upd_total_shard[i]; fresh += h.wgt0_shard[i * 16]; }
+  out->updated_last = last; out->weight_gt0 = 0;
+  out->bricks_active = h.n_active[c->last_parity]; out->bricks_total = c->n_stored_bricks;
+  out->updated_total = total + last; out->frames_fused = h.frames_fused; out->frames_lost = h.frames_lost;
+  if (fresh_out) *fresh_out = fresh;
+  return 0;
+}
+extern "C" int kf_get_fusion_counters(kf_ctx* c, kf_volume_stats* out) {
+  if (!c || !out) return KF_ERR_ARG;
+  return read_fusion_counters(c, out, nullptr);
+}
+
 extern "C" int kf_get_volume_stats(kf_ctx* c, kf_volume_stats* out) {
   if (!c || !out) return KF_ERR_ARG;
   // weight_gt0 (the reference prints it after every integrate: integrateVolume.cu:91-94).  A host that asks now and then gets it from a sweep of the volume
@@ -741,14 +760,10 @@ extern "C" int kf_get_volume_stats(kf_ctx* c, kf_volume_stats* out) {
     KF_CHECK(hipMemsetAsync(c->counters->wgt0_shard, 0, sizeof(c->counters->wgt0_shard), c->stream));      // (stream-ordered in front of the next fusion pass)
     c->wgt0_base = n; c->wgt0_valid = 1;
   }
-  KfCounters h;
-  KF_CHECK(hipMemcpyAsync(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-  KF_CHECK(hipStreamSynchronize(c->stream));
-  unsigned long long last = 0, total = 0, fresh = 0;
-  for (int i = 0; i < 64; ++i) { last += h.upd_shard[c->last_parity][i * 16]; total += h.upd_shard[c->last_parity ^ 1][i * 16] + h.upd_total_shard[i]; fresh += h.wgt0_shard[i * 16]; }
-  out->updated_last = last; out->weight_gt0 = c->wgt0_base + fresh;
-  out->bricks_active = h.n_active[c->last_parity]; out->bricks_total = c->n_stored_bricks;
-  out->updated_total = total + last; out->frames_fused = h.frames_fused; out->frames_lost = h.frames_lost;
+  unsigned long long fresh = 0;
+  const int st = read_fusion_counters(c, out, &fresh);
+  if (st) return st;
+  out->weight_gt0 = c->wgt0_base + fresh;
   return 0;
 }
 

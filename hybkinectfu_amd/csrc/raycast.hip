@@ -225,37 +225,53 @@ __device__ __forceinline__ void rc_tile_bounds(const RaycastArgs& a, const unsig
   const float cell = v.cell, slack = 1e-3f * v.size;
   const float r_super = 0.8660254f * 1.01f * (float)(KF_MACRO << KF_SUPER_SHIFT) * cell + slack, r_macro = 0.8660254f * 1.01f * (float)KF_MACRO * cell + slack;
   unsigned* list = s_rb + 4;
-  // level 0: non-empty super cells that meet the tile's frustum -> the list
-  for (int s = (int)threadIdx.x; s < ns * ns * ns; s += RAYCAST_THREADS) {
-    if (!rc_bit(s_super, (unsigned)s)) continue;
-    const int sx = s % ns, sy = (s / ns) % ns, sz = s / (ns * ns);
-    const float h = 0.5f * (float)(KF_MACRO << KF_SUPER_SHIFT);
-    float dist;
-    if (rc_sphere_in_frustum(f, ((float)(sx * (KF_MACRO << KF_SUPER_SHIFT)) + h) * cell, ((float)(sy * (KF_MACRO << KF_SUPER_SHIFT)) + h) * cell,
-                             ((float)(sz * (KF_MACRO << KF_SUPER_SHIFT)) + h) * cell, r_super, dist)) {
-      const unsigned k = atomicAdd(&s_rb[0], 1u);
-      if (k < RC_BOUNDS_MAX) list[k] = (unsigned)s;
-    }
-  }
-  __syncthreads();
-  const unsigned n = s_rb[0];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (n <= RC_BOUNDS_MAX) {
-    // level 1: the macro cells of the listed super cells, one super cell per wave and round, one macro cell per lane
-    float lo = __builtin_huge_valf(), hi = 0.f;
-    for (unsigned k = (unsigned)wave; k < n; k += RAYCAST_THREADS / 64) {
-      const int s = (int)list[k];
-      const int mx = ((s % ns) << KF_SUPER_SHIFT) + (lane & 3), my = (((s / ns) % ns) << KF_SUPER_SHIFT) + ((lane >> 2) & 3), mz = ((s / (ns * ns)) << KF_SUPER_SHIFT) + (lane >> 4);
-      if (mx >= nm || my >= nm || mz >= nm) continue;
-      const unsigned mi = __umul24(__umul24((unsigned)mz, (unsigned)nm) + (unsigned)my, (unsigned)nm) + (unsigned)mx;
-      if (!rc_bit(s_macro, mi)) continue;
+  float lo = __builtin_huge_valf(), hi = 0.f;
+  unsigned n = 0u;
+  if (nm * nm * nm <= RAYCAST_THREADS * 16) {
+    // few macro cells (up to 512^3: 4096): every thread tests its share of them directly, bit first -- one barrier instead of two, no list
+    for (int m = (int)threadIdx.x; m < nm * nm * nm; m += RAYCAST_THREADS) {
+      if (!rc_bit(s_macro, (unsigned)m)) continue;
+      const int mx = m % nm, my = (m / nm) % nm, mz = m / (nm * nm);
       float dist;
       if (rc_sphere_in_frustum(f, ((float)(mx * KF_MACRO) + 0.5f * KF_MACRO) * cell, ((float)(my * KF_MACRO) + 0.5f * KF_MACRO) * cell, ((float)(mz * KF_MACRO) + 0.5f * KF_MACRO) * cell, r_macro, dist)) {
         lo = fminf(lo, fmaxf(dist - r_macro, 0.f)); hi = fmaxf(hi, dist + r_macro);
       }
     }
-    if (hi > 0.f) { atomicMin(&s_rb[1], __float_as_uint(lo)); atomicMax(&s_rb[2], __float_as_uint(hi)); }     // non-negative floats order like their bits
+  } else {
+    // level 0: non-empty super cells that meet the tile's frustum -> the list
+    for (int s = (int)threadIdx.x; s < ns * ns * ns; s += RAYCAST_THREADS) {
+      if (!rc_bit(s_super, (unsigned)s)) continue;
+      const int sx = s % ns, sy = (s / ns) % ns, sz = s / (ns * ns);
+      const float h = 0.5f * (float)(KF_MACRO << KF_SUPER_SHIFT);
+      float dist;
+      if (rc_sphere_in_frustum(f, ((float)(sx * (KF_MACRO << KF_SUPER_SHIFT)) + h) * cell, ((float)(sy * (KF_MACRO << KF_SUPER_SHIFT)) + h) * cell,
+                               ((float)(sz * (KF_MACRO << KF_SUPER_SHIFT)) + h) * cell, r_super, dist)) {
+        const unsigned k = atomicAdd(&s_rb[0], 1u);
+        if (k < RC_BOUNDS_MAX) list[k] = (unsigned)s;
+      }
+    }
+    __syncthreads();
+    n = s_rb[0];
+    if (n <= RC_BOUNDS_MAX) {
+      // level 1: the macro cells of the listed super cells, one super cell per wave and round, one macro cell per lane
+      for (unsigned k = (unsigned)wave; k < n; k += RAYCAST_THREADS / 64) {
+        const int s = (int)list[k];
+        const int mx = ((s % ns) << KF_SUPER_SHIFT) + (lane & 3), my = (((s / ns) % ns) << KF_SUPER_SHIFT) + ((lane >> 2) & 3), mz = ((s / (ns * ns)) << KF_SUPER_SHIFT) + (lane >> 4);
+        if (mx >= nm || my >= nm || mz >= nm) continue;
+        const unsigned mi = __umul24(__umul24((unsigned)mz, (unsigned)nm) + (unsigned)my, (unsigned)nm) + (unsigned)mx;
+        if (!rc_bit(s_macro, mi)) continue;
+        float dist;
+        if (rc_sphere_in_frustum(f, ((float)(mx * KF_MACRO) + 0.5f * KF_MACRO) * cell, ((float)(my * KF_MACRO) + 0.5f * KF_MACRO) * cell, ((float)(mz * KF_MACRO) + 0.5f * KF_MACRO) * cell, r_macro, dist)) {
+          lo = fminf(lo, fmaxf(dist - r_macro, 0.f)); hi = fmaxf(hi, dist + r_macro);
+        }
+      }
+    }
   }
+  // the wave's extremes by shuffles, then ONE pair of LDS atomics per wave (non-negative floats order like their bits)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
+  if (lane == 0 && hi > 0.f) { atomicMin(&s_rb[1], __float_as_uint(lo)); atomicMax(&s_rb[2], __float_as_uint(hi)); }
   __syncthreads();
   if (n > RC_BOUNDS_MAX) { t_lo = 0.f; t_hi = __builtin_huge_valf(); return; }
   t_lo = __uint_as_float(s_rb[1]); t_hi = __uint_as_float(s_rb[2]);
@@ -583,11 +599,11 @@ extern "C" int kf_slab_mask_candidates(kf_ctx* c, const float* dev_t, const floa
 //      alpha along (alpha 0: the reference gave up at that crossing -- the pixel stays empty, as in the sequential march);
 //   3. kf_slab_ray_normals: every rank rebuilds the winners' vertices from the rays (a pure function of pose and camera, which all ranks hold bit for bit);
 //      the rank that OWNS the vertex's voxel layer evaluates gradientForPoint (:16-42) -- its taps reach two layers, inside any halo -- and contributes
-//      (normal, 1), everybody else zeros; the previous sample's position, whose voxel the function bounds-tests, is found by replaying the chain of additions
+//      the normal (three words; all-zero bits = none), everybody else zeros; the previous sample's position, whose voxel the function bounds-tests, is found by replaying the chain of additions
 //      from t_min (:116), exactly as the march walked it;
 //   4. the caller's integer SUM all-reduce (exactly one contributor per pixel: the winner's bits, -0.0 included) and kf_set_model_maps_rays, which writes
 //      the model maps and levels 1 and 2 of their pyramids.
-// Two collectives and three launches per frame, as before; 8 + 16 bytes per pixel on the wire (was 4 + 16).
+// Two collectives and three launches per frame; 8 + 12 bytes per pixel on the wire (round 4: 8 + 16 -- the fourth word only said "valid", which a unit normal says itself).
 extern "C" int kf_raycast_volume_slab_cross(kf_ctx* c, const kf_mat44* transform, const kf_raycast_params* rp, const kf_camera_params* cam,
                                             float near_plane, float far_plane, uint64_t* dev_ta) {
   if (!c || !rp || !dev_ta) return KF_ERR_ARG;
@@ -595,7 +611,7 @@ extern "C" int kf_raycast_volume_slab_cross(kf_ctx* c, const kf_mat44* transform
   if (st) return st;
   return raycast_launch(c, 0, transform, rp, cam, near_plane, far_plane, nullptr, nullptr, nullptr, (unsigned long long*)dev_ta);
 }
-struct SlabNormalArgs { KfVolume vol; KfCam cam; const float* pose; KfMat pose_val; const unsigned long long* ta; float4* cand; float inc, near_plane, far_plane; };
+struct SlabNormalArgs { KfVolume vol; KfCam cam; const float* pose; KfMat pose_val; const unsigned long long* ta; float* cand; float inc, near_plane, far_plane; };   // cand: 3 floats per pixel
 __global__ void __launch_bounds__(256) k_slab_ray_normals(SlabNormalArgs a) {
   const int x = (int)blockIdx.x * 32 + (int)(threadIdx.x & 31), y = (int)blockIdx.y * 8 + (int)(threadIdx.x >> 5);
   if (x >= a.cam.cols || y >= a.cam.rows) return;
@@ -604,7 +620,7 @@ __global__ void __launch_bounds__(256) k_slab_ray_normals(SlabNormalArgs a) {
   const unsigned long long w = a.ta[i];
   const float t_cross = __uint_as_float((unsigned)(w >> 32));
   const unsigned alpha_bits = (unsigned)w;
-  float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+  float3 out = kf3(0.f, 0.f, 0.f);                                             // all-zero bits: not this rank's vertex, or no gradient (a found gradient is a unit vector)
   if (t_cross < __builtin_huge_valf() && alpha_bits != 0u) {
     float3 org, dir, cam_dir;
     rc_pixel_ray(a.cam, a.pose ? a.pose : a.pose_val.m, x, y, org, dir, cam_dir);
@@ -616,20 +632,20 @@ __global__ void __launch_bounds__(256) k_slab_ray_normals(SlabNormalArgs a) {
       float tmin, tmax;
       rc_ray_interval(v.size, a.near_plane, a.far_plane, org, dir, cam_dir, tmin, tmax);
       float t = tmin, t_prev = tmin;
-      while (t < t_cross) { t_prev = t; t += a.inc; }                        // the march's own chain of additions: t ends ON t_cross, t_prev on the sample before it
+      if (t < t_cross) kf_ray_advance(t, t_prev, a.inc, t_cross);            // the march's own chain of additions (its closed form, exact: kf_selftest_div mode 12): t ends ON t_cross, t_prev on the sample before it
       const float3 last_pos = kf_add(org, kf_scale(dir, t_prev));
       float3 grad;
-      if (gradient_for_point(v, last_pos, vtx, rS, rcell, grad)) out = make_float4(grad.x, grad.y, grad.z, 1.0f);
+      if (gradient_for_point(v, last_pos, vtx, rS, rcell, grad)) out = grad;
     }
   }
-  a.cand[i] = out;
+  a.cand[3 * i] = out.x; a.cand[3 * i + 1] = out.y; a.cand[3 * i + 2] = out.z;
 }
 extern "C" int kf_slab_ray_normals(kf_ctx* c, const kf_mat44* transform, const kf_raycast_params* rp, const kf_camera_params* cam,
                                    float near_plane, float far_plane, const uint64_t* dev_ta_min, float* dev_cand) {
   if (!c || !rp || !cam || !dev_ta_min || !dev_cand) return KF_ERR_ARG;
   if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
   SlabNormalArgs a;
-  a.vol = c->vol; a.ta = (const unsigned long long*)dev_ta_min; a.cand = (float4*)dev_cand;
+  a.vol = c->vol; a.ta = (const unsigned long long*)dev_ta_min; a.cand = dev_cand;
   a.cam.cols = (int)cam->cols; a.cam.rows = (int)cam->rows; a.cam.cx = cam->cx; a.cam.cy = cam->cy; a.cam.fx = cam->fx; a.cam.fy = cam->fy;
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane;
   if (transform) { for (int k = 0; k < 16; ++k) a.pose_val.m[k] = transform->m[k]; a.pose = nullptr; }
@@ -637,7 +653,7 @@ extern "C" int kf_slab_ray_normals(kf_ctx* c, const kf_mat44* transform, const k
   hipLaunchKernelGGL(k_slab_ray_normals, dim3(kf_div_up(c->cols, 32), kf_div_up(c->rows, 8)), dim3(256), 0, c->stream, a);
   return (int)hipGetLastError();
 }
-struct SlabUnpackArgs { const unsigned long long* ta; const float4* cand; float4* v; float4* n; KfCam cam; const float* pose; KfMat pose_val; KfPyrOut pyr; };
+struct SlabUnpackArgs { const unsigned long long* ta; const float* cand; float4* v; float4* n; KfCam cam; const float* pose; KfMat pose_val; KfPyrOut pyr; };   // cand: 3 floats per pixel
 // one 32x8 pixel tile per workgroup: the tile's whole 2x2 and 4x4 blocks also give levels 1 and 2 of the model maps' pyramids (kf_tile_pyramid),
 // so the tracker that follows finds them done, as after a single-GPU raycast
 __global__ void __launch_bounds__(256) k_slab_rays_unpack(SlabUnpackArgs a) {
@@ -646,8 +662,8 @@ __global__ void __launch_bounds__(256) k_slab_rays_unpack(SlabUnpackArgs a) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f), n = v;
   if (x < a.cam.cols && y < a.cam.rows) {
     const int i = y * a.cam.cols + x;
-    const float4 cd = a.cand[i];
-    if (cd.w != 0.f) {                                                       // the vertex's owner found a gradient: vertex = org + dir * alpha (raycastingVolume.cu:90), w = 1
+    const float3 cd = kf3(a.cand[3 * i], a.cand[3 * i + 1], a.cand[3 * i + 2]);
+    if ((__float_as_uint(cd.x) | __float_as_uint(cd.y) | __float_as_uint(cd.z)) != 0u) {     // the vertex's owner found a gradient (a unit vector: some bit is set): vertex = org + dir * alpha (raycastingVolume.cu:90), w = 1
       float3 org, dir, cam_dir;
       rc_pixel_ray(a.cam, a.pose ? a.pose : a.pose_val.m, x, y, org, dir, cam_dir);
       const float3 vtx = kf_add(org, kf_scale(dir, __uint_as_float((unsigned)a.ta[i])));
@@ -671,7 +687,7 @@ extern "C" int kf_set_model_maps_rays(kf_ctx* c, const kf_mat44* transform, cons
     a.pyr.v1 = c->model_v[1]; a.pyr.n1 = c->model_n[1]; a.pyr.v2 = c->model_v[2]; a.pyr.n2 = c->model_n[2];
     a.pyr.c1 = c->cols >> 1; a.pyr.r1 = c->rows >> 1; a.pyr.c2 = a.pyr.c1 >> 1; a.pyr.r2 = a.pyr.r1 >> 1;
   }
-  a.ta = (const unsigned long long*)dev_ta_min; a.cand = (const float4*)dev_cand; a.v = c->model_v[0]; a.n = c->model_n[0];
+  a.ta = (const unsigned long long*)dev_ta_min; a.cand = dev_cand; a.v = c->model_v[0]; a.n = c->model_n[0];
   a.cam.cols = (int)cam->cols; a.cam.rows = (int)cam->rows; a.cam.cx = cam->cx; a.cam.cy = cam->cy; a.cam.fx = cam->fx; a.cam.fy = cam->fy;
   if (transform) { for (int k = 0; k < 16; ++k) a.pose_val.m[k] = transform->m[k]; a.pose = nullptr; }
   else a.pose = c->track->pose;                       // the pose the raycast used: nothing moves it between the raycast and this call

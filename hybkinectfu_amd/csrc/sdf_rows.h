@@ -19,6 +19,9 @@
 //     count; the fractions and the interpolation are tolerance-side (the 27 sums are checked at 1e-5 of the largest entry against fp64).
 #pragma once
 #include "kf_internal.h"
+#ifndef SDF_TAP_BATCH
+#define SDF_TAP_BATCH 6
+#endif
 
 // adjusted base cell along one axis, the fraction inside it, and the range test of the unadjusted cell (tsdfVolume.h:50-56, :155-169)
 struct SdfCell { int g; float f; bool ok; };
@@ -213,20 +216,28 @@ __device__ __forceinline__ bool sdf_pixel_row(const KfVolume& v, const AD& S, co
   SDF_NEIGHBOUR(sv[4], czp, cz, Lz, Wz, cx.ok && cy.ok, zs[0] && zs[1], zs[1] && zs[2], zs[2] && zs[3])
   SDF_NEIGHBOUR(sv[5], czm, cz, Lz, Wz, cx.ok && cy.ok, zs[0] && zs[1], zs[1] && zs[2], zs[2] && zs[3])
 #undef SDF_NEIGHBOUR
-  // ---- the six rotated lookups: ONE batch of 48 gathers (the pixel then costs two memory round trips: this one and the 32-voxel gather above) --------
+#if SDF_TAP_BATCH < 6
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  // ---- the six rotated lookups, SDF_TAP_BATCH at a time (6: ONE batch of 48 gathers -- the pixel then costs two memory round trips, this one and the
+  // 32-voxel gather above; 2: three batches of 16, for launch shapes with fewer registers per lane and more waves to cover the round trips) --------
   float sw[6];
-  {
-    SdfTap<AD> tap[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const float4 pr = kf_mat_vec(s_m[1 + k], p4);
+  for (int k0 = 0; k0 < 6; k0 += SDF_TAP_BATCH) {
+    SdfTap<AD> tap[SDF_TAP_BATCH];
+#pragma unroll
+    for (int k = 0; k < SDF_TAP_BATCH; ++k) {
+      const float4 pr = kf_mat_vec(s_m[1 + k0 + k], p4);
       tap[k] = sdf_tap_prepare<AD>(kf3(pr.x, pr.y, pr.z), r, rS, cell, rcell, S);
     }
-    float2 qt[6][8];
+    float2 qt[SDF_TAP_BATCH][8];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) sdf_tap_load<AD>(S, tap[k], qt[k]);
+    for (int k = 0; k < SDF_TAP_BATCH; ++k) sdf_tap_load<AD>(S, tap[k], qt[k]);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { const bool o = sdf_tap_finish<AD>(tap[k], qt[k], sw[k]); ok = ok && o; }
+    for (int k = 0; k < SDF_TAP_BATCH; ++k) { const bool o = sdf_tap_finish<AD>(tap[k], qt[k], sw[k0 + k]); ok = ok && o; }
+#if SDF_TAP_BATCH < 6
+    __builtin_amdgcn_sched_barrier(0);           // (else the scheduler hoists every batch's gathers to the top: 80 loads in flight and their registers spilled)
+#endif
   }
   if (__builtin_expect(__any(off_line && ok), 0)) {
     // never taken for v_h = cell (a neighbour's cell is one to the side, give or take a rounding that keeps it on the line); kept so that the

@@ -880,16 +880,33 @@ __device__ __forceinline__ void icp_solo_finish(const IcpLoopArgs& L, float (*s_
   if (L.cull_on)                                                               // the launch's tail (cull.h), every workgroup's share in turn: nobody else is left
     for (int w = 0; w < L.n_loop; ++w) cull_tail(L.cull, s_tinv, w, L.n_loop, s_cull);
 }
+// Who ends a persistent tracking launch?  One compare-and-swap on KfTrackState::commit_word decides for every workgroup: (tag_base | 1) the launch's own
+// workgroups, (tag_base | 2) ONE workgroup that finishes it alone after a time-out.  `want`: 1 or 2; `seen0`: the word as this workgroup read it when it
+// started (an older launch's value, normally).  Returns the winner (1 or 2); *mine: this call's compare-and-swap set the word.  One lane calls.
+__device__ __forceinline__ unsigned track_commit_decide(KfTrackState* st, unsigned tag_base, unsigned want, unsigned seen0, bool* mine) {
+  unsigned expect = seen0;
+  *mine = false;
+  for (;;) {
+    if ((expect & ~63u) == tag_base) return expect & 63u;                 // this launch's word is set: somebody decided
+    const unsigned seen = atomicCAS(&st->commit_word, expect, tag_base | want);
+    if (seen == expect) { *mine = true; return want; }
+    expect = seen;                                                          // (an older word replaced by this launch's)
+  }
+}
 // a fold of the loop timed out (uniform: every lane of the workgroup is here): claim the launch or leave
-#define ICP_ON_ABORT() do { \
+// s_abort on exit of the decision: 2 this workgroup finishes the frame alone; 1 somebody else does (leave); 3 the launch's own workgroups are ending it -- only
+// possible when the time-out hit the LAST fold (a workgroup that passed it proves every partial sum of every step published, this one's included): retry that fold
+#define ICP_DECIDE_ABORT() do { \
     if (threadIdx.x == 0) { \
-      const unsigned old_ = atomicExch(&st->rescue_tag, L.tag_base); \
-      s_abort = (old_ != L.tag_base) ? 2 : 1;                      /* 2: this workgroup is the first to give up -> it finishes the frame alone */ \
-      if (s_abort == 2) __hip_atomic_store(L.stall_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+      bool mine_; \
+      const unsigned who_ = track_commit_decide(st, L.tag_base, 2u, commit_seen0, &mine_); \
+      if (who_ == 2u && mine_) { \
+        __hip_atomic_store(&st->rescue_tag, L.tag_base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      /* whoever still polls leaves */ \
+        __hip_atomic_store(L.stall_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+        s_abort = 2; \
+      } else s_abort = who_ == 2u ? 1 : 3; \
     } \
     __syncthreads(); \
-    if (s_abort == 2) ICP_SOLO_CALL; \
-    return; \
   } while (0)
 #ifdef KF_ICP_NO_SOLO          /* A/B variant only (tools/build_variant.sh): what the solo path costs the hot loop in registers / code placement */
 #define ICP_SOLO_CALL do { if (threadIdx.x == 0) { st->status = KF_TRACK_STALLED; st->tracked = 0; } } while (0)
@@ -919,6 +936,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   // injection (kf_inject_track_stall) -- the last workgroup behaves as if it never became resident
   // (the pose and the claim word are requested together: one round trip)
   const float pose_e = st->pose[threadIdx.x & 15];                             // ICP.cpp:62 cur_transform = _pose
+  const unsigned commit_seen0 = __hip_atomic_load(&st->commit_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (requested with the pose and the claim word: one round trip)
   if (__hip_atomic_load(&st->rescue_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == L.tag_base) return;
   if (L.play_dead && (int)blockIdx.x == L.n_loop - 1) return;
   if (threadIdx.x < 16) s_cur[threadIdx.x] = pose_e;
@@ -1045,9 +1063,21 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop(IcpLoopArgs L) {
   }
   if (stamp) { for (int i = 0; i < 6; ++i) st->reduced[20 + i] = seg[i]; }
   // the last step's system, then commit _pose (ICP.cpp:84)
-  if (!timed_out) fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort, 0, &st->rescue_tag, L.tag_base);
-  if (timed_out || s_abort) ICP_ON_ABORT();
+  __shared__ unsigned s_who;
+  for (;;) {
+    if (!timed_out) fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort, 0, &st->rescue_tag, L.tag_base);
+    if (!(timed_out || s_abort)) break;
+    ICP_DECIDE_ABORT();
+    if (s_abort == 2) { ICP_SOLO_CALL; return; }
+    if (s_abort != 3 || timed_out) return;                                     // somebody else finishes the launch alone
+    __syncthreads();
+    if (threadIdx.x == 0) s_abort = 0;                                         // the others are through: every sum is published, the last fold cannot wait again
+    __syncthreads();
+  }
+  // exactly one party ends the launch: a lane of an idle wave settles it while wave 0 solves; s_who is read behind apply_step's barrier
+  if (threadIdx.x == 128) { bool mine_; s_who = track_commit_decide(st, L.tag_base, 1u, commit_seen0, &mine_); }
   s_code = apply_step(a, s_tot, s_cur, nullptr, s_pose[cur_buf ^ 1]);
+  if (s_who == 2u) return;                                                     // a workgroup claimed the launch after a time-out: it commits and runs every share of the tail
   if (s_code == STEP_APPLIED) { cur_buf ^= 1; s_cur = s_pose[cur_buf]; }
   const bool tail = L.cull_on && s_code == STEP_APPLIED;                       // (uniform over the launch: every workgroup arrives at the same verdict)
   if (blockIdx.x != 0 && !tail) return;
@@ -1081,6 +1111,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop_batched(IcpLoopArgs L)
   float* s_cur = s_pose[0];
   KfTrackState* st = L.track;
   const float pose_e = st->pose[threadIdx.x & 15];                             // ICP.cpp:62 cur_transform = _pose
+  const unsigned commit_seen0 = __hip_atomic_load(&st->commit_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (__hip_atomic_load(&st->rescue_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == L.tag_base) return;
   if (L.play_dead && (int)blockIdx.x == L.n_loop - 1) return;
   if (threadIdx.x < 16) s_cur[threadIdx.x] = pose_e;
@@ -1142,9 +1173,20 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop_batched(IcpLoopArgs L)
     }
     if (timed_out) break;
   }
-  if (!timed_out) fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort, 0, &st->rescue_tag, L.tag_base);
-  if (timed_out || s_abort) ICP_ON_ABORT();
+  __shared__ unsigned s_who;
+  for (;;) {
+    if (!timed_out) fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort, 0, &st->rescue_tag, L.tag_base);
+    if (!(timed_out || s_abort)) break;
+    ICP_DECIDE_ABORT();
+    if (s_abort == 2) { ICP_SOLO_CALL; return; }
+    if (s_abort != 3 || timed_out) return;
+    __syncthreads();
+    if (threadIdx.x == 0) s_abort = 0;
+    __syncthreads();
+  }
+  if (threadIdx.x == 128) { bool mine_; s_who = track_commit_decide(st, L.tag_base, 1u, commit_seen0, &mine_); }      // (see k_icp_loop)
   s_code = apply_step(a, s_tot, s_cur, nullptr, s_pose[cur_buf ^ 1]);
+  if (s_who == 2u) return;
   if (s_code == STEP_APPLIED) { cur_buf ^= 1; s_cur = s_pose[cur_buf]; }
   if (blockIdx.x != 0) return;
   if (threadIdx.x < 27) st->reduced[threadIdx.x] = s_tot[threadIdx.x];
@@ -1233,7 +1275,9 @@ static inline void launch_sdf_step(kf_ctx* c, int grid, const TrackArgs& a) {
 // and the loop leaves as soon as the increment's norm drops below 1e-3 (SDF.cpp:87-90) -- no launches that find `converged` and return.
 // A fold that times out is finished by ONE workgroup playing every workgroup in turn (as icp_solo_finish, but the same code: `first` / `stride`), and
 // exactly one party ends the launch (KfTrackState::commit_word).
+#ifndef SDF_THREADS
 #define SDF_THREADS ICP_THREADS
+#endif
 struct SdfLoopArgs {
   KfVolume vol; const float* depth; KfCam cam;
   int max_iter;
@@ -1324,6 +1368,31 @@ __device__ __forceinline__ int sdf_apply_step_wave(const float* s_tot, float* s_
   __syncthreads();
   return *s_code;
 }
+// icp_wg_reduce for any workgroup size T (a multiple of 64): 16-lane row totals by DPP, one LDS word per (sum, row), then 4 lanes per sum add a quarter of the
+// T / 16 row totals each and two DPP shifts combine them (fixed order).  s_wave: 27 x (T / 16) floats.
+template <int T>
+__device__ __forceinline__ bool sdf_wg_reduce(float acc[27], float* s_wave, int& k, float& sw) {
+  constexpr int ROWS = T / 16, PER = ROWS / 4;
+  const int row = threadIdx.x >> 4;
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = kf_row_scan_sum(acc[i]);
+  if ((threadIdx.x & 15) == 15) {
+#pragma unroll
+    for (int i = 0; i < 27; ++i) s_wave[i * ROWS + row] = acc[i];
+  }
+  __syncthreads();
+  k = threadIdx.x >> 2; sw = 0.f;
+  if (threadIdx.x < 27 * 4) {
+    const int part = threadIdx.x & 3;
+    sw = s_wave[k * ROWS + part * PER];
+#pragma unroll
+    for (int w = 1; w < PER; ++w) sw += s_wave[k * ROWS + part * PER + w];
+    sw += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sw), 0x111, 0xf, 0xf, true));   // row_shr:1
+    sw += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sw), 0x112, 0xf, 0xf, true));   // row_shr:2
+    return part == 3;
+  }
+  return false;
+}
 template <typename AD>
 __global__ void __launch_bounds__(SDF_THREADS) k_sdf_loop(SdfLoopArgs L) {
   __shared__ float s_m[7][16];
@@ -1375,7 +1444,7 @@ __global__ void __launch_bounds__(SDF_THREADS) k_sdf_loop(SdfLoopArgs L) {
           sdf_accumulate_pixel<AD>(L.vol, S, s_m, L.cam, i, d, w_h, v_h, rS, rcell, L.slab_pixels != 0, acc);
         }
         int k; float sw;
-        if (icp_wg_reduce(acc, s_wave, k, sw))
+        if (sdf_wg_reduce<SDF_THREADS>(acc, s_wave, k, sw))
           __hip_atomic_store(L.slots + (size_t)it * KF_ICP_LOOP_MAX_WG * 32 + w * 32 + k,
                              ((unsigned long long)(L.tag_base + (unsigned)it) << 32) | (unsigned long long)__float_as_uint(sw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();                                                   // s_wave is reused by the next turn
@@ -1392,17 +1461,10 @@ __global__ void __launch_bounds__(SDF_THREADS) k_sdf_loop(SdfLoopArgs L) {
       int role;
       if (solo) role = timed_out ? 0 : 4;
       else {
-        const unsigned want = L.tag_base | (timed_out ? 2u : 1u);
-        unsigned expect = commit_seen0, seen;
-        for (;;) {
-          if ((expect & ~63u) == L.tag_base) { seen = expect; break; }     // this launch's word is set: somebody decided
-          seen = atomicCAS(&st->commit_word, expect, want);
-          if (seen == expect) { seen = want; break; }
-          expect = seen;                                                   // (an older word replaced by this launch's, or -- never on one stream -- by another's)
-        }
-        const unsigned who = seen & 63u;
+        bool mine;
+        const unsigned who = track_commit_decide(st, L.tag_base, timed_out ? 2u : 1u, commit_seen0, &mine);
         if (!timed_out) role = who == 1u ? 1 : 0;
-        else if (seen == want && expect != want) {                         // this workgroup's compare-and-swap took the word: it finishes the launch alone
+        else if (who == 2u && mine) {                                      // this workgroup's compare-and-swap took the word: it finishes the launch alone
           __hip_atomic_store(&st->rescue_tag, L.tag_base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);       // whoever still polls leaves
           __hip_atomic_store(L.stall_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           role = 2;

@@ -87,7 +87,7 @@ SYMBOLS = [
     "kf_icp_partition_begin", "kf_icp_partition_steps", "kf_icp_partition_step", "kf_icp_partition_finish",
     "kf_sdf_partition_begin", "kf_sdf_partition_step", "kf_sdf_partition_finish", "kf_set_defer", "kf_inject_track_stall",
     "kf_download_volume_device", "kf_upload_volume_device", "kf_resize_slab", "kf_count_layer_work", "kf_read_layer_work",
-    "kf_upload_depth_mm_next", "kf_take_next_depth", "kf_cull_tail_counts", "kf_count_observed_voxels",
+    "kf_upload_depth_mm_next", "kf_take_next_depth", "kf_cull_tail_counts", "kf_count_observed_voxels", "kf_get_fusion_counters",
 ]
 
 
@@ -426,8 +426,13 @@ class Context:
     def reset_volume(self):
         _chk(self.lib.kf_reset_volume(self.h), "kf_reset_volume")
 
-    def stats(self):
+    def stats(self, observed=True):
+        """observed=False: kf_get_fusion_counters -- the update counters only (weight_gt0 = 0), no sweep, no effect on the observed-voxel count's bookkeeping"""
         s = VolumeStats()
+        if not observed:
+            _chk(self.lib.kf_get_fusion_counters(self.h, C.byref(s)), "kf_get_fusion_counters")
+            return dict(updated_last=s.updated_last, weight_gt0=0, bricks_active=s.bricks_active, bricks_total=s.bricks_total,
+                        updated_total=s.updated_total, frames_fused=s.frames_fused, frames_lost=s.frames_lost)
         _chk(self.lib.kf_get_volume_stats(self.h, C.byref(s)), "kf_get_volume_stats")
         if os.environ.get("KF_STATS_CROSSCHECK") == "1":       # tests/conftest.py: every stats() call checks the running count against a sweep of the volume
             swept = self.count_observed_voxels()

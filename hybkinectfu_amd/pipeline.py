@@ -73,8 +73,9 @@ class SingleGpuPipeline:
     def sync(self):
         self.ctx.sync()
 
-    def stats(self):
-        return self.ctx.stats()
+    def stats(self, observed=False):
+        """the fusion passes' counters (updated voxels, frames fused / lost, queued bricks); observed=True adds weight_gt0 (kf_get_volume_stats)"""
+        return self.ctx.stats(observed)
 
     def stage_timers(self, mask):
         self.ctx.stage_timers(mask)
@@ -192,21 +193,21 @@ class SlabExchange:
         MIN all-reduce(ta), asynchronous       ta[px] = (crossing parameter << 32 | vertex parameter alpha) as int64: positive floats order like their bits,
           -> [overlap(): independent work]     so the first crossing along the ray wins and brings its alpha along
           -> wait
-        normals(ta, cand)                      every rank rebuilds the winners' vertices from the rays; the OWNER of a vertex's layer writes (normal, 1)
+        normals(ta, cand)                      every rank rebuilds the winners' vertices from the rays; the OWNER of a vertex's layer writes the normal (3 words)
         integer SUM all-reduce(cand bits)      exactly one rank contributes non-zero bits per pixel; integer sums keep -0.0
         unpack(ta, cand)                       -> model maps (+ pyramids) of every rank
 
     The gradient is the vertex owner's job, not the crossing owner's: the reference's vertex is an extrapolation (raycastingVolume.cu:89-90) that can land
     far from the crossing, outside that slab's halo.  `normals` / `unpack` are device launches (kf_slab_ray_normals / kf_set_model_maps_rays) in
     SlabPipeline; the CPU-only tests and `bench.py --collective-selftest` pass restatements and a gloo group, so the SAME sequence of collectives runs
-    at world_size 2 / 3 without a GPU.  8 + 16 bytes per pixel on the wire.
+    at world_size 2 / 3 without a GPU.  8 + 12 bytes per pixel on the wire.
     """
 
     def __init__(self, rows, cols, device, dist, normals, unpack):
         import torch
         self.dist, self.normals, self.unpack = dist, normals, unpack
         self.ta = torch.empty((rows, cols), dtype=torch.int64, device=device)              # this rank's crossings, then (in place) the winners
-        self.cand = torch.empty((rows, cols, 4), dtype=torch.float32, device=device)       # (normal xyz, 1) where this rank owns the winner's vertex
+        self.cand = torch.empty((rows, cols, 3), dtype=torch.float32, device=device)       # the normal where this rank owns the winner's vertex (all-zero bits elsewhere: a found normal is a unit vector)
         self.cand_bits = self.cand.view(torch.int32)
 
     def merge(self, overlap=None):
@@ -522,8 +523,8 @@ class SlabPipeline:
         self.ctx.sync()
         self.torch.cuda.synchronize()
 
-    def stats(self):
-        return self.ctx.stats()
+    def stats(self, observed=False):
+        return self.ctx.stats(observed)
 
     def stage_timers(self, mask):
         self.ctx.stage_timers(mask)

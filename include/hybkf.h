@@ -73,8 +73,8 @@ typedef struct kf_track_result {
   int32_t  tracked;         /* bool returned by findCameraPose */
   int32_t  status;          /* KF_TRACK_* */
   int32_t  iterations;      /* Gauss-Newton iterations actually applied */
-  int32_t  launch_form;     /* how the last ICP call was launched: 0 none (frame 0, SDF tracker), 1 persistent device loop, 2 one launch per
-                             * Gauss-Newton step (image too large for co-resident workgroups, GPU shared, after a stall), 3 persistent loop that timed
+  int32_t  launch_form;     /* how the last kf_icp_track / kf_sdf_track call was launched: 0 none (frame 0), 1 persistent device loop, 2 one launch per
+                             * Gauss-Newton step / iteration (GPU shared, a second context, after a stall), 3 persistent loop that timed
                              * out waiting for a workgroup that was not resident and was finished by one workgroup alone (the frame is kept,
                              * milliseconds late); the same pose bits in every form */
 } kf_track_result;
@@ -253,9 +253,13 @@ int kf_upload_map(kf_ctx* ctx, int map_id, uint32_t level, const void* src, size
  * colour (3 bytes/voxel, may be NULL).  Blocking. */
 int kf_download_volume(kf_ctx* ctx, uint32_t z_begin, uint32_t z_end, float* tsdf, float* weight, uint8_t* color);
 int kf_upload_volume(kf_ctx* ctx, uint32_t z_begin, uint32_t z_end, const float* tsdf, const float* weight, const uint8_t* color);
-int kf_get_volume_stats(kf_ctx* ctx, kf_volume_stats* out);                /* blocking (a read-back; weight_gt0 is a running count kept by the fusion kernels:
-                                                                              no sweep of the volume unless an upload / slab resize came in between).
-                                                                              Reference: the per-frame count integrateVolume.cu:91-94 prints */
+int kf_get_volume_stats(kf_ctx* ctx, kf_volume_stats* out);                /* blocking.  weight_gt0 -- the count the reference prints per frame,
+                                                                              integrateVolume.cu:91-94 -- comes from a sweep of the volume for a host that asks now
+                                                                              and then; asked twice within 8 fused frames, the fusion launches keep it as a running
+                                                                              count (+3.6 us per frame at 512^3) and the call is a read-back until 64 frames pass
+                                                                              without a question (KF_OBSERVED_COUNT=0 / 1: always sweep / always count) */
+int kf_get_fusion_counters(kf_ctx* ctx, kf_volume_stats* out);             /* the same read-back WITHOUT the observed-voxel count (weight_gt0 = 0): never sweeps, and does
+                                                                              not count as a question for that count -- what a measurement harness brackets its regions with */
 int kf_count_observed_voxels(kf_ctx* ctx, uint64_t* out);                  /* the same number by a sweep of the owned layers (blocking): the tests' cross-check
                                                                               of the running count; src/cuda/integrateVolume.cu:78-96 counts the same way */
 int kf_stored_z_range(kf_ctx* ctx, uint32_t* z_begin, uint32_t* z_end);

@@ -46,19 +46,19 @@ def ta_alpha(ta):
 
 
 def unpack(ta, cand, pose=POSE, cam=CAM):
-    """k_slab_rays_unpack: where the vertex's owner found a gradient (cand.w != 0): vertex = origin + direction * alpha, w = 1, normal = cand.xyz with w = 0;
-    zeros elsewhere."""
+    """k_slab_rays_unpack: where the vertex's owner found a gradient (cand = its three words, some bit set -- a unit vector): vertex = origin + direction * alpha,
+    w = 1, normal = cand with w = 0; zeros elsewhere."""
     c = cand.numpy()
     rows, cols = c.shape[:2]
     org, dirs = pixel_rays(pose, cam, rows, cols)
-    valid = c[..., 3] != 0
+    valid = (c.view(np.uint32) != 0).any(axis=-1)
     alpha = ta_alpha(ta).numpy()
     v = np.zeros((rows, cols, 4), np.float32)
     n = np.zeros_like(v)
     vt = org[None, None, :] + dirs * alpha[..., None]
     v[..., 0:3] = np.where(valid[..., None], vt, np.float32(0.0))
     v[..., 3] = valid.astype(np.float32)
-    n[..., 0:3] = np.where(valid[..., None], c[..., 0:3], np.float32(0.0))
+    n[..., 0:3] = np.where(valid[..., None], c, np.float32(0.0))
     return torch.from_numpy(v), torch.from_numpy(n)
 
 
@@ -95,12 +95,9 @@ def synthetic_crossings(rows, cols, rank, world, seed):
         assert torch.equal(ta_min, want_ta), "the MIN all-reduce did not deliver the first crossings"
         cand.zero_()
         sel = valid & (v_owner == rank)
-        cand[..., 0:3] = torch.where(sel.unsqueeze(-1), n_true, torch.zeros_like(n_true))
-        cand[..., 3] = sel.to(torch.float32)
+        cand.copy_(torch.where(sel.unsqueeze(-1), n_true, torch.zeros_like(n_true)))
 
-    full = torch.zeros((rows, cols, 4))
-    full[..., 0:3] = torch.where(valid.unsqueeze(-1), n_true, torch.zeros_like(n_true))
-    full[..., 3] = valid.to(torch.float32)
+    full = torch.where(valid.unsqueeze(-1), n_true, torch.zeros_like(n_true))
     want_v, want_n = unpack(want_ta, full.contiguous())
     return ta.contiguous(), normals, want_ta, full.contiguous(), want_v, want_n
 

@@ -572,7 +572,7 @@ def test_maximum_configuration_2048_cubed():
         ok, pose, status, iters = pipe.track_result()
         assert ok and status == 0 and iters == (0 if k == 0 else 19)
         assert np.linalg.norm(pose[:3, 3] - S.trajectory_pose(k, size)[:3, 3]) < 2e-3
-    st = pipe.stats()
+    st = pipe.stats(observed=True)
     assert st["frames_fused"] == n and st["frames_lost"] == 0
     assert st["updated_last"] > 4e8 and st["weight_gt0"] >= st["updated_last"] and st["bricks_active"] > 100_000      # (whole free-space bricks are retired by the cull from the second frame on: counted, not queued)
     hit = pipe.ctx.download_map(K.MAP_MODEL_VERTICES)[..., 3] != 0

@@ -77,14 +77,16 @@ def test_slabs_equal_whole_volume(world, maxw, frames, balanced):
             c.sync()
             tas.append(ta)
         ta_min = torch.stack(tas).min(dim=0).values.contiguous()
-        acc = torch.zeros((cam[1], cam[0], 4), dtype=torch.int32, device=dev)
+        acc = torch.zeros((cam[1], cam[0], 3), dtype=torch.int32, device=dev)
+        owners = torch.zeros((cam[1], cam[0]), dtype=torch.int32, device=dev)
         for c in slabs:
-            cand = torch.empty((cam[1], cam[0], 4), dtype=torch.float32, device=dev)
+            cand = torch.empty((cam[1], cam[0], 3), dtype=torch.float32, device=dev)
             c.slab_ray_normals(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], ta_min.data_ptr(), cand.data_ptr())
             c.sync()
             acc += cand.view(torch.int32)
+            owners += (cand.view(torch.int32) != 0).any(dim=-1).to(torch.int32)
         rays = acc.view(torch.float32).contiguous()
-        assert int(((rays[..., 3] != 0) & (rays[..., 3] != 1)).sum()) == 0                 # exactly one owner per vertex
+        assert int(owners.max()) == 1                                                      # exactly one owner per vertex
         for c in slabs:
             c.set_model_maps_rays(None, ta_min.data_ptr(), rays.data_ptr())
             c.sync()
@@ -236,9 +238,9 @@ def test_unpack_kernel_equals_cpu_restatement():
     ta_min = torch.stack([x[0] for x in tas]).min(dim=0).values.contiguous()
     _, _, want_ta, merged, want_v, want_n = tas[0]
     assert torch.equal(ta_min, want_ta)
-    total = torch.zeros((48, 64, 4), dtype=torch.int32)
+    total = torch.zeros((48, 64, 3), dtype=torch.int32)
     for r in range(world):                                        # every rank's normals step (also checks the winners it is handed), integer-summed
-        cand = torch.empty((48, 64, 4))
+        cand = torch.empty((48, 64, 3))
         tas[r][1](ta_min, cand)
         total += cand.view(torch.int32)
     assert torch.equal(total, merged.view(torch.int32))
@@ -496,13 +498,13 @@ def test_vertex_extrapolated_out_of_the_crossing_slab():
             c.sync()
             tas.append(ta)
         ta_min = torch.stack(tas).min(dim=0).values.contiguous()
-        acc = torch.zeros((cam[1], cam[0], 4), dtype=torch.int32, device=dev)
+        acc = torch.zeros((cam[1], cam[0], 3), dtype=torch.int32, device=dev)
         for r, c in enumerate(slabs):
-            cand = torch.empty((cam[1], cam[0], 4), dtype=torch.float32, device=dev)
+            cand = torch.empty((cam[1], cam[0], 3), dtype=torch.float32, device=dev)
             c.slab_ray_normals(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], ta_min.data_ptr(), cand.data_ptr())
             c.sync()
             acc += cand.view(torch.int32)
-            foreign += int(((cand[..., 3] == 1) & (tas[r] != ta_min)).sum())           # this slab owns the vertex of a crossing another slab met
+            foreign += int(((cand.view(torch.int32) != 0).any(dim=-1) & (tas[r] != ta_min)).sum())           # this slab owns the vertex of a crossing another slab met
         rays = acc.view(torch.float32).contiguous()
         for c in slabs:
             c.set_model_maps_rays(None, ta_min.data_ptr(), rays.data_ptr())

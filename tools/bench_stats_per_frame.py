@@ -22,7 +22,7 @@ def run(a, b, ask):
     for k in range(a, b):
         pipe.process_frame_device(dev.data_ptr() + (k % 100) * fb, k, dev.data_ptr() + ((k + 1) % 100) * fb)
         if ask:
-            last = pipe.stats()["weight_gt0"]
+            last = pipe.stats(observed=True)["weight_gt0"]
     pipe.sync()
     return last
 run(0, 10, True)

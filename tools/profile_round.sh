@@ -2,10 +2,10 @@
 # Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes (FETCH_SIZE, WRITE_SIZE) for C2 / C4 / C5 -- every bench.py
 # run launches the fusion kernel in its DEFER form (the stream's frames) and in its PLAIN read-modify-write form (the `roofline` leg behind the
 # timed region) -- and, C2 / C4, past weight saturation (--pre-frames 160); plus marching-cubes extractions (tools/bench_mcubes.py).
-# usage: tools/profile_round.sh <round-tag> [configs...] ; results under gpurun_out/<tag>/, summaries copied by hand into profiles/.
+# usage: tools/profile_round.sh <round-tag> [configs...] ; results under gpurun_out/<tag>/ (+ gpurun_out/<tag>_c3/: tools/profile_c3.sh), summaries copied by hand into profiles/.
 # (rocprofv3 is given the interpreter itself after `--`, never a wrapper; --pmc runs carry no trace flags.)
 set -o pipefail
-TAG=${1:-r04}; shift
+TAG=${1:-r05}; shift
 CFGS=${@:-c2 c4 c5}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
@@ -30,3 +30,5 @@ for kind in fetch write; do
   rocprofv3 --pmc $CT -d $OUT/pmc_${kind}_mc_c2 --output-format csv -- python3 $ROOT/tools/bench_mcubes.py c2 3 > $OUT/mc_$kind.log 2>&1 || exit 1
 done
 python3 $ROOT/tools/pmc_summary.py $OUT
+# C3: the SDF tracker's launch (k_sdf_loop) -- kernel stats + SQ / FETCH / WRITE / L2 counters (the dominant kernel of a BASELINE config had no profile)
+bash $ROOT/tools/profile_c3.sh ${TAG}_c3 k_sdf_loop > $OUT/c3.log 2>&1 || tail -5 $OUT/c3.log
