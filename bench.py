@@ -383,6 +383,35 @@ def pcie_inclusive(wl, frames_mm, n_frames=100, warmup=10, repeats=3):
                      "profiles/r05_pcie_first_run.txt)" % repeats)
 
 
+def stats_every_frame_block(wl, n_frames=150, warmup=10):
+    """A host that asks for the observed-voxel count after EVERY frame, as the reference prints it (src/cuda/integrateVolume.cu:91-94): kf_get_volume_stats is a
+    blocking read-back per frame; from the second question on the fusion launches keep the count themselves (their COUNT instantiations), so no call sweeps the
+    volume (round 4: a 0.25 ms sweep per call at 512^3, 1.5 ms at 1024^3).  The last answer is cross-checked against a sweep (kf_count_observed_voxels)."""
+    import torch
+    from hybkinectfu_amd.pipeline import SingleGpuPipeline
+    cam = wl["cam"]
+    frames, _ = S.make_stream(100, cam, wl["size"])
+    dev = torch.from_numpy(frames.astype(np.int16)).cuda()
+    fb = cam[0] * cam[1] * 2
+    pipe = SingleGpuPipeline(K.camera(*cam), wl["res"], wl["size"], wl, device=torch.cuda.current_device())
+    count = 0
+    for k in range(warmup):
+        pipe.process_frame_device(dev.data_ptr() + (k % 100) * fb, k, dev.data_ptr() + ((k + 1) % 100) * fb)
+        count = pipe.stats(observed=True)["weight_gt0"]
+    pipe.sync()
+    t0 = time.perf_counter()
+    for k in range(warmup, warmup + n_frames):
+        pipe.process_frame_device(dev.data_ptr() + (k % 100) * fb, k, dev.data_ptr() + ((k + 1) % 100) * fb)
+        count = pipe.stats(observed=True)["weight_gt0"]
+    pipe.sync()
+    dt = time.perf_counter() - t0
+    swept = pipe.ctx.count_observed_voxels()
+    pipe.close()
+    return dict(workload=wl["desc"], value=round(n_frames / dt, 2), unit="frames/s", steps=n_frames, observed_voxels=int(count), swept=int(swept), equal=bool(count == swept),
+                note="kf_get_volume_stats (blocking read-back) after every frame; the count is kept by the fusion launches, not swept (profiles/r05_observed_count.txt: "
+                     "2.1 k frames/s with a sweep per call)")
+
+
 def profiled_traffic(key):
     """HBM-side bytes per launch from the builder's rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, profiles/integrate_traffic.json), or None"""
     try:
@@ -850,6 +879,7 @@ def main():
         out["steady_state"] = {"C2": steady_state("c2"), "C4": steady_state("c4")}
         if args.config == "auto":
             out["scene_noise"] = scene_noise_block(wl)
+            out["stats_every_frame"] = stats_every_frame_block(wl)
     if world == 1 and not args.no_cpu_baseline and not wl.get("extract_mesh"):      # (the oracle's 2048^3 volume would need 103 GB of host memory)
         pipe.close()
         n_sample = 150 if wl["res"] <= 512 else 40                                    # 10-20 s of CPU work either way
