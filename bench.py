@@ -186,6 +186,30 @@ def single_gpu_reference(name, n_frames=50, warmup=10, n_unique=None, overrides=
                ms_per_step=round(1000.0 * dt / (n_frames - warmup), 4), frames_lost=int(lost),
                n_upd_per_frame=int((s1["updated_total"] - s0["updated_total"]) / max(n_frames - warmup, 1)),
                stage_us={STAGE_NAMES[i]: round(1000.0 * float(ms[i]) / max(int(cnt[i]), 1), 2) for i in (2, 3, 4, 5)})
+    if wl["res"] >= 768 and not wl.get("color"):
+        # the fusion kernel's PLAIN read-modify-write form at this size against the HBM roofline (the timed frames above ran the DEFER form): as the headline's
+        # `roofline` leg -- kf_set_defer(0), two frames for the flush, then the kernel's own dispatch time (HIP events) and N_upd over 8 frames
+        k0 = n_frames
+        pipe.ctx.set_defer(0)
+        for k in range(k0, k0 + 2):
+            pipe.process_frame_device(dev.data_ptr() + at(k) * fb, k, dev.data_ptr() + at(k + 1) * fb)
+        pipe.sync()
+        sp0 = pipe.stats()
+        pipe.stage_timers((1 << 8) | (1 << 5))
+        for k in range(k0 + 2, k0 + 10):
+            pipe.process_frame_device(dev.data_ptr() + at(k) * fb, k, dev.data_ptr() + at(k + 1) * fb)
+        pipe.sync()
+        pms, pcnt = pipe.read_stage_ms()
+        sp1 = pipe.stats()
+        pipe.stage_timers(0)
+        pipe.ctx.set_defer(-1)
+        if int(pcnt[5]) >= 5 and float(pms[5]) > 0:
+            k_ms = float(pms[5]) / int(pcnt[5])
+            alg = (sp1["updated_total"] - sp0["updated_total"]) / 8.0 * 16.0 + cam[0] * cam[1] * 4.0
+            out["plain_kernel_roofline"] = dict(bound="hbm", kernel="k_integrate_pairs (plain read-modify-write form: deferral off)", kernel_ms=round(k_ms, 5), launches_timed=int(pcnt[5]),
+                                                algorithmic_bytes_per_launch=int(alg), achieved=round(alg / (k_ms * 1e-3) / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                                                frac=round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic=profiled_traffic(wl["name"])[0],
+                                                measured="live, HIP events stamped by the kernel's own dispatch, 8 frames behind this block's timed frames with kf_set_defer(0)")
     if wl.get("extract_mesh"):
         import ctypes as C
         pipe.ctx.marching_cubes(300.0 * wl["size"] / wl["res"])        # first call allocates the extraction's scratch
