@@ -498,6 +498,34 @@ __device__ __forceinline__ bool kf_interp_finish(const KfInterp& it, const float
          q[4].x * a * ib * ic + q[5].x * a * ib * c + q[6].x * a * b * ic + q[7].x * a * b * c;
   return true;
 }
+// The same without a branch around anything that leads to a load: a lookup that fails its range test still computes (meaningless) fractions and reads voxel 0
+// of the stored volume -- valid memory, value unused -- so that the gathers of SEVERAL lookups really go out together (behind `if (ok)` each lookup's eight
+// loads sit in a block of their own with its own wait: six "batched" gradient taps were six dependent round trips).  Used by k_slab_ray_normals only: in the raycast's
+// own evaluation (pairs, 80-register cap) the branch-free form measured 8 us SLOWER at 1024^3 and equal at 512^3 (profiles/r05_raycast_bounds.txt)
+__device__ __forceinline__ KfInterp kf_interp_prepare_nb(const KfVolume& v, float3 pos, const KfRecip& rS, const KfRecip& rcell) {
+  KfInterp it;
+  const float r = (float)v.res;
+  int3 g = make_int3(kf_f2i(kf_div(pos.x * r, rS)), kf_f2i(kf_div(pos.y * r, rS)), kf_f2i(kf_div(pos.z * r, rS)));   // tsdfVolume.h:50-56
+  const int R = v.res;
+  const bool in = !(g.x <= 0 || g.x >= R - 1 || g.y <= 0 || g.y >= R - 1 || g.z <= 0 || g.z >= R - 1);
+  const float cell = v.cell;
+  g.x = (pos.x < ((float)g.x + 0.5f) * cell) ? (g.x - 1) : g.x;
+  g.y = (pos.y < ((float)g.y + 0.5f) * cell) ? (g.y - 1) : g.y;
+  g.z = (pos.z < ((float)g.z + 0.5f) * cell) ? (g.z - 1) : g.z;
+  it.g = g;
+  it.a = kf_div(pos.x - ((float)g.x + 0.5f) * cell, rcell);
+  it.b = kf_div(pos.y - ((float)g.y + 0.5f) * cell, rcell);
+  it.c = kf_div(pos.z - ((float)g.z + 0.5f) * cell, rcell);
+  it.ok = in && kf_z_stored(v, g.z) && kf_z_stored(v, g.z + 1);
+  return it;
+}
+__device__ __forceinline__ void kf_interp_load_nb(const KfVolume& v, const KfInterp& it, float2 q[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const size_t idx = kf_vox_index(v, it.g.x + (k >> 2), it.g.y + ((k >> 1) & 1), it.g.z + (k & 1));
+    q[k] = v.tw[it.ok ? idx : (size_t)0];
+  }
+}
 // two lookups, 16 gathers in flight
 __device__ __forceinline__ void kf_interpolate_sdf_pair(const KfVolume& v, float3 p1, float3 p2, const KfRecip& rS, const KfRecip& rcell,
                                                         bool& ok1, float& d1, bool& ok2, float& d2) {

@@ -37,9 +37,12 @@ struct RaycastArgs {
 };
 
 // gradientForPoint raycastingVolume.cu:16-42: bounds tested on the LAST sample's voxel, taps taken around the vertex.
-// The +/- taps of an axis are looked up as a pair (16 gathers in flight); the reference's early-outs are pure, so testing
-// the pair's verdicts in its order (+ then -) is equivalent.
+// The six taps (+x, -x, +y, -y, +z, -z) are looked up BATCH at a time (BATCH x 8 gathers in flight: 2 = the +/- pair of an axis, 3 = two round trips for the
+// six, 6 = one); the reference's early-outs are pure, so loading a batch and then testing the verdicts in its order (+ then -, x then y then z) is equivalent.
+// The interpolation itself is the reference's, operation for operation (kf_interp_prepare / kf_interp_finish).
+template <int BATCH>
 __device__ __forceinline__ bool gradient_for_point(const KfVolume& v, float3 samplepos, float3 vtx, const KfRecip& rS, const KfRecip& rcell, float3& grad) {
+  static_assert(BATCH == 2 || BATCH == 3 || BATCH == 6, "six taps in whole batches");
   const float rf = (float)v.res;
   const int3 g = make_int3(kf_f2i(kf_div(samplepos.x * rf, rS)), kf_f2i(kf_div(samplepos.y * rf, rS)), kf_f2i(kf_div(samplepos.z * rf, rS)));
   const int R = v.res;
@@ -47,16 +50,26 @@ __device__ __forceinline__ bool gradient_for_point(const KfVolume& v, float3 sam
   if (g.y <= 1 || g.y >= R - 2) return false;
   if (g.z <= 1 || g.z >= R - 2) return false;
   const float cell = v.cell;
-  float f1, f2; bool o1, o2; float3 n;
-  kf_interpolate_sdf_pair(v, kf3(vtx.x + cell, vtx.y, vtx.z), kf3(vtx.x - cell, vtx.y, vtx.z), rS, rcell, o1, f1, o2, f2);
-  if (!o1 || !o2) return false;
-  n.x = f1 - f2;
-  kf_interpolate_sdf_pair(v, kf3(vtx.x, vtx.y + cell, vtx.z), kf3(vtx.x, vtx.y - cell, vtx.z), rS, rcell, o1, f1, o2, f2);
-  if (!o1 || !o2) return false;
-  n.y = f1 - f2;
-  kf_interpolate_sdf_pair(v, kf3(vtx.x, vtx.y, vtx.z + cell), kf3(vtx.x, vtx.y, vtx.z - cell), rS, rcell, o1, f1, o2, f2);
-  if (!o1 || !o2) return false;
-  n.z = f1 - f2;
+  float f[6]; bool o[6];
+#pragma unroll
+  for (int k0 = 0; k0 < 6; k0 += BATCH) {
+    KfInterp it[BATCH]; float2 q[BATCH][8];
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const int t = k0 + k; const float d = (t & 1) ? -cell : cell;
+      const float3 p = kf3(vtx.x + ((t >> 1) == 0 ? d : 0.f), vtx.y + ((t >> 1) == 1 ? d : 0.f), vtx.z + ((t >> 1) == 2 ? d : 0.f));
+      it[k] = BATCH == 2 ? kf_interp_prepare(v, p, rS, rcell) : kf_interp_prepare_nb(v, p, rS, rcell);
+    }
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) { if (BATCH == 2) kf_interp_load(v, it[k], q[k]); else kf_interp_load_nb(v, it[k], q[k]); }     // (larger batches: no branch around the loads, so that they travel together)
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) { f[k0 + k] = 0.f; o[k0 + k] = kf_interp_finish(it[k], q[k], f[k0 + k]); }
+    // (:22-37: the reference returns at the first failing tap; every tap of this batch and the earlier ones must have succeeded to go on)
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) if (!o[k0 + k]) return false;
+  }
+  float3 n;
+  n.x = f[0] - f[1]; n.y = f[2] - f[3]; n.z = f[4] - f[5];
   float len = kf_norm(n);
   if ((double)len < 1e-8) return false;
   grad = kf_scale(n, 1 / len);                               // fp32 reciprocal (:40), unlike normalize()
@@ -71,6 +84,9 @@ __device__ __forceinline__ bool gradient_for_point(const KfVolume& v, float3 sam
 #define RC_ADVANCE kf_ray_advance_plain
 #endif
 #define RAYCAST_THREADS 512
+#ifndef RC_GRAD_BATCH
+#define RC_GRAD_BATCH 2           // taps of the crossing's gradient looked up together (2 / 3 / 6); 3 (two round trips) measured slower under the launch's 80-register cap: 46.0 vs 45.1 us at C2, 85.0 vs 83.6 at C4
+#endif
 #define RAYCAST_LDS_BYTES 49152   // budget for the two bit tables: 3 workgroups x 8 waves stay resident per CU (160 KiB LDS)
 
 // bit `i` of a packed table
@@ -371,7 +387,7 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
         const float3 vtx = kf_add(org, kf_scale(dir, alpha));
         if (a.has_color) { uchar4 c = make_uchar4(0, 0, 0, 0); kf_interpolate_color(v, vtx, c); out_c = c; }
         float3 grad;
-        if (gradient_for_point(v, last_pos, vtx, rS, rcell, grad)) {
+        if (gradient_for_point<RC_GRAD_BATCH>(v, last_pos, vtx, rS, rcell, grad)) {
           out_v = make_float4(vtx.x, vtx.y, vtx.z, 1.0f);
           out_n = make_float4(grad.x, grad.y, grad.z, 0.f);
           out_alpha = alpha;
@@ -613,7 +629,8 @@ extern "C" int kf_raycast_volume_slab_cross(kf_ctx* c, const kf_mat44* transform
 }
 struct SlabNormalArgs { KfVolume vol; KfCam cam; const float* pose; KfMat pose_val; const unsigned long long* ta; float* cand; float inc, near_plane, far_plane; };   // cand: 3 floats per pixel
 __global__ void __launch_bounds__(256) k_slab_ray_normals(SlabNormalArgs a) {
-  const int x = (int)blockIdx.x * 32 + (int)(threadIdx.x & 31), y = (int)blockIdx.y * 8 + (int)(threadIdx.x >> 5);
+  // (a workgroup is a 32x8 pixel tile, a wave an 8x8 patch of it: its 64 vertices stay inside a few bricks -- fewer cache lines per gather instruction)
+  const int x = (int)blockIdx.x * 32 + (int)(threadIdx.x >> 6) * 8 + (int)(threadIdx.x & 7), y = (int)blockIdx.y * 8 + (int)((threadIdx.x >> 3) & 7);
   if (x >= a.cam.cols || y >= a.cam.rows) return;
   const KfVolume& v = a.vol;
   const int i = y * a.cam.cols + x;
@@ -635,7 +652,7 @@ __global__ void __launch_bounds__(256) k_slab_ray_normals(SlabNormalArgs a) {
       if (t < t_cross) kf_ray_advance(t, t_prev, a.inc, t_cross);            // the march's own chain of additions (its closed form, exact: kf_selftest_div mode 12): t ends ON t_cross, t_prev on the sample before it
       const float3 last_pos = kf_add(org, kf_scale(dir, t_prev));
       float3 grad;
-      if (gradient_for_point(v, last_pos, vtx, rS, rcell, grad)) out = grad;
+      if (gradient_for_point<6>(v, last_pos, vtx, rS, rcell, grad)) out = grad;                  // (the six taps' 48 gathers in one batch: this kernel has the registers)
     }
   }
   a.cand[3 * i] = out.x; a.cand[3 * i + 1] = out.y; a.cand[3 * i + 2] = out.z;
