@@ -213,7 +213,8 @@ extern "C" int kf_create(const kf_config* cfg, kf_ctx** out) {
   v.nm = (v.res + KF_MACRO - 1) / KF_MACRO;
   v.ns = (v.nm + (1 << KF_SUPER_SHIFT) - 1) >> KF_SUPER_SHIFT;
   v.macro_words = kf_bit_words((size_t)v.nm * v.nm * v.nm); v.super_words = kf_bit_words((size_t)v.ns * v.ns * v.ns);
-  TRY(dev_alloc(&v.macrobits, (size_t)(v.macro_words + v.super_words)));
+  v.nq = (v.nb + 1) >> 1; v.meso_words = kf_bit_words((size_t)v.nq * v.nq * v.nq);
+  TRY(dev_alloc(&v.macrobits, kf_skip_table_words(v)));
   TRY(dev_alloc(&v.negbits, kf_negbit_words(c->n_stored_bricks)));
   TRY(dev_alloc(&v.pend, c->n_stored_bricks));
   TRY(dev_alloc(&c->active_bricks, c->n_stored_bricks + 8));       // + 16 aligned spare bytes behind the queue (integrate.hip: queue_pad; +8 words keeps them aligned for any count)
@@ -245,7 +246,7 @@ extern "C" int kf_reset_volume(kf_ctx* c) {
   KF_CHECK(hipMemsetAsync(c->vol.tw, 0, c->n_stored_vox * sizeof(float2), c->stream));
   if (c->vol.color) KF_CHECK(hipMemsetAsync(c->vol.color, 0, c->n_stored_vox * sizeof(uchar4), c->stream));
   KF_CHECK(hipMemsetAsync(c->vol.flags, 0, c->n_stored_bricks, c->stream));
-  KF_CHECK(hipMemsetAsync(c->vol.macrobits, 0, (size_t)(c->vol.macro_words + c->vol.super_words) * sizeof(unsigned), c->stream));
+  KF_CHECK(hipMemsetAsync(c->vol.macrobits, 0, kf_skip_table_words(c->vol) * sizeof(unsigned), c->stream));
   KF_CHECK(hipMemsetAsync(c->vol.negbits, 0, kf_negbit_words(c->n_stored_bricks) * sizeof(unsigned), c->stream));
   KF_CHECK(hipMemsetAsync(c->vol.pend, 0, c->n_stored_bricks * sizeof(unsigned long long), c->stream));
   KF_CHECK(hipMemsetAsync(c->counters, 0, sizeof(KfCounters), c->stream));
@@ -551,7 +552,7 @@ static int volume_xfer(kf_ctx* c, uint32_t z0, uint32_t z1, float* tsdf, float* 
       if (e == hipSuccess) {
         hipLaunchKernelGGL(k_volume_import, dim3(grid), dim3(256), 0, c->stream, c->vol, (int)z0, (int)z1, dt, dw, dc);
         int fg = (int)(c->n_stored_bricks > 4096 ? 4096 : c->n_stored_bricks);
-        hipMemsetAsync(c->vol.macrobits, 0, (size_t)(c->vol.macro_words + c->vol.super_words) * sizeof(unsigned), c->stream);   // rebuilt with the flags
+        hipMemsetAsync(c->vol.macrobits, 0, kf_skip_table_words(c->vol) * sizeof(unsigned), c->stream);   // rebuilt with the flags
         hipLaunchKernelGGL(k_rebuild_flags, dim3(fg), dim3(256), 0, c->stream, c->vol, c->n_stored_bricks);
       }
     }
@@ -598,7 +599,7 @@ extern "C" int kf_upload_volume_device(kf_ctx* c, uint32_t z0, uint32_t z1, cons
   const int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
   hipLaunchKernelGGL(k_volume_import, dim3(grid), dim3(256), 0, c->stream, c->vol, (int)z0, (int)z1, dev_tsdf, dev_weight, (const unsigned char*)dev_color);
   const int fg = (int)(c->n_stored_bricks > 4096 ? 4096 : c->n_stored_bricks);
-  KF_CHECK(hipMemsetAsync(c->vol.macrobits, 0, (size_t)(c->vol.macro_words + c->vol.super_words) * sizeof(unsigned), c->stream));   // rebuilt with the flags
+  KF_CHECK(hipMemsetAsync(c->vol.macrobits, 0, kf_skip_table_words(c->vol) * sizeof(unsigned), c->stream));   // rebuilt with the flags
   hipLaunchKernelGGL(k_rebuild_flags, dim3(fg), dim3(256), 0, c->stream, c->vol, c->n_stored_bricks);
   return (int)hipGetLastError();
 }
@@ -663,7 +664,7 @@ extern "C" int kf_resize_slab(kf_ctx* c, uint32_t z_begin, uint32_t z_end, uint3
   c->n_stored_bricks = n_new; c->n_stored_vox = n_new * KF_BRICK_VOX; c->mc_blocks_cap = (c->n_stored_vox + 255) / 256;
   ++c->vol_flags_serial; c->pend_live = 0;
   // brick flags, has-negative bits and the macro / super cell tables of what is stored now
-  KF_CHECK(hipMemsetAsync(v.macrobits, 0, (size_t)(v.macro_words + v.super_words) * sizeof(unsigned), c->stream));
+  KF_CHECK(hipMemsetAsync(v.macrobits, 0, kf_skip_table_words(v) * sizeof(unsigned), c->stream));
   hipLaunchKernelGGL(k_rebuild_flags, dim3((unsigned)(n_new > 4096 ? 4096 : n_new)), dim3(256), 0, c->stream, v, n_new);
   KF_CHECK(hipStreamSynchronize(c->stream));
   return (int)hipGetLastError();

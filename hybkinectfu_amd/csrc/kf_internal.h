@@ -53,13 +53,15 @@ struct KfVolume {
   float2* tw;            // (tsdf, weight) per voxel
   uchar4* color;         // (c0, c1, c2, unused) per voxel; null when the context has no colour
   uint8_t* flags;        // per brick KF_FLAG_*
-  unsigned* macrobits;   // two packed bit tables over the WHOLE volume, [macro_words | super_words]: bit = some voxel of the 32^3-voxel macro cell /
+  unsigned* macrobits;   // packed bit tables over the WHOLE volume, [macro_words | super_words | meso_words]: bit = some voxel of the 32^3-voxel macro cell /
                          // of the 128^3-voxel super cell has (had) tsdf < 0; set with atomicOr by whoever finds a brick's first negative voxel
   unsigned* negbits;     // one bit per STORED brick slot: the brick's KF_FLAG_HASNEG, packed so the raycast can keep the table in LDS
   unsigned long long* pend;   // per STORED brick slot: four 16-bit deferred-weight words (quarter q at bits 16q), see KF_PEND_SAT above
   int nm;                // macro cells per axis = ceil(res / 32)
   int ns;                // super cells per axis = ceil(nm / 4)
   int macro_words, super_words;   // words of the two tables (each padded to whole 16-byte vectors)
+  int nq, meso_words;             // a third table behind them (round 5): one bit per MESO cell = 2 x 2 x 2 bricks (16^3 voxels), nq cells per axis; the raycast keeps it in LDS
+                                  // when it fits (1024^3: 32 KiB, where the per-brick bits -- 256 KiB -- do not) and walks two bricks at a time through empty meso cells
   int res;               // voxels per axis
   int nb;                // bricks per axis
   int bz0, bz1;          // stored brick layers
@@ -409,7 +411,10 @@ __device__ __forceinline__ void kf_mark_macro(const KfVolume& v, int bx, int by,
   atomicOr(&v.macrobits[mi >> 5], 1u << (mi & 31u));
   const unsigned si = (unsigned)((((mz >> KF_SUPER_SHIFT) * v.ns) + (my >> KF_SUPER_SHIFT)) * v.ns + (mx >> KF_SUPER_SHIFT));
   atomicOr(&v.macrobits[v.macro_words + (si >> 5)], 1u << (si & 31u));
+  const unsigned qi = (unsigned)((((bz >> 1) * v.nq) + (by >> 1)) * v.nq + (bx >> 1));       // the meso cell: 2 bricks per edge
+  atomicOr(&v.macrobits[v.macro_words + v.super_words + (qi >> 5)], 1u << (qi & 31u));
 }
+__host__ __device__ static inline size_t kf_skip_table_words(const KfVolume& v) { return (size_t)v.macro_words + (size_t)v.super_words + (size_t)v.meso_words; }
 __device__ __forceinline__ unsigned kf_brick_slot(const KfVolume& v, int bx, int by, int bz) {
   return __umul24(__umul24((unsigned)(bz - v.bz0), (unsigned)v.nb) + (unsigned)by, (unsigned)v.nb) + (unsigned)bx;
 }

@@ -31,6 +31,7 @@ struct RaycastArgs {
   float inc, near_plane, far_plane;
   int has_color;
   int neg_words;                 // words of vol.negbits to keep in LDS (0: the table does not fit -> brick flags are read from global memory)
+  int meso_words;                // words of the meso table (16^3-voxel cells) to keep in LDS behind the macro / super tables (0: it does not fit)
   int tile_bounds;               // 1: every workgroup first bounds its tile's rays by the non-empty macro cells its frustum meets (rc_tile_bounds; KF_RAYCAST_BOUNDS=0: off)
   int exp_mode;                  // timing experiments only (KF_RAYCAST_EXP): 1 = stop at the crossing without evaluating it
   KfCounters* work;              // measurement passes only (kf_stage_timers bit 16): count the reference march's samples and the hits
@@ -98,14 +99,15 @@ __device__ __forceinline__ bool rc_bit(const unsigned* words, unsigned i) { retu
 // sample's tsdf is fetched on demand), so a ray's range may be marched in pieces by different lanes: the first crossing of the ray
 // is the first piece's that has one.
 struct RcRay { float3 org, dir, inv_dir; };
-__device__ __forceinline__ void rc_march(const RaycastArgs& a, const KfVolume& v, const unsigned* s_macro, const unsigned* s_super, const unsigned* s_neg, bool neg_in_lds, const RcRay& ray,
+__device__ __forceinline__ void rc_march(const RaycastArgs& a, const KfVolume& v, const unsigned* s_macro, const unsigned* s_super, const unsigned* s_meso, const unsigned* s_neg, bool neg_in_lds, const RcRay& ray,
                                          const KfRecip& rS, float t_end, float& t, float& t_prev, bool& have_last, float& last_sdf,
                                          float& t_cross, float& t_cross_prev, int& n_iter, int& n_samp, int& n_macro) {
   const float3 org = ray.org, dir = ray.dir;
   const int R = v.res;
   const float rf = (float)R;
   const int zs0 = v.bz0 * KF_BRICK, zs1 = v.bz1 * KF_BRICK;
-  const int nm = v.nm, ns = v.ns;
+  const int nm = v.nm, ns = v.ns, nq = v.nq;
+  const bool meso_in_lds = a.meso_words != 0;
   // the empty-space walk measures in VOXEL units along each axis: with q the sample's (unrounded) voxel coordinate and `base` the first voxel
   // of its cell (32 voxels wide for a macro cell, 8 for a brick), the cell's far face lies E - (q - base) voxels ahead for a ray going up
   // the axis and q - base voxels for one going down: one fused multiply-add per axis with the ray's constants sgn / up, times cell / |dir|
@@ -137,8 +139,12 @@ __device__ __forceinline__ void rc_march(const RaycastArgs& a, const KfVolume& v
     // level 0: the 128^3-voxel super cell (4 x 4 x 4 macro cells) the same way -- two thirds of a ray's trips were macro cells of open space
     const bool super_empty = !rc_bit(s_super, __umul24(__umul24((unsigned)(mz >> KF_SUPER_SHIFT), (unsigned)ns) + (unsigned)(my >> KF_SUPER_SHIFT), (unsigned)ns) + (unsigned)(mx >> KF_SUPER_SHIFT));
     const bool owned = gz >= v.own_z0 && gz < v.own_z1;
+    // level 1.5 (round 5): the 16^3-voxel meso cell (2 x 2 x 2 bricks) -- inside a non-empty macro cell most bricks are still empty, and at 1024^3 the per-brick bits do
+    // not fit into LDS (every brick-level trip then reads the flag byte from global memory): the meso bits do (32 KiB), and an empty meso cell is walked in one trip
+    const bool meso_empty = meso_in_lds && !macro_empty &&
+                            !rc_bit(s_meso, __umul24(__umul24((unsigned)(gz >> 4), (unsigned)nq) + (unsigned)(gy >> 4), (unsigned)nq) + (unsigned)(gx >> 4));
     size_t slot = 0; bool has_neg = false;
-    if (!macro_empty && owned) {
+    if (!macro_empty && !meso_empty && owned) {
       slot = kf_brick_slot(v, gx >> 3, gy >> 3, gz >> 3);
       has_neg = neg_in_lds ? rc_bit(s_neg, (unsigned)slot) : (v.flags[slot] & KF_FLAG_HASNEG) != 0;
     }
@@ -147,12 +153,12 @@ __device__ __forceinline__ void rc_march(const RaycastArgs& a, const KfVolume& v
       // macro cell: walk to its far side; owned brick with the table an LDS read away: brick by brick is cheaper than sample by
       // sample (the cell is the VOXEL's brick: if rounding put pos a hair outside it, the walk is merely shorter, never past the
       // far face); otherwise one sample
-      const bool walk = macro_empty || (owned && neg_in_lds);
+      const bool walk = macro_empty || meso_empty || (owned && neg_in_lds);
       if (walk) {
         const int sup = (KF_MACRO << KF_SUPER_SHIFT);
-        const int mask = super_empty ? ~(sup - 1) : macro_empty ? ~31 : ~7;
-        const float edge = super_empty ? (float)sup : macro_empty ? 32.f : 8.f;
-        const float eps = super_empty ? 1e-4f * (float)sup : macro_empty ? 3.2e-3f : 8e-3f;       // eps: 1e-4 / 1e-4 / 1e-3 of the cell edge, in voxels
+        const int mask = super_empty ? ~(sup - 1) : macro_empty ? ~31 : meso_empty ? ~15 : ~7;
+        const float edge = super_empty ? (float)sup : macro_empty ? 32.f : meso_empty ? 16.f : 8.f;
+        const float eps = super_empty ? 1e-4f * (float)sup : macro_empty ? 3.2e-3f : meso_empty ? 4e-3f : 8e-3f;       // eps: 1e-4 / 1e-4 / 2.5e-4 / 1e-3 of the cell edge, in voxels
         // the exit parameter only has to be conservative (eps and the 1e-6 t margin absorb a few ulps)
         const float dx = __builtin_fmaf(qx - (float)(gx & mask), sgn.x, up.x * edge) - eps;
         const float dy = __builtin_fmaf(qy - (float)(gy & mask), sgn.y, up.y * edge) - eps;
@@ -302,9 +308,10 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
 #ifdef KF_EXPERIMENTS
   const unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #endif
-  const int skip_words = v.macro_words + v.super_words;          // multiples of 4: everything is moved as uint4
+  const int skip_words = v.macro_words + v.super_words + a.meso_words;   // multiples of 4: everything is moved as uint4 (the meso table lies behind the other two: one copy)
   const unsigned* s_macro = s_tables;
   const unsigned* s_super = s_tables + v.macro_words;
+  const unsigned* s_meso = s_tables + v.macro_words + v.super_words;
   const unsigned* s_neg = s_tables + skip_words;
   __shared__ unsigned s_rb[RC_BOUNDS_WORDS];
   if (threadIdx.x == 0) { s_rb[0] = 0u; s_rb[1] = 0x7F800000u; s_rb[2] = 0u; s_rb[3] = 0u; }
@@ -366,7 +373,7 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
     // the tile's bounds (rc_tile_bounds): nothing before tile_lo or from tile_hi on can be a crossing's negative sample; the long first walk in closed form
     t_end = fminf(t_end, tile_hi);
     if (t < tile_lo && t < t_end) { kf_ray_advance(t, t_prev, a.inc, fminf(tile_lo, t_end)); have_last = false; }
-    rc_march(a, v, s_macro, s_super, s_neg, neg_in_lds, ray, rS, t_end, t, t_prev, have_last, last_sdf, t_cross, t_cross_prev, n_iter, n_samp, n_macro);
+    rc_march(a, v, s_macro, s_super, s_meso, s_neg, neg_in_lds, ray, rS, t_end, t, t_prev, have_last, last_sdf, t_cross, t_cross_prev, n_iter, n_samp, n_macro);
 #ifdef KF_EXPERIMENTS
     st2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -500,9 +507,14 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
   { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_RAYCAST_EXP"); a.exp_mode = em; }
   { static int tb = -1; if (tb < 0) { const char* e = getenv("KF_RAYCAST_BOUNDS"); tb = e ? atoi(e) : 1; } a.tile_bounds = tb; }
   a.work = c->count_work ? c->counters : nullptr;
-  const size_t macro_bytes = (size_t)(c->vol.macro_words + c->vol.super_words) * 4, neg_bytes = kf_negbit_words(c->n_stored_bricks) * 4;
-  a.neg_words = (macro_bytes + neg_bytes <= RAYCAST_LDS_BYTES) ? (int)(neg_bytes / 4) : 0;
+  size_t macro_bytes = (size_t)(c->vol.macro_words + c->vol.super_words) * 4;
+  const size_t neg_bytes = kf_negbit_words(c->n_stored_bricks) * 4, meso_bytes = (size_t)c->vol.meso_words * 4;
   if (macro_bytes > RAYCAST_LDS_BYTES) return KF_ERR_STATE;
+  static int meso_env = -1;
+  if (meso_env < 0) { const char* e = getenv("KF_RAYCAST_MESO"); meso_env = e ? atoi(e) : 1; }
+  a.meso_words = (meso_env && macro_bytes + meso_bytes <= RAYCAST_LDS_BYTES) ? c->vol.meso_words : 0;      // (2048^3: 256 KiB, no)
+  macro_bytes += (size_t)a.meso_words * 4;                  // from here on: everything in front of the per-brick bits
+  a.neg_words = (macro_bytes + neg_bytes <= RAYCAST_LDS_BYTES) ? (int)(neg_bytes / 4) : 0;
   kf_evt_begin(c, KF_STAGE_RAYCAST);
   {
     hipEvent_t ke0 = nullptr, ke1 = nullptr;               // the kernel's own timer rides on its dispatch (kf_evt_attach): the kernel as rocprofv3 sees it
