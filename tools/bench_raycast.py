@@ -45,6 +45,17 @@ if os.environ.get("KF_RAYCAST_EXP") == "3":
     print("march ticks per wave ~ %.0f + %.0f x max trips + %.0f x max samples + %.0f x sampling lanes   (mean %.0f, residual rms %.0f)" % (coef[0], coef[1], coef[2], coef[3], mt.mean(), np.sqrt(((A @ coef - mt) ** 2).mean())))
     slow = np.argsort(mt)[-len(mt) // 50:]
     print("slowest 2%% of waves: march ticks %.0f, max trips %.1f, max samples %.1f, sampling lanes %.1f, eval ticks %.0f" % (mt[slow].mean(), tr.max(axis=1)[slow].mean(), sm.max(axis=1)[slow].mean(), (sm > 0).sum(axis=1)[slow].mean(), v[..., 2].reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)[:, 0][slow].mean()))
+    # how coherent are the slow waves?  (would finishing a few long rays cooperatively inside their wave help, or are all 64 rays of a slow wave long?)
+    mx = tr.max(axis=1)
+    slowest = np.argsort(mx)[-len(mx) // 20:]
+    for thr in (8, 12):
+        act = (tr[slowest] > thr).sum(axis=1)
+        print("slowest 5%% of waves: lanes still marching after %2d trips: mean %.1f, median %.0f, <= 8 lanes in %.0f %% of them; their max trips %.1f, mean trips %.1f" % (
+            thr, act.mean(), np.median(act), 100.0 * (act <= 8).mean(), mx[slowest].mean(), tr[slowest].mean()))
+    wg = mx.reshape(H // 8, W // 8)
+    wgmax = wg.reshape(H // 16, 2, W // 32, 4).max(axis=(1, 3))
+    print("per-WORKGROUP max trips: mean %.1f p99 %.0f max %.0f; waves of the slowest 5%% of workgroups: mean of their wave-max %.1f" % (
+        wgmax.mean(), np.percentile(wgmax, 99), wgmax.max(), wg.reshape(H // 16, 2, W // 32, 4).transpose(0, 2, 1, 3).reshape(-1, 8)[np.argsort(wgmax.reshape(-1))[-len(wgmax.reshape(-1)) // 20:]].mean()))
     # per 8x8 patch (= one wave): the wave runs as long as its slowest lane
     trips = v[..., 3].reshape(v.shape[0] // 8, 8, v.shape[1] // 8, 8).max(axis=(1, 3))
     print("per-wave max trips: mean %.1f  p99 %.0f  max %.0f" % (trips.mean(), np.percentile(trips, 99), trips.max()))
