@@ -1134,6 +1134,15 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop_batched(IcpLoopArgs L)
     int px_l, grid_l;
     icp_level_geometry(npx, L.n_virtual, l, px_l, grid_l);
     for (int it = 0; it < L.iters[l]; ++it, ++step) {
+      // this step's FIRST turn's pixels are requested before the previous step's sums are waited for (they depend on the level only): in flight during the fold;
+      // every later turn's pixels are requested one turn ahead (below)
+      float4 ivn[ICP_PX], inn[ICP_PX];
+#pragma unroll
+      for (int j = 0; j < ICP_PX; ++j) {
+        const int i = icp_dealt_pixel_of(j, grid_l, (int)blockIdx.x);
+        ivn[j] = make_float4(0.f, 0.f, 0.f, 0.f); inn[j] = ivn[j];
+        if ((int)blockIdx.x < grid_l && j < px_l && i < npx) { ivn[j] = new_v[i]; inn[j] = new_n[i]; }
+      }
       if (step > 0) {
         fold_partials_tagged(L.slots + (size_t)(step - 1) * KF_ICP_LOOP_MAX_WG * 32, n_prev, L.tag_base + (unsigned)(step - 1), s_tot, &s_abort, 0, &st->rescue_tag, L.tag_base);
         if (s_abort) { timed_out = true; break; }
@@ -1149,13 +1158,19 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_loop_batched(IcpLoopArgs L)
       // published as ONE set of 27 words -- a step's fold then walks n_loop x 27 tagged words (205 at 1280x960), not grid_l x 27 (800): round 4's batched
       // loop spent four polling passes per step on them.  The per-step form folds its 800 partials in the same groups (fold_partials, TrackArgs::fold_group).
       float gsum = 0.f;
+      // the NEXT turn's pixels are requested before this turn's pixel phase: a turn's own loads (L2 / Infinity Cache, ~1 us) would otherwise be exposed three or
+      // four times per step -- the workgroups of a step reach the exchange that much earlier
       for (int w = (int)blockIdx.x; w < grid_l; w += L.n_loop) {
         float4 iv[ICP_PX], in_[ICP_PX];
 #pragma unroll
-        for (int j = 0; j < ICP_PX; ++j) {
-          const int i = icp_dealt_pixel_of(j, grid_l, w);
-          iv[j] = make_float4(0.f, 0.f, 0.f, 0.f); in_[j] = iv[j];
-          if (j < px_l && i < npx) { iv[j] = new_v[i]; in_[j] = new_n[i]; }
+        for (int j = 0; j < ICP_PX; ++j) { iv[j] = ivn[j]; in_[j] = inn[j]; }
+        if (w + L.n_loop < grid_l) {
+#pragma unroll
+          for (int j = 0; j < ICP_PX; ++j) {
+            const int i = icp_dealt_pixel_of(j, grid_l, w + L.n_loop);
+            ivn[j] = make_float4(0.f, 0.f, 0.f, 0.f); inn[j] = ivn[j];
+            if (j < px_l && i < npx) { ivn[j] = new_v[i]; inn[j] = new_n[i]; }
+          }
         }
         float acc[27];
 #pragma unroll
