@@ -13,9 +13,12 @@
 //   * bricks are 4 KiB contiguous, so the trilinear taps at the hit (2 + 6 lookups x 8 voxels) touch 1-2 bricks.
 #include "kf_internal.h"
 #include "bilateral_tile.h"
+#include "grad_shared.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <string.h>
+
+static int rc_shared_grad_env() { static int sg = -1; if (sg < 0) { const char* e = getenv("KF_RAYCAST_SHARED_GRAD"); sg = e ? atoi(e) : 1; } return sg; }
 
 struct RaycastArgs {
   KfVolume vol;
@@ -32,6 +35,7 @@ struct RaycastArgs {
   int has_color;
   int neg_words;                 // words of vol.negbits to keep in LDS (0: the table does not fit -> brick flags are read from global memory)
   int meso_words;                // words of the meso table (16^3-voxel cells) to keep in LDS behind the macro / super tables (0: it does not fit)
+  int shared_grad;               // 1: a crossing's six gradient taps come from one 32-voxel neighbourhood (grad_shared.h; KF_RAYCAST_SHARED_GRAD=0: six separate lookups; 2: shared, with every other wave forced down the fallback -- tests)
   int tile_bounds;               // 1: every workgroup first bounds its tile's rays by the non-empty macro cells its frustum meets (rc_tile_bounds; KF_RAYCAST_BOUNDS=0: off)
   int exp_mode;                  // timing experiments only (KF_RAYCAST_EXP): 1 = stop at the crossing without evaluating it
   KfCounters* work;              // measurement passes only (kf_stage_timers bit 16): count the reference march's samples and the hits
@@ -77,6 +81,16 @@ __device__ __forceinline__ bool gradient_for_point(const KfVolume& v, float3 sam
   return true;
 }
 
+// The same verdict and gradient from the shared neighbourhood (grad_shared.h): nine cell computations and 32 gathers instead of 18 and 48.  A wave in which
+// some lane's tap cell is not "vtx's cell moved by one" -- and whose verdict is not false already -- evaluates the generic way, all lanes together.
+template <int BATCH, int ROUNDS>
+__device__ __forceinline__ bool gradient_for_point_either(int shared, bool odd_wave, const KfVolume& v, float3 samplepos, float3 vtx, const KfRecip& rS, const KfRecip& rcell, float3& grad) {
+  int verdict = 2;
+  if (shared) verdict = rc_gradient_shared<ROUNDS>(v, samplepos, vtx, rS, rcell, shared == 2 && odd_wave, grad);       // (`shared` is a launch argument: uniform; 2: every other wave is sent down the generic path)
+  if (verdict == 2) verdict = gradient_for_point<BATCH>(v, samplepos, vtx, rS, rcell, grad) ? 1 : 0;
+  return verdict == 1;
+}
+
 // the walk of the ray parameter: the chain of additions itself.  Its closed form (kf_ray_advance: exact, self-tested) is 3-4 % SLOWER here --
 // a walk is 1-12 additions at the stock increment (4.5 voxels) and the chain costs three instructions per step (-DKF_RAY_ADVANCE_CLOSED for the A/B)
 #ifdef KF_RAY_ADVANCE_CLOSED
@@ -87,6 +101,9 @@ __device__ __forceinline__ bool gradient_for_point(const KfVolume& v, float3 sam
 #define RAYCAST_THREADS 512
 #ifndef RC_GRAD_BATCH
 #define RC_GRAD_BATCH 2           // taps of the crossing's gradient looked up together (2 / 3 / 6); 3 (two round trips) measured slower under the launch's 80-register cap: 46.0 vs 45.1 us at C2, 85.0 vs 83.6 at C4
+#endif
+#ifndef RC_GRAD_ROUNDS
+#define RC_GRAD_ROUNDS 4          // the shared-neighbourhood form of those taps (grad_shared.h): gathers in 1 / 2 / 4 dependent rounds of 32 / 16 / 8
 #endif
 #define RAYCAST_LDS_BYTES 49152   // budget for the two bit tables: 3 workgroups x 8 waves stay resident per CU (160 KiB LDS)
 
@@ -403,7 +420,7 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
         const float3 vtx = kf_add(org, kf_scale(dir, alpha));
         if (a.has_color) { uchar4 c = make_uchar4(0, 0, 0, 0); kf_interpolate_color(v, vtx, c); out_c = c; }
         float3 grad;
-        if (gradient_for_point<RC_GRAD_BATCH>(v, last_pos, vtx, rS, rcell, grad)) {
+        if (gradient_for_point_either<RC_GRAD_BATCH, RC_GRAD_ROUNDS>(a.shared_grad, ((tile_x + tile_y + wave) & 1) != 0, v, last_pos, vtx, rS, rcell, grad)) {
           out_v = make_float4(vtx.x, vtx.y, vtx.z, 1.0f);
           out_n = make_float4(grad.x, grad.y, grad.z, 0.f);
           out_alpha = alpha;
@@ -515,6 +532,7 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
   { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_RAYCAST_EXP"); a.exp_mode = em; }
   { static int tb = -1; if (tb < 0) { const char* e = getenv("KF_RAYCAST_BOUNDS"); tb = e ? atoi(e) : 1; } a.tile_bounds = tb; }
+  a.shared_grad = rc_idx32_fits(c->vol) ? rc_shared_grad_env() : 0;
   a.work = c->count_work ? c->counters : nullptr;
   size_t macro_bytes = (size_t)(c->vol.macro_words + c->vol.super_words) * 4;
   const size_t neg_bytes = kf_negbit_words(c->n_stored_bricks) * 4, meso_bytes = (size_t)c->vol.meso_words * 4;
@@ -648,7 +666,7 @@ extern "C" int kf_raycast_volume_slab_cross(kf_ctx* c, const kf_mat44* transform
   if (st) return st;
   return raycast_launch(c, 0, transform, rp, cam, near_plane, far_plane, nullptr, nullptr, nullptr, (unsigned long long*)dev_ta);
 }
-struct SlabNormalArgs { KfVolume vol; KfCam cam; const float* pose; KfMat pose_val; const unsigned long long* ta; float* cand; float inc, near_plane, far_plane; };   // cand: 3 floats per pixel
+struct SlabNormalArgs { KfVolume vol; KfCam cam; const float* pose; KfMat pose_val; const unsigned long long* ta; float* cand; float inc, near_plane, far_plane; int shared_grad; };   // cand: 3 floats per pixel
 __global__ void __launch_bounds__(256) k_slab_ray_normals(SlabNormalArgs a) {
   // (a workgroup is a 32x8 pixel tile, a wave an 8x8 patch of it: its 64 vertices stay inside a few bricks -- fewer cache lines per gather instruction)
   const int x = (int)blockIdx.x * 32 + (int)(threadIdx.x >> 6) * 8 + (int)(threadIdx.x & 7), y = (int)blockIdx.y * 8 + (int)((threadIdx.x >> 3) & 7);
@@ -673,7 +691,7 @@ __global__ void __launch_bounds__(256) k_slab_ray_normals(SlabNormalArgs a) {
       if (t < t_cross) kf_ray_advance(t, t_prev, a.inc, t_cross);            // the march's own chain of additions (its closed form, exact: kf_selftest_div mode 12): t ends ON t_cross, t_prev on the sample before it
       const float3 last_pos = kf_add(org, kf_scale(dir, t_prev));
       float3 grad;
-      if (gradient_for_point<6>(v, last_pos, vtx, rS, rcell, grad)) out = grad;                  // (the six taps' 48 gathers in one batch: this kernel has the registers)
+      if (gradient_for_point_either<6, 1>(a.shared_grad, ((blockIdx.x + blockIdx.y + (threadIdx.x >> 6)) & 1u) != 0u, v, last_pos, vtx, rS, rcell, grad)) out = grad;                  // (the six taps' 48 gathers in one batch: this kernel has the registers)
     }
   }
   a.cand[3 * i] = out.x; a.cand[3 * i + 1] = out.y; a.cand[3 * i + 2] = out.z;
@@ -686,6 +704,7 @@ extern "C" int kf_slab_ray_normals(kf_ctx* c, const kf_mat44* transform, const k
   a.vol = c->vol; a.ta = (const unsigned long long*)dev_ta_min; a.cand = dev_cand;
   a.cam.cols = (int)cam->cols; a.cam.rows = (int)cam->rows; a.cam.cx = cam->cx; a.cam.cy = cam->cy; a.cam.fx = cam->fx; a.cam.fy = cam->fy;
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane;
+  a.shared_grad = rc_idx32_fits(c->vol) ? rc_shared_grad_env() : 0;
   if (transform) { for (int k = 0; k < 16; ++k) a.pose_val.m[k] = transform->m[k]; a.pose = nullptr; }
   else a.pose = c->track->pose;
   hipLaunchKernelGGL(k_slab_ray_normals, dim3(kf_div_up(c->cols, 32), kf_div_up(c->rows, 8)), dim3(256), 0, c->stream, a);

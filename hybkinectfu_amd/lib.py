@@ -5,6 +5,7 @@ hybkinectfu_amd/host/.  There is NO CPU fallback: if the HIP library is missing,
 """
 import ctypes as C
 import os
+import weakref
 import subprocess
 
 import numpy as np
@@ -140,6 +141,15 @@ def half_camera(c):
     return CameraParams(c.cols // 2, c.rows // 2, f(c.cx) / f(2), f(c.cy) / f(2), f(c.fx) / f(2), f(c.fy) / f(2))
 
 
+_LIVE = weakref.WeakSet()
+
+
+def live_contexts():
+    """Contexts created through this module and not yet closed (a second live kf_ctx switches the persistent loops off, so a
+    leaked one changes launch forms: test harnesses close what a failed test left open)."""
+    return [c for c in list(_LIVE) if c.h]
+
+
 class Context:
     """One kf_ctx (one GPU / one z-slab)."""
 
@@ -154,6 +164,7 @@ class Context:
                      int(has_color), device, z0, z1, halo)
         self.h = C.c_void_p()
         _chk(self.lib.kf_create(C.byref(cfg), C.byref(self.h)), "kf_create")
+        _LIVE.add(self)
         z0s, z1s = C.c_uint32(), C.c_uint32()
         _chk(self.lib.kf_stored_z_range(self.h, C.byref(z0s), C.byref(z1s)), "kf_stored_z_range")
         self.stored = (z0s.value, z1s.value)

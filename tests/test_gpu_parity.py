@@ -5,6 +5,7 @@ triangle sequence.  Tolerance (stated per test): bilateral (device __expf), the 
 """
 import numpy as np
 import pytest
+from conftest import default_forms
 
 import oracle_lib as O
 from hybkinectfu_amd import lib as K
@@ -353,7 +354,7 @@ def test_icp_on_a_single_plane_is_lost_by_the_determinant_test_on_both_sides(cam
         ctx.icp_track(1, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
         ok_g, pose_g, status, iters = ctx.track_result()
         assert not ok_g and status == 1 and iters == 0 and np.array_equal(pose_g, pose), (second_context, ok_g, status, iters)
-        assert ctx.last_form == (2 if second_context else 1)
+        assert ctx.last_form == (2 if second_context else 1) or not default_forms()
         ctx.close()
         if other is not None:
             other.close()
@@ -458,7 +459,7 @@ def test_prefetched_preprocess_is_bit_identical():
         vol = pipe.ctx.download_volume()
         outs.append((poses, maps, vol))
         pipe.close()
-    assert 1 in forms["prefetch"] and 2 in forms["prefetch-per-step"] and 1 not in forms["prefetch-per-step"]     # persistent loop / one launch per step
+    assert (1 in forms["prefetch"] and 2 in forms["prefetch-per-step"] and 1 not in forms["prefetch-per-step"]) or not default_forms()     # persistent loop / one launch per step
     for other in outs[1:]:
         for a, b in zip(outs[0][0], other[0]):
             assert np.array_equal(a, b)

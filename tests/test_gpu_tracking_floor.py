@@ -12,6 +12,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import default_forms
 
 from hybkinectfu_amd import lib as K
 from hybkinectfu_amd import scene as S
@@ -50,7 +51,7 @@ def test_sequence_divergence_within_twice_the_oracle_floor(case, second_context)
     meta, o_poses = json.loads(str(g["meta"])), g["poses"]
     assert meta["all_tracked"] and 0 < meta["floor_dt_m"] < 2e-5 and 0 < meta["floor_dr"] < 2e-5
     poses, forms = gpu_sequence(meta, len(o_poses), second_context)
-    assert forms == ({0, 2} if second_context else {0, 1})          # frame 0 does not track; then the persistent loop resp. per-step launches
+    assert forms == ({0, 2} if second_context else {0, 1}) or not default_forms()          # frame 0 does not track; then the persistent loop resp. per-step launches
     dt = float(np.max(np.abs(poses[:, :3, 3].astype(np.float64) - o_poses[:, :3, 3])))
     dr = float(np.max(np.abs(poses[:, :3, :3].astype(np.float64) - o_poses[:, :3, :3])))
     assert dt <= 2.0 * meta["floor_dt_m"] and dr <= 2.0 * meta["floor_dr"], (dt, dr, meta["floor_dt_m"], meta["floor_dr"])
