@@ -6,6 +6,9 @@ import json
 import sys
 
 import numpy as np
+import torch
+
+torch.zeros(1, device="cuda:0")          # (torch's HIP runtime first, as everywhere in the suite: initialised after the library's, it finds no device)
 
 from hybkinectfu_amd import lib as K
 from hybkinectfu_amd import scene as S
@@ -35,7 +38,6 @@ def main(res, cols, rows):
                     if tag == "n":
                         out["%s%dhits" % (name, j)] = int((np.abs(a[..., :3]).sum(axis=-1) > 0).sum())
             else:
-                import torch
                 ta = torch.empty((rows, cols), dtype=torch.int64, device="cuda:0")
                 cand = torch.empty((rows, cols, 3), dtype=torch.float32, device="cuda:0")
                 ctx.raycast_slab_cross(pose, 0.7 * trunc, P["depth_trunc_min"], P["depth_trunc_max"], ta.data_ptr())

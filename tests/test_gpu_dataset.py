@@ -48,6 +48,11 @@ def test_dataset_frames_tracked_and_recorded(tmp_path):
         q = H.quat_from_pose(got[k])
         assert lines[3 + k] == "%.14g %.6g %.6g %.6g %.6g %.6g %.6g %.6g" % (
             (float("%.6f" % stamps[k]),) + tuple(float(v) for v in got[k][:3, 3]) + tuple(float(v) for v in q))
+        # ... and independently of the library's own converter: the written quaternion (x y z w, TrajectoryRecorder.cpp) is the pose's rotation
+        from scipy.spatial.transform import Rotation
+        fq = np.array([float(v) for v in lines[3 + k].split()[4:8]])
+        ref = Rotation.from_matrix(got[k][:3, :3].astype(np.float64)).as_quat()
+        assert min(np.max(np.abs(fq - ref)), np.max(np.abs(fq + ref))) < 5e-6, (k, fq, ref)
 
 
 def test_pose_finder_from_file_drives_the_fusion(tmp_path):
@@ -65,6 +70,10 @@ def test_pose_finder_from_file_drives_the_fusion(tmp_path):
     app.close()
     # CameraPoseFinderFromFile.cpp:82-87: frame 0 keeps the initial pose, later frames are re-based on it
     file_pose = [H.pose_from_quat(*_file_row(d, k)) for k in range(n)]
+    from scipy.spatial.transform import Rotation
+    for k in range(n):                                           # the library's quaternion -> pose against scipy's
+        t, q = _file_row(d, k)
+        assert np.allclose(file_pose[k][:3, :3], Rotation.from_quat(np.asarray(q, np.float64)).as_matrix(), atol=1e-5) and np.allclose(file_pose[k][:3, 3], t, atol=1e-7)
     refer = poses[0].astype(np.float64) @ np.linalg.inv(file_pose[0].astype(np.float64))
     assert np.array_equal(poses[0], S.pose0(size).astype(np.float32))
     for k in range(1, n):
