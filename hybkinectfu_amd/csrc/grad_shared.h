@@ -53,8 +53,9 @@ __device__ __forceinline__ RcGradCells rc_grad_cells(const KfVolume& v, float3 v
   return G;
 }
 
-// Addressing.  Element offsets in 32 bits (any stored volume of at most 2^32 voxels: 1024^3 whole; the launch checks rc_idx32_fits), separable:
-// idx(x, y, z) = ox(x) + oy(y) + oz(z), coordinates clamped into the stored volume.  Here as BYTE offsets modulo 2^32.
+// Addressing: BYTE offsets modulo 2^32, separable -- off(x, y, z) = bx(x) + by(y) + bz(z) -- relative to a brick layer of the stored volume (the view's first:
+// below), coordinates clamped into the stored volume.  Every component may wrap; the sum is right whenever the true offset is below 2^32, which the view test
+// guarantees for every voxel a lane loads.  Any volume size (2048^3: 256 MB per brick layer, a view of 16 layers).
 struct RcIdx32Addr {
   unsigned nb, nb2; int zlo, zhi, R, bz0;
   __device__ __forceinline__ explicit RcIdx32Addr(const KfVolume& v) {
@@ -66,19 +67,17 @@ struct RcIdx32Addr {
   __device__ __forceinline__ unsigned bz(int z, int zb0) const { z = min(max(z, zlo), zhi); return (kf_opaque(__umul24((unsigned)((z >> 3) - bz0 - zb0), nb2)) << 12) + ((unsigned)(z & 7) << 9); }
   __device__ __forceinline__ int zbrick(int z) const { z = min(max(z, zlo), zhi); return (z >> 3) - bz0; }
 };
-__host__ __device__ static inline bool rc_idx32_fits(const KfVolume& v) {
-  return (unsigned long long)(v.bz1 - v.bz0) * (unsigned long long)v.nb * (unsigned long long)v.nb * KF_BRICK_VOX <= (1ull << 32);
-}
 // The loads go through a raw buffer descriptor (MI355X guide: __builtin_amdgcn_make_buffer_rsrc + raw_buffer_load: one 32-bit offset register per gather,
 // no 64-bit address pairs) whose base is WAVE-UNIFORM: the stored volume may hold 8 GB, a 32-bit byte offset reaches 4 GB, but the 64 neighbourhoods of one
 // 8x8-pixel wave lie within a few bricks of each other.  The view starts `half` brick layers (2 GB worth, at least one) below the first lane's
-// neighbourhood and is 2 * half layers deep; a wave with a lane outside it takes the generic path (a silhouette spanning more than a quarter of a
-// 1024^3 volume in z inside one 8x8 patch: rare).
+// neighbourhood and is 2 * half layers deep; a wave with a lane outside it takes the generic path (1024^3: a silhouette spanning more than a quarter of
+// the volume in z inside one 8x8 patch, rare; 2048^3: 16 brick layers = 0.5 m at 8 m, i.e. the waves on depth discontinuities).
 struct RcWaveView { __amdgpu_buffer_rsrc_t rsrc; int zb0; };
-__device__ __forceinline__ int rc_view_half_layers(const KfVolume& v) {
+__device__ __forceinline__ int rc_view_half_layers(const KfVolume& v, int forced) {
   const unsigned long long layer = (unsigned long long)v.nb * v.nb * KF_BRICK_VOX * sizeof(float2);       // bytes per brick layer
-  const unsigned long long h = (1ull << 31) / layer;
-  return h < 1 ? 1 : (int)h;
+  const unsigned long long h = (1ull << 31) / layer;                     // (>= 1 up to 5792 bricks per axis; kf_create stops at 1024)
+  const int most = h < 1 ? 1 : (h > 4096 ? 4096 : (int)h);
+  return forced > 0 && forced < most ? forced : most;                    // forced (KF_RAYCAST_VIEW_HALF, tests): a shallower view, so that small volumes meet its edges too
 }
 __device__ __forceinline__ RcWaveView rc_wave_view(const KfVolume& v, int zb0) {
   RcWaveView w; w.zb0 = zb0;
@@ -187,9 +186,10 @@ __device__ __forceinline__ bool rc_grad_taps(const KfVolume& v, const RcGradCell
 }
 
 // 0: the reference's verdict is false; 1: `grad` is the reference's gradient; 2: (wave-uniform) this wave must evaluate the generic way
-// force_generic (uniform; tests only): answer 2 -- the outcome never seen with real data (no tap of 8 M random points left its line), so the suite forces it
+// force_generic (uniform; tests only): answer 2 -- the outcome never seen with real data (no tap of 8 M random points left its line), so the suite forces it;
+// view_half (tests only, 0 = as deep as 32-bit offsets allow): see rc_view_half_layers
 template <int ROUNDS>
-__device__ __forceinline__ int rc_gradient_shared(const KfVolume& v, float3 samplepos, float3 vtx, const KfRecip& rS, const KfRecip& rcell, bool force_generic, float3& grad) {
+__device__ __forceinline__ int rc_gradient_shared(const KfVolume& v, float3 samplepos, float3 vtx, const KfRecip& rS, const KfRecip& rcell, bool force_generic, int view_half, float3& grad) {
   const float rf = (float)v.res;
   const int3 g = make_int3(kf_f2i(kf_div(samplepos.x * rf, rS)), kf_f2i(kf_div(samplepos.y * rf, rS)), kf_f2i(kf_div(samplepos.z * rf, rS)));
   const int R = v.res;
@@ -203,7 +203,7 @@ __device__ __forceinline__ int rc_gradient_shared(const KfVolume& v, float3 samp
   const RcIdx32Addr E(v);
   const int zb_lo = E.zbrick(G.c0[2].g - 1), zb_hi = E.zbrick(G.c0[2].g + 2);
   const unsigned long long fm = __ballot(fast);
-  const int half = rc_view_half_layers(v);
+  const int half = rc_view_half_layers(v, view_half);
   int zb0 = 0;
   if (fm) zb0 = max(__builtin_amdgcn_readlane(zb_lo, (int)(__ffsll((long long)fm) - 1)) - half, 0);
   const bool in_view = zb_lo >= zb0 && zb_hi < zb0 + 2 * half;

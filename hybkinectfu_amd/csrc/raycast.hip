@@ -18,7 +18,16 @@
 #include <stdlib.h>
 #include <string.h>
 
-static int rc_shared_grad_env() { static int sg = -1; if (sg < 0) { const char* e = getenv("KF_RAYCAST_SHARED_GRAD"); sg = e ? atoi(e) : 1; } return sg; }
+// KF_RAYCAST_SHARED_GRAD (0 / 1 / 2, see RaycastArgs::shared_grad) in bits 0-7, KF_RAYCAST_VIEW_HALF (tests: brick layers of the gathers' view on either side, 0 = most) above.
+// Read at every launch (two getenv calls), unlike the other switches: a test can then compare the forms on ONE context -- the only way at 2048^3, where a second process
+// would have to fuse 69 GB again.
+static int rc_shared_grad_env() {
+  const char* e = getenv("KF_RAYCAST_SHARED_GRAD"); const char* h = getenv("KF_RAYCAST_VIEW_HALF");
+  const int mode = e ? atoi(e) : 1, half = h ? atoi(h) : 0;
+  return mode <= 0 ? 0 : ((mode & 255) | ((half > 0 && half < 4096 ? half : 0) << 8));
+}
+// the gathers' view spans at least two brick layers: they must fit 32-bit offsets (they do up to 724 bricks per axis; beyond: six separate lookups)
+static int rc_shared_grad_for(const KfVolume& v) { return (unsigned long long)v.nb * v.nb * KF_BRICK_VOX * sizeof(float2) <= (1ull << 31) ? rc_shared_grad_env() : 0; }
 
 struct RaycastArgs {
   KfVolume vol;
@@ -86,7 +95,7 @@ __device__ __forceinline__ bool gradient_for_point(const KfVolume& v, float3 sam
 template <int BATCH, int ROUNDS>
 __device__ __forceinline__ bool gradient_for_point_either(int shared, bool odd_wave, const KfVolume& v, float3 samplepos, float3 vtx, const KfRecip& rS, const KfRecip& rcell, float3& grad) {
   int verdict = 2;
-  if (shared) verdict = rc_gradient_shared<ROUNDS>(v, samplepos, vtx, rS, rcell, shared == 2 && odd_wave, grad);       // (`shared` is a launch argument: uniform; 2: every other wave is sent down the generic path)
+  if (shared) verdict = rc_gradient_shared<ROUNDS>(v, samplepos, vtx, rS, rcell, (shared & 255) == 2 && odd_wave, shared >> 8, grad);       // (`shared` is a launch argument: uniform; 2: every other wave is sent down the generic path)
   if (verdict == 2) verdict = gradient_for_point<BATCH>(v, samplepos, vtx, rS, rcell, grad) ? 1 : 0;
   return verdict == 1;
 }
@@ -104,6 +113,9 @@ __device__ __forceinline__ bool gradient_for_point_either(int shared, bool odd_w
 #endif
 #ifndef RC_GRAD_ROUNDS
 #define RC_GRAD_ROUNDS 4          // the shared-neighbourhood form of those taps (grad_shared.h): gathers in 1 / 2 / 4 dependent rounds of 32 / 16 / 8
+#endif
+#ifndef RC_SLAB_GRAD_ROUNDS
+#define RC_SLAB_GRAD_ROUNDS 1     // the same in k_slab_ray_normals (no register cap there)
 #endif
 #define RAYCAST_LDS_BYTES 49152   // budget for the two bit tables: 3 workgroups x 8 waves stay resident per CU (160 KiB LDS)
 
@@ -532,7 +544,7 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
   { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_RAYCAST_EXP"); a.exp_mode = em; }
   { static int tb = -1; if (tb < 0) { const char* e = getenv("KF_RAYCAST_BOUNDS"); tb = e ? atoi(e) : 1; } a.tile_bounds = tb; }
-  a.shared_grad = rc_idx32_fits(c->vol) ? rc_shared_grad_env() : 0;
+  a.shared_grad = rc_shared_grad_for(c->vol);
   a.work = c->count_work ? c->counters : nullptr;
   size_t macro_bytes = (size_t)(c->vol.macro_words + c->vol.super_words) * 4;
   const size_t neg_bytes = kf_negbit_words(c->n_stored_bricks) * 4, meso_bytes = (size_t)c->vol.meso_words * 4;
@@ -691,7 +703,7 @@ __global__ void __launch_bounds__(256) k_slab_ray_normals(SlabNormalArgs a) {
       if (t < t_cross) kf_ray_advance(t, t_prev, a.inc, t_cross);            // the march's own chain of additions (its closed form, exact: kf_selftest_div mode 12): t ends ON t_cross, t_prev on the sample before it
       const float3 last_pos = kf_add(org, kf_scale(dir, t_prev));
       float3 grad;
-      if (gradient_for_point_either<6, 1>(a.shared_grad, ((blockIdx.x + blockIdx.y + (threadIdx.x >> 6)) & 1u) != 0u, v, last_pos, vtx, rS, rcell, grad)) out = grad;                  // (the six taps' 48 gathers in one batch: this kernel has the registers)
+      if (gradient_for_point_either<6, RC_SLAB_GRAD_ROUNDS>(a.shared_grad, ((blockIdx.x + blockIdx.y + (threadIdx.x >> 6)) & 1u) != 0u, v, last_pos, vtx, rS, rcell, grad)) out = grad;                  // (the six taps' 48 gathers in one batch: this kernel has the registers)
     }
   }
   a.cand[3 * i] = out.x; a.cand[3 * i + 1] = out.y; a.cand[3 * i + 2] = out.z;
@@ -704,7 +716,7 @@ extern "C" int kf_slab_ray_normals(kf_ctx* c, const kf_mat44* transform, const k
   a.vol = c->vol; a.ta = (const unsigned long long*)dev_ta_min; a.cand = dev_cand;
   a.cam.cols = (int)cam->cols; a.cam.rows = (int)cam->rows; a.cam.cx = cam->cx; a.cam.cy = cam->cy; a.cam.fx = cam->fx; a.cam.fy = cam->fy;
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane;
-  a.shared_grad = rc_idx32_fits(c->vol) ? rc_shared_grad_env() : 0;
+  a.shared_grad = rc_shared_grad_for(c->vol);
   if (transform) { for (int k = 0; k < 16; ++k) a.pose_val.m[k] = transform->m[k]; a.pose = nullptr; }
   else a.pose = c->track->pose;
   hipLaunchKernelGGL(k_slab_ray_normals, dim3(kf_div_up(c->cols, 32), kf_div_up(c->rows, 8)), dim3(256), 0, c->stream, a);

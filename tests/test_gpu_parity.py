@@ -578,6 +578,20 @@ def test_maximum_configuration_2048_cubed():
     assert st["updated_last"] > 4e8 and st["weight_gt0"] >= st["updated_last"] and st["bricks_active"] > 100_000      # (whole free-space bricks are retired by the cull from the second frame on: counted, not queued)
     hit = pipe.ctx.download_map(K.MAP_MODEL_VERTICES)[..., 3] != 0
     assert hit.sum() > 0.9 * hit.size
+    # the raycast's two gradient forms at this size (csrc/grad_shared.h: the gathers' view is 16 brick layers deep here, so waves on depth discontinuities take
+    # the fallback): identical maps from the same volume and pose; KF_RAYCAST_SHARED_GRAD is read per launch for exactly this
+    import os
+    maps = {}
+    for mode in ("1", "0", "2"):
+        os.environ["KF_RAYCAST_SHARED_GRAD"] = mode
+        try:
+            pipe.ctx.raycast(pose, 0.035, P["depth_trunc_min"], 8.0)
+        finally:
+            del os.environ["KF_RAYCAST_SHARED_GRAD"]
+        maps[mode] = (pipe.ctx.download_map(K.MAP_MODEL_VERTICES), pipe.ctx.download_map(K.MAP_MODEL_NORMALS))
+    assert (np.abs(maps["1"][1][..., :3]).sum(axis=-1) > 0).sum() > 0.8 * hit.size
+    for mode in ("0", "2"):
+        assert np.array_equal(bits(maps["1"][0]), bits(maps[mode][0])) and np.array_equal(bits(maps["1"][1]), bits(maps[mode][1])), mode
     pipe.ctx.marching_cubes(300 * size / res)
     cnt = C.c_uint32()
     assert pipe.ctx.lib.kf_triangle_count(pipe.ctx.h, C.byref(cnt)) == 0
