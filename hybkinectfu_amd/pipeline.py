@@ -212,10 +212,14 @@ class SlabExchange:
 
     def merge(self, overlap=None):
         dist = self.dist
-        pending = dist.all_reduce(self.ta, op=dist.ReduceOp.MIN, async_op=True)
-        if overlap is not None:
+        if overlap is None:
+            # nothing to overlap: a synchronous collective is enqueued on the CURRENT stream (the pipeline's own: torch >= 2.8 ProcessGroupNCCL, asyncOp = false) --
+            # an asynchronous one runs on RCCL's internal stream, with an event hand-off into it and another one back (~15 us of stream time per collective)
+            dist.all_reduce(self.ta, op=dist.ReduceOp.MIN)
+        else:
+            pending = dist.all_reduce(self.ta, op=dist.ReduceOp.MIN, async_op=True)
             overlap()             # runs while the collective is in flight (RCCL's own stream until wait() joins it)
-        pending.wait()
+            pending.wait()
         self.normals(self.ta, self.cand)
         dist.all_reduce(self.cand_bits, op=dist.ReduceOp.SUM)
         self.unpack(self.ta, self.cand)
