@@ -190,9 +190,9 @@ def merge_candidates(t, v, n, all_reduce_min, all_reduce_sum_i32):
 class SlabExchange:
     """The collective sequence that merges one frame's per-slab raycast results (first crossing along each ray wins):
 
-        MIN all-reduce(ta), asynchronous       ta[px] = (crossing parameter << 32 | vertex parameter alpha) as int64: positive floats order like their bits,
-          -> [overlap(): independent work]     so the first crossing along the ray wins and brings its alpha along
-          -> wait
+        MIN all-reduce(ta)                     ta[px] = (crossing parameter << 32 | vertex parameter alpha) as int64: positive floats order like their bits,
+          (asynchronous around overlap()       so the first crossing along the ray wins and brings its alpha along
+           when a caller passes one)
         normals(ta, cand)                      every rank rebuilds the winners' vertices from the rays; the OWNER of a vertex's layer writes the normal (3 words)
         integer SUM all-reduce(cand bits)      exactly one rank contributes non-zero bits per pixel; integer sums keep -0.0
         unpack(ta, cand)                       -> model maps (+ pyramids) of every rank
