@@ -32,6 +32,7 @@ struct IntegrateArgs {
   int clear_tiles, n_tile_floats;   // the fusion pass clears the tile tables (maxima to 0, minima to +inf) once the cull has read them
   int defer_cull;                // deferred-weight words are in use (k_integrate_pairs<.., DEFER>) and the tile minima describe this depth map: the cull may
                                  // retire whole free-space bricks (counted, their pending counts bumped, never queued)
+  int macro_depth;               // 1: the depth-range test once per macro cell in front of the 64 brick tests (cull_test_cell; KF_CULL_MACRO_DEPTH=0: off)
   int free_ok;                   // sdf_trunc > 0 (and the shortcut not disabled): free-space waves skip the quotients (k_integrate_pairs)
   unsigned long long* layer_work;   // non-null on sampled frames (kf_count_layer_work): voxels updated per BRICK LAYER of the whole volume, queued bricks only --
                                     // what z-slab ranks balance their boundaries on (pipeline.SlabPipeline.rebalance)
@@ -77,6 +78,32 @@ __device__ __forceinline__ bool cull_test_cell(const IntegrateArgs& a, const flo
   bool keep = cell_exists &&
               cull_sphere_visible(a, m, (float)(mx * 32 + 16) * cell, (float)(my * 32 + 16) * cell, (float)(mz * 32 + 16) * cell,
                                   27.0f * cell + 1e-4f * v.size, px, py, pz);
+  // The brick test's depth-range argument once for the whole macro cell (wave-uniform): its 32^3 voxel centres span +-15.5 cells around the centre; when the
+  // cell's pixel footprint spans at most 4 x 4 of the 16-pixel tiles, sixteen lanes read one tile maximum each, and unless SOME tile holds a depth whose
+  // surface the cell's near side can reach (z_near < tile maximum + truncation), no voxel of the cell passes the reference's predicate (:50, :64-67) -- the
+  // 64 brick tests (their loads, their quotients) are not made.  In a room seen from inside, most of the frustum's cells lie behind the walls.
+  if (keep && a.macro_depth) {
+    const float hM = 15.5f * cell, epsM = 1e-4f * v.size;
+    const float exM = hM * (fabsf(m[0]) + fabsf(m[1]) + fabsf(m[2])) + epsM, eyM = hM * (fabsf(m[4]) + fabsf(m[5]) + fabsf(m[6])) + epsM;
+    const float ezM = hM * (fabsf(m[8]) + fabsf(m[9]) + fabsf(m[10])) + epsM;
+    const float znM = pz - ezM, zfM = pz + ezM;
+    if (znM > 4.f * cell) {
+      const float xl = px - exM, xr = px + exM, yl = py - eyM, yr = py + eyM;
+      const float u0 = (xl < 0.f ? xl / znM : xl / zfM) * a.dcam.fx + a.dcam.cx, u1 = (xr > 0.f ? xr / znM : xr / zfM) * a.dcam.fx + a.dcam.cx;
+      const float w0 = (yl < 0.f ? yl / znM : yl / zfM) * a.dcam.fy + a.dcam.cy, w1 = (yr > 0.f ? yr / znM : yr / zfM) * a.dcam.fy + a.dcam.cy;
+      int ix0 = (int)floorf(u0 + (0.5f - KF_CULL_PX_SLACK)), ix1 = (int)floorf(u1 + (0.5f + KF_CULL_PX_SLACK));
+      int iy0 = (int)floorf(w0 + (0.5f - KF_CULL_PX_SLACK)), iy1 = (int)floorf(w1 + (0.5f + KF_CULL_PX_SLACK));
+      ix0 = max(ix0, 0); iy0 = max(iy0, 0); ix1 = min(ix1, a.dcam.cols - 1); iy1 = min(iy1, a.dcam.rows - 1);
+      if (ix0 > ix1 || iy0 > iy1) keep = false;                              // no voxel's pixel lies in the image
+      else {
+        const int tx0 = ix0 >> 4, tx1 = ix1 >> 4, ty0 = iy0 >> 4, ty1 = iy1 >> 4;
+        if (tx1 - tx0 < 4 && ty1 - ty0 < 4) {
+          const float t = a.tile_max[a.tile_off[1] + min(ty0 + ((lane >> 2) & 3), ty1) * a.tile_w[1] + min(tx0 + (lane & 3), tx1)];
+          if (__ballot(t != 0.f && znM < t + a.sdf_trunc) == 0ull) keep = false;
+        }
+      }
+    }
+  }
   keep = keep && bx < v.nb && by < v.nb && bz >= v.bz0 && bz < v.bz1;
   // brick: voxel centres span [(8b+0.5), (8b+7.5)] * cell per axis: an axis-aligned box of half-extent 3.5 cells around
   // (8b+4)*cell.  Every test below is linear in the voxel position, so its extreme over the box is the value at the centre plus

@@ -1000,6 +1000,7 @@ void kf_fill_cull_args(kf_ctx* c, IntegrateArgs& a, const kf_camera_params* dcam
   a.tinv = c->track->pose_inv; a.track = c->track;       // kept current by whoever commits the device-resident pose
   a.parity = c->int_parity;
   a.n_tile_floats = c->n_tile_floats;
+  { static int md = -1; if (md < 0) { const char* e = getenv("KF_CULL_MACRO_DEPTH"); md = e ? atoi(e) : 1; } a.macro_depth = md; }
 }
 bool kf_cull_tail_fits(const kf_ctx* c, int n_wg, int waves) {
   const int nmxy = (c->vol.nb + 3) >> 2, nmz = ((c->vol.bz1 + 3) >> 2) - (c->vol.bz0 >> 2);
