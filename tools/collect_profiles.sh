@@ -9,7 +9,7 @@ for c in $CFGS; do
   f=$(find gpurun_out/$RUN/trace_$c -name "*kernel_stats.csv" 2>/dev/null | head -1)
   [ -n "$f" ] && cp "$f" profiles/${TAG}_${c}_kernel_stats.csv && echo "profiles/${TAG}_${c}_kernel_stats.csv"
 done
-[ -f gpurun_out/$RUN/summary.txt ] && cp gpurun_out/$RUN/summary.txt profiles/${TAG}_summary.txt
+# (gpurun_out/$RUN/summary.txt -- the PMC summary -- is merged into profiles/${TAG}_summary.txt by hand: one file, blocks from the runs that are current)
 if [ -d gpurun_out/${RUN}_c3 ]; then
   cp gpurun_out/${RUN}_c3/kernel_stats.csv profiles/${TAG}_c3_kernel_stats.csv
   cp gpurun_out/${RUN}_c3/counters.txt profiles/${TAG}_c3_counters.txt
