@@ -1703,7 +1703,9 @@ extern "C" int kf_icp_track(kf_ctx* c, uint32_t frame_id, const kf_icp_params* i
   int fold_group = 0;
   {
     const bool beyond = c->loop_occupancy < 1 || (long long)grid0 > (long long)c->loop_occupancy * c->num_cus;
-    const int room = c->loop_occupancy_batched >= 1 ? c->num_cus - c->num_cus / 5 : 0;      // 256 CUs: 205 resident workgroups, 51 CUs left to the riders
+    static int room_env = -1;                                // KF_ICP_BATCHED_ROOM=n: resident workgroups of the batched loop (A/B; every launch form folds in groups of n, so the forms stay bitwise equal)
+    if (room_env < 0) { const char* e = getenv("KF_ICP_BATCHED_ROOM"); room_env = e ? atoi(e) : 0; }
+    const int room = c->loop_occupancy_batched >= 1 ? ((room_env >= 16 && room_env <= c->num_cus * c->loop_occupancy_batched) ? room_env : c->num_cus - c->num_cus / 5) : 0;      // 256 CUs: 205 resident workgroups, 51 CUs left to the riders
     const bool can_batch = beyond && batched_env && !coop_env && room >= 16 && grid0 <= KF_ICP_LOOP_MAX_WG;
     if (can_batch) fold_group = room;
     if (use_loop && beyond) {
