@@ -36,6 +36,9 @@ struct RaycastArgs {
   KfMat pose_val;
   float4* out_v; float4* out_n; uchar4* out_rgb;
   float* out_t;                  // optional: ray parameter of the first crossing this context detected (+inf: none) -- z-slab merge
+  unsigned long long* own_ta;    // z-slab merge, speculative normals (kf_raycast_volume_slab_cross_spec): a second copy of this context's words (the caller all-reduces out_ta in place) ...
+  float* out_spec;               // ... and, three floats per pixel, the gradient at this context's own crossing's vertex when that vertex lies in the layers it OWNS (else zeros):
+                                 // what kf_slab_ray_normals would compute for the pixel if this crossing wins the MIN all-reduce -- evaluated here, in the shadow of the march
   unsigned long long* out_ta;    // z-slab merge (what SlabPipeline runs): per pixel (bits of the crossing's ray parameter) << 32 | bits of the VERTEX's ray parameter
                                  // alpha -- +inf / 0 without a crossing, alpha 0 where the reference gives up at the crossing (raycastingVolume.cu:87-88).  Only the two
                                  // interpolations at the crossing are evaluated here; the gradient around the vertex is the job of whoever owns the vertex (k_slab_ray_normals)
@@ -422,20 +425,25 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
       const float3 pos = kf_add(org, kf_scale(dir, t_cross)), last_pos = kf_add(org, kf_scale(dir, t_cross_prev));
       float ftdt, ft; bool ok_cur, ok_last;
       kf_interpolate_sdf_pair(v, pos, last_pos, rS, rcell, ok_cur, ftdt, ok_last, ft);
-      if (a.out_ta) {
-        // z-slabs: the vertex org + dir * alpha may lie ANYWHERE along the ray -- alpha = t - inc * f(t) / (f(t) - f(t - inc)) extrapolates without bound when the
-        // two interpolated values nearly agree (an isolated negative voxel at a silhouette) -- so its gradient taps are not this slab's to read: only alpha leaves
-        if (ok_cur && ok_last) out_alpha = t_cross - a.inc * ftdt / (ftdt - ft);
-      } else
-      if (ok_cur && ok_last) {                                              // :87-88 `break` on either failure
+      // :87-88 `break` on either failure.  One gradient evaluation serves both outputs: the model maps (vertex, normal) -- or, z-slabs, the speculative normal.
+      // z-slabs: the vertex org + dir * alpha may lie ANYWHERE along the ray -- alpha = t - inc * f(t) / (f(t) - f(t - inc)) extrapolates without bound when the
+      // two interpolated values nearly agree (an isolated negative voxel at a silhouette) -- so its gradient taps are not this slab's to read unless the vertex
+      // lies in the layers it OWNS (the owner's part of k_slab_ray_normals, for this context's own crossing: same vertex, same layer test, same gradient;
+      // last_pos is the march's own previous sample -- what that kernel finds by replaying the chain of additions); alpha leaves either way.
+      if (ok_cur && ok_last) {
         const float alpha = t_cross - a.inc * ftdt / (ftdt - ft);
         const float3 vtx = kf_add(org, kf_scale(dir, alpha));
-        if (a.has_color) { uchar4 c = make_uchar4(0, 0, 0, 0); kf_interpolate_color(v, vtx, c); out_c = c; }
-        float3 grad;
-        if (gradient_for_point_either<RC_GRAD_BATCH, RC_GRAD_ROUNDS>(a.shared_grad, ((tile_x + tile_y + wave) & 1) != 0, v, last_pos, vtx, rS, rcell, grad)) {
-          out_v = make_float4(vtx.x, vtx.y, vtx.z, 1.0f);
-          out_n = make_float4(grad.x, grad.y, grad.z, 0.f);
+        bool want = true;
+        if (a.out_ta) {
           out_alpha = alpha;
+          int gzv = kf_f2i(kf_div(vtx.z * (float)v.res, rS));
+          gzv = max(0, min(gzv, v.res - 1));
+          want = a.out_spec != nullptr && __float_as_uint(alpha) != 0u && gzv >= v.own_z0 && gzv < v.own_z1;
+        } else if (a.has_color) { uchar4 c = make_uchar4(0, 0, 0, 0); kf_interpolate_color(v, vtx, c); out_c = c; }
+        float3 grad;
+        if (want && gradient_for_point_either<RC_GRAD_BATCH, RC_GRAD_ROUNDS>(a.shared_grad, ((tile_x + tile_y + wave) & 1) != 0, v, last_pos, vtx, rS, rcell, grad)) {
+          out_n = make_float4(grad.x, grad.y, grad.z, 0.f);
+          if (!a.out_ta) { out_v = make_float4(vtx.x, vtx.y, vtx.z, 1.0f); out_alpha = alpha; }
         }
       }
     } else if (t_cross < inf) out_v = make_float4(t_cross, 0.f, 0.f, 1.f);
@@ -447,7 +455,11 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
     out_n = make_float4((float)n_samp, (float)(n_macro & 0xFFFF), (float)(n_macro >> 16), 0.f);
   }
 #endif
-  if (a.out_ta) a.out_ta[pix] = ((unsigned long long)__float_as_uint(t_cross) << 32) | (unsigned long long)(t_cross < inf ? __float_as_uint(out_alpha) : 0u);
+  if (a.out_ta) {
+    const unsigned long long word = ((unsigned long long)__float_as_uint(t_cross) << 32) | (unsigned long long)(t_cross < inf ? __float_as_uint(out_alpha) : 0u);
+    a.out_ta[pix] = word;
+    if (a.out_spec) { a.own_ta[pix] = word; a.out_spec[3 * pix] = out_n.x; a.out_spec[3 * pix + 1] = out_n.y; a.out_spec[3 * pix + 2] = out_n.z; }
+  }
   else { a.out_v[pix] = out_v; a.out_n[pix] = out_n; }
   if (a.work) {
     // what the REFERENCE's march reads for this ray (raycastingVolume.cu:65-119): one voxel per sample from t_min up to the
@@ -522,7 +534,8 @@ __global__ void __launch_bounds__(RAYCAST_THREADS) __attribute__((amdgpu_waves_p
 }
 
 static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, const kf_raycast_params* rp, const kf_camera_params* cam,
-                          float near_plane, float far_plane, float* out_t, float4* out_v, float4* out_n, unsigned long long* out_ta = nullptr) {
+                          float near_plane, float far_plane, float* out_t, float4* out_v, float4* out_n, unsigned long long* out_ta = nullptr,
+                          unsigned long long* own_ta = nullptr, float* out_spec = nullptr) {
   if (!c || !rp || !cam) return KF_ERR_ARG;
   if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
   if (has_color && (!c->vol.color || !c->raycast_rgb)) return KF_ERR_STATE;
@@ -541,6 +554,7 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
     a.pyr.c1 = c->cols >> 1; a.pyr.r1 = c->rows >> 1; a.pyr.c2 = a.pyr.c1 >> 1; a.pyr.r2 = a.pyr.r1 >> 1;
   }
   a.out_v = out_v ? out_v : c->model_v[0]; a.out_n = out_n ? out_n : c->model_n[0]; a.out_rgb = c->raycast_rgb; a.out_t = out_t; a.out_ta = out_ta;
+  a.own_ta = own_ta; a.out_spec = (out_ta && own_ta) ? out_spec : nullptr;
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
   { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_RAYCAST_EXP"); a.exp_mode = em; }
   { static int tb = -1; if (tb < 0) { const char* e = getenv("KF_RAYCAST_BOUNDS"); tb = e ? atoi(e) : 1; } a.tile_bounds = tb; }
@@ -678,7 +692,15 @@ extern "C" int kf_raycast_volume_slab_cross(kf_ctx* c, const kf_mat44* transform
   if (st) return st;
   return raycast_launch(c, 0, transform, rp, cam, near_plane, far_plane, nullptr, nullptr, nullptr, (unsigned long long*)dev_ta);
 }
-struct SlabNormalArgs { KfVolume vol; KfCam cam; const float* pose; KfMat pose_val; const unsigned long long* ta; float* cand; float inc, near_plane, far_plane; int shared_grad; };   // cand: 3 floats per pixel
+extern "C" int kf_raycast_volume_slab_cross_spec(kf_ctx* c, const kf_mat44* transform, const kf_raycast_params* rp, const kf_camera_params* cam,
+                                                 float near_plane, float far_plane, uint64_t* dev_ta, uint64_t* dev_ta_own, float* dev_spec) {
+  if (!c || !rp || !dev_ta || !dev_ta_own || !dev_spec) return KF_ERR_ARG;
+  const int st = slab_halo_check(c, rp);
+  if (st) return st;
+  return raycast_launch(c, 0, transform, rp, cam, near_plane, far_plane, nullptr, nullptr, nullptr, (unsigned long long*)dev_ta, (unsigned long long*)dev_ta_own, dev_spec);
+}
+struct SlabNormalArgs { KfVolume vol; KfCam cam; const float* pose; KfMat pose_val; const unsigned long long* ta; float* cand; float inc, near_plane, far_plane; int shared_grad;
+                        const unsigned long long* own_ta; const float* spec; };   // own_ta / spec: kf_raycast_volume_slab_cross_spec's second outputs, or null   // cand: 3 floats per pixel
 __global__ void __launch_bounds__(256) k_slab_ray_normals(SlabNormalArgs a) {
   // (a workgroup is a 32x8 pixel tile, a wave an 8x8 patch of it: its 64 vertices stay inside a few bricks -- fewer cache lines per gather instruction)
   const int x = (int)blockIdx.x * 32 + (int)(threadIdx.x >> 6) * 8 + (int)(threadIdx.x & 7), y = (int)blockIdx.y * 8 + (int)((threadIdx.x >> 3) & 7);
@@ -689,7 +711,11 @@ __global__ void __launch_bounds__(256) k_slab_ray_normals(SlabNormalArgs a) {
   const float t_cross = __uint_as_float((unsigned)(w >> 32));
   const unsigned alpha_bits = (unsigned)w;
   float3 out = kf3(0.f, 0.f, 0.f);                                             // all-zero bits: not this rank's vertex, or no gradient (a found gradient is a unit vector)
-  if (t_cross < __builtin_huge_valf() && alpha_bits != 0u) {
+  if (t_cross < __builtin_huge_valf() && alpha_bits != 0u && a.own_ta && a.own_ta[i] == w) {
+    // this context's own crossing won: its march has evaluated the vertex already, if the vertex is this context's (zeros otherwise: the owner's
+    // own crossing word differs from the winner's, so the owner takes the branch below)
+    out = kf3(a.spec[3 * i], a.spec[3 * i + 1], a.spec[3 * i + 2]);
+  } else if (t_cross < __builtin_huge_valf() && alpha_bits != 0u) {
     float3 org, dir, cam_dir;
     rc_pixel_ray(a.cam, a.pose ? a.pose : a.pose_val.m, x, y, org, dir, cam_dir);
     const float3 vtx = kf_add(org, kf_scale(dir, __uint_as_float(alpha_bits)));
@@ -708,12 +734,13 @@ __global__ void __launch_bounds__(256) k_slab_ray_normals(SlabNormalArgs a) {
   }
   a.cand[3 * i] = out.x; a.cand[3 * i + 1] = out.y; a.cand[3 * i + 2] = out.z;
 }
-extern "C" int kf_slab_ray_normals(kf_ctx* c, const kf_mat44* transform, const kf_raycast_params* rp, const kf_camera_params* cam,
-                                   float near_plane, float far_plane, const uint64_t* dev_ta_min, float* dev_cand) {
+static int slab_ray_normals(kf_ctx* c, const kf_mat44* transform, const kf_raycast_params* rp, const kf_camera_params* cam,
+                            float near_plane, float far_plane, const uint64_t* dev_ta_min, const uint64_t* dev_ta_own, const float* dev_spec, float* dev_cand) {
   if (!c || !rp || !cam || !dev_ta_min || !dev_cand) return KF_ERR_ARG;
   if ((int)cam->cols != c->cols || (int)cam->rows != c->rows) return KF_ERR_ARG;
   SlabNormalArgs a;
   a.vol = c->vol; a.ta = (const unsigned long long*)dev_ta_min; a.cand = dev_cand;
+  a.own_ta = (dev_ta_own && dev_spec) ? (const unsigned long long*)dev_ta_own : nullptr; a.spec = dev_spec;
   a.cam.cols = (int)cam->cols; a.cam.rows = (int)cam->rows; a.cam.cx = cam->cx; a.cam.cy = cam->cy; a.cam.fx = cam->fx; a.cam.fy = cam->fy;
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane;
   a.shared_grad = rc_shared_grad_for(c->vol);
@@ -721,6 +748,15 @@ extern "C" int kf_slab_ray_normals(kf_ctx* c, const kf_mat44* transform, const k
   else a.pose = c->track->pose;
   hipLaunchKernelGGL(k_slab_ray_normals, dim3(kf_div_up(c->cols, 32), kf_div_up(c->rows, 8)), dim3(256), 0, c->stream, a);
   return (int)hipGetLastError();
+}
+extern "C" int kf_slab_ray_normals(kf_ctx* c, const kf_mat44* transform, const kf_raycast_params* rp, const kf_camera_params* cam,
+                                   float near_plane, float far_plane, const uint64_t* dev_ta_min, float* dev_cand) {
+  return slab_ray_normals(c, transform, rp, cam, near_plane, far_plane, dev_ta_min, nullptr, nullptr, dev_cand);
+}
+extern "C" int kf_slab_ray_normals_spec(kf_ctx* c, const kf_mat44* transform, const kf_raycast_params* rp, const kf_camera_params* cam,
+                                        float near_plane, float far_plane, const uint64_t* dev_ta_min, const uint64_t* dev_ta_own, const float* dev_spec, float* dev_cand) {
+  if (!dev_ta_own || !dev_spec) return KF_ERR_ARG;
+  return slab_ray_normals(c, transform, rp, cam, near_plane, far_plane, dev_ta_min, dev_ta_own, dev_spec, dev_cand);
 }
 struct SlabUnpackArgs { const unsigned long long* ta; const float* cand; float4* v; float4* n; KfCam cam; const float* pose; KfMat pose_val; KfPyrOut pyr; };   // cand: 3 floats per pixel
 // one 32x8 pixel tile per workgroup: the tile's whole 2x2 and 4x4 blocks also give levels 1 and 2 of the model maps' pyramids (kf_tile_pyramid),

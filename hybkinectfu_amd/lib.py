@@ -84,7 +84,7 @@ SYMBOLS = [
     "kf_icp_track", "kf_sdf_track", "kf_read_track_result", "kf_request_track_result", "kf_wait_track_result", "kf_integrate_volume", "kf_raycast_volume",
     "kf_marching_cubes", "kf_clear_triangles", "kf_triangle_count", "kf_read_triangles", "kf_download_map",
     "kf_upload_map", "kf_download_volume", "kf_upload_volume", "kf_get_volume_stats", "kf_stored_z_range",
-    "kf_stage_timers", "kf_read_stage_ms", "kf_read_work_counters", "kf_set_stream", "kf_raycast_volume_slab", "kf_slab_mask_candidates", "kf_set_model_maps_device", "kf_raycast_volume_slab_cross", "kf_slab_ray_normals", "kf_set_model_maps_rays", "kf_selftest_div",
+    "kf_stage_timers", "kf_read_stage_ms", "kf_read_work_counters", "kf_set_stream", "kf_raycast_volume_slab", "kf_slab_mask_candidates", "kf_set_model_maps_device", "kf_raycast_volume_slab_cross", "kf_slab_ray_normals", "kf_raycast_volume_slab_cross_spec", "kf_slab_ray_normals_spec", "kf_set_model_maps_rays", "kf_selftest_div",
     "kf_icp_partition_begin", "kf_icp_partition_steps", "kf_icp_partition_step", "kf_icp_partition_finish",
     "kf_sdf_partition_begin", "kf_sdf_partition_step", "kf_sdf_partition_finish", "kf_set_defer", "kf_inject_track_stall",
     "kf_download_volume_device", "kf_upload_volume_device", "kf_resize_slab", "kf_count_layer_work", "kf_read_layer_work",
@@ -372,6 +372,20 @@ class Context:
         tp = C.byref(Mat44.of(pose)) if pose is not None else None
         _chk(self.lib.kf_slab_ray_normals(self.h, tp, C.byref(rp), C.byref(self.cam), C.c_float(near), C.c_float(far), C.c_void_p(dev_ta_min),
                                           C.c_void_p(dev_cand)), "kf_slab_ray_normals")
+
+    def raycast_slab_cross_spec(self, pose, inc, near, far, dev_ta, dev_ta_own, dev_spec):
+        """raycast_slab_cross + a second copy of the words and the speculative normals of this context's own crossings (kf_raycast_volume_slab_cross_spec)"""
+        rp = RaycastParams(inc)
+        tp = C.byref(Mat44.of(pose)) if pose is not None else None
+        _chk(self.lib.kf_raycast_volume_slab_cross_spec(self.h, tp, C.byref(rp), C.byref(self.cam), C.c_float(near), C.c_float(far), C.c_void_p(dev_ta),
+                                                        C.c_void_p(dev_ta_own), C.c_void_p(dev_spec)), "kf_raycast_volume_slab_cross_spec")
+
+    def slab_ray_normals_spec(self, pose, inc, near, far, dev_ta_min, dev_ta_own, dev_spec, dev_cand):
+        """slab_ray_normals that copies the speculative normal where this context's own crossing won and evaluates the rest"""
+        rp = RaycastParams(inc)
+        tp = C.byref(Mat44.of(pose)) if pose is not None else None
+        _chk(self.lib.kf_slab_ray_normals_spec(self.h, tp, C.byref(rp), C.byref(self.cam), C.c_float(near), C.c_float(far), C.c_void_p(dev_ta_min),
+                                               C.c_void_p(dev_ta_own), C.c_void_p(dev_spec), C.c_void_p(dev_cand)), "kf_slab_ray_normals_spec")
 
     def set_model_maps_rays(self, pose, dev_ta_min, dev_cand):
         tp = C.byref(Mat44.of(pose)) if pose is not None else None

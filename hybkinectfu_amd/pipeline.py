@@ -4,6 +4,8 @@ SingleGpuPipeline: one context, the whole volume.  Everything a frame needs is e
 no host synchronisation: the pose and the tracking verdict stay on the device (kf_icp_track), integrate is predicated on
 the verdict inside the kernel (src/HybKinectfu.cpp:123), and raycast reads the device-resident pose.
 """
+import os
+
 from . import lib as K
 from . import scene as S
 
@@ -364,8 +366,19 @@ class SlabPipeline:
         assert self.stream.cuda_stream != 0
         self.ctx.set_stream(self.stream.cuda_stream)
         c = self.ctx
-        self.ex = SlabExchange(kcam.rows, kcam.cols, dev, dist,
-                               normals=lambda ta, cand: c.slab_ray_normals(None, self.inc, P["depth_trunc_min"], self.trunc_max, ta.data_ptr(), cand.data_ptr()),
+        # speculative normals (include/hybkf.h: kf_raycast_volume_slab_cross_spec): the marching launch evaluates the gradient of this rank's own crossings where it owns
+        # the vertex, keeps its own words in ta_own (ex.ta is all-reduced in place) and the gradients in spec; the normals launch copies them where the rank's crossing
+        # won and evaluates only what is left.  KF_SLAB_SPECULATE=0: the two-launch form without it (A/B).
+        self.speculate = os.environ.get("KF_SLAB_SPECULATE", "1") != "0"
+        self.ta_own = torch.empty((kcam.rows, kcam.cols), dtype=torch.int64, device=dev)
+        self.spec = torch.empty((kcam.rows, kcam.cols, 3), dtype=torch.float32, device=dev)
+
+        def normals(ta, cand):
+            if self.speculate:
+                c.slab_ray_normals_spec(None, self.inc, P["depth_trunc_min"], self.trunc_max, ta.data_ptr(), self.ta_own.data_ptr(), self.spec.data_ptr(), cand.data_ptr())
+            else:
+                c.slab_ray_normals(None, self.inc, P["depth_trunc_min"], self.trunc_max, ta.data_ptr(), cand.data_ptr())
+        self.ex = SlabExchange(kcam.rows, kcam.cols, dev, dist, normals=normals,
                                unpack=lambda ta, cand: c.set_model_maps_rays(None, ta.data_ptr(), cand.data_ptr()))
         self.sums = torch.zeros(32, dtype=torch.float32, device=dev)
         self._frame_ns, self._pooled_frame_s = 0, 0.0
@@ -482,7 +495,10 @@ class SlabPipeline:
         else:
             c.icp_track(frame_id, P["icp_thre_dist"], P["icp_thre_sin_angle"], P["camera_shake_dist"], P["camera_shake_angle"])
         c.integrate(None, P["integrate_sdf_trunc"], self.integ_dist)
-        c.raycast_slab_cross(None, self.inc, P["depth_trunc_min"], self.trunc_max, ex.ta.data_ptr())
+        if self.speculate:
+            c.raycast_slab_cross_spec(None, self.inc, P["depth_trunc_min"], self.trunc_max, ex.ta.data_ptr(), self.ta_own.data_ptr(), self.spec.data_ptr())
+        else:
+            c.raycast_slab_cross(None, self.inc, P["depth_trunc_min"], self.trunc_max, ex.ta.data_ptr())
 
         if self._merge_events is not None:
             e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)

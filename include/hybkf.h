@@ -201,7 +201,7 @@ int kf_raycast_volume(kf_ctx* ctx, int has_color, const kf_mat44* transform, con
  *   MIN all-reduce of the words   (caller; positive floats order like their bits: the first crossing along the ray wins and brings its alpha);
  *   kf_slab_ray_normals           every context rebuilds the winners' vertices from the pixels' rays -- a pure function of pose and camera, which all
  *                                 contexts hold bit for bit -- and the one that OWNS a vertex's voxel layer evaluates gradientForPoint (:16-42) for it:
- *                                 dev_cand[px] = float4 (normal xyz, 1), zeros elsewhere.  (The vertex is an extrapolation that can land far from the
+ *                                 dev_cand[px] = 3 floats (the unit normal), all-zero bits elsewhere.  (The vertex is an extrapolation that can land far from the
  *                                 crossing, outside the crossing slab's halo: its taps belong to the vertex's owner.)
  *   integer SUM all-reduce        of dev_cand (caller; one contributor per pixel: the owner's bits);
  *   kf_set_model_maps_rays        vertices from alpha, normals from dev_cand -> model maps and levels 1, 2 of their pyramids.
@@ -211,6 +211,16 @@ int kf_raycast_volume_slab_cross(kf_ctx* ctx, const kf_mat44* transform, const k
 int kf_slab_ray_normals(kf_ctx* ctx, const kf_mat44* transform, const kf_raycast_params* raycast_params, const kf_camera_params* depth_camera,
                         float near_plane, float far_plane, const uint64_t* dev_ta_min, float* dev_cand);
 int kf_set_model_maps_rays(kf_ctx* ctx, const kf_mat44* transform, const kf_camera_params* depth_camera, const uint64_t* dev_ta_min, const float* dev_cand);
+/* The same merge with the normals evaluated SPECULATIVELY by the marching launch (what pipeline.SlabPipeline runs): a context's own crossing is the likely
+ * winner of its pixel, and its vertex nearly always lies in the layers the context owns -- so kf_raycast_volume_slab_cross_spec also evaluates
+ * gradientForPoint (:16-42) there, in the shadow of the march, and leaves dev_ta_own[px] = a second copy of its word (the caller all-reduces dev_ta in place)
+ * and dev_spec[px] = 3 floats: that gradient, or zeros when the vertex is not this context's.  kf_slab_ray_normals_spec then copies dev_spec where the
+ * context's own word won (dev_ta_own[px] == dev_ta_min[px]) and evaluates only the rest -- vertices this context owns under a crossing another context
+ * met.  Same dev_cand as kf_slab_ray_normals, bit for bit; the caller pairs the buffers of ONE frame (same volume state, pose, camera, increment, planes). */
+int kf_raycast_volume_slab_cross_spec(kf_ctx* ctx, const kf_mat44* transform, const kf_raycast_params* raycast_params, const kf_camera_params* depth_camera,
+                                      float near_plane, float far_plane, uint64_t* dev_ta, uint64_t* dev_ta_own, float* dev_spec);
+int kf_slab_ray_normals_spec(kf_ctx* ctx, const kf_mat44* transform, const kf_raycast_params* raycast_params, const kf_camera_params* depth_camera,
+                             float near_plane, float far_plane, const uint64_t* dev_ta_min, const uint64_t* dev_ta_own, const float* dev_spec, float* dev_cand);
 /* MAP FORM of the merge (the earlier protocol, kept for per-kernel tests): the slab that meets a crossing evaluates the whole hit itself -- dev_t[px] =
  * the crossing's ray parameter (+inf if none), dev_v / dev_n[px] = float4 vertex / normal (zeros when the march gives up there) -- and the caller keeps,
  * per pixel, the entry with the smallest t (kf_slab_mask_candidates zeroes the losers for an integer SUM).  It drops the rare pixel whose extrapolated

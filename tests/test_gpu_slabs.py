@@ -13,6 +13,28 @@ pytestmark = pytest.mark.gpu
 P = S.STOCK
 
 
+def _normals_both_forms(c, cam, inc, ta, ta_min, dev):
+    """kf_slab_ray_normals and its speculative form (kf_raycast_volume_slab_cross_spec + kf_slab_ray_normals_spec, what SlabPipeline runs) on one context:
+    the same crossing words, the same candidates, bit for bit.  Returns the candidates."""
+    import torch
+    ta2, own = torch.empty_like(ta), torch.empty_like(ta)
+    spec = torch.empty((cam[1], cam[0], 3), dtype=torch.float32, device=dev)
+    c.raycast_slab_cross_spec(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], ta2.data_ptr(), own.data_ptr(), spec.data_ptr())
+    c.sync()
+    assert torch.equal(ta2, ta) and torch.equal(own, ta)
+    cand = torch.empty((cam[1], cam[0], 3), dtype=torch.float32, device=dev)
+    c.slab_ray_normals(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], ta_min.data_ptr(), cand.data_ptr())
+    cand2 = torch.full((cam[1], cam[0], 3), 7.0, dtype=torch.float32, device=dev)
+    c.slab_ray_normals_spec(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], ta_min.data_ptr(), own.data_ptr(), spec.data_ptr(), cand2.data_ptr())
+    c.sync()
+    assert torch.equal(cand.view(torch.int32), cand2.view(torch.int32))
+    # where this context's own crossing won, the candidate IS the speculative gradient
+    won = (own == ta_min) & ((ta_min & 0xFFFFFFFF) != 0)
+    assert torch.equal(cand2.view(torch.int32)[won], spec.view(torch.int32)[won])
+    return cand
+
+
+
 @pytest.mark.parametrize("world,maxw,frames,balanced", [(2, P["volume_max_weight"], 3, False), (4, P["volume_max_weight"], 3, False),
                                                         (2, 3.0, 9, False),       # max_weight 3: from frame 3 on the saturation-aware fusion runs in every context
                                                         (3, P["volume_max_weight"], 3, True)])   # unequal slabs from the one-frame work probe (bench.py's default for N > 1)
@@ -79,10 +101,8 @@ def test_slabs_equal_whole_volume(world, maxw, frames, balanced):
         ta_min = torch.stack(tas).min(dim=0).values.contiguous()
         acc = torch.zeros((cam[1], cam[0], 3), dtype=torch.int32, device=dev)
         owners = torch.zeros((cam[1], cam[0]), dtype=torch.int32, device=dev)
-        for c in slabs:
-            cand = torch.empty((cam[1], cam[0], 3), dtype=torch.float32, device=dev)
-            c.slab_ray_normals(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], ta_min.data_ptr(), cand.data_ptr())
-            c.sync()
+        for c, ta in zip(slabs, tas):
+            cand = _normals_both_forms(c, cam, inc, ta, ta_min, dev)
             acc += cand.view(torch.int32)
             owners += (cand.view(torch.int32) != 0).any(dim=-1).to(torch.int32)
         rays = acc.view(torch.float32).contiguous()
@@ -500,9 +520,7 @@ def test_vertex_extrapolated_out_of_the_crossing_slab():
         ta_min = torch.stack(tas).min(dim=0).values.contiguous()
         acc = torch.zeros((cam[1], cam[0], 3), dtype=torch.int32, device=dev)
         for r, c in enumerate(slabs):
-            cand = torch.empty((cam[1], cam[0], 3), dtype=torch.float32, device=dev)
-            c.slab_ray_normals(None, inc, P["depth_trunc_min"], P["depth_trunc_max"], ta_min.data_ptr(), cand.data_ptr())
-            c.sync()
+            cand = _normals_both_forms(c, cam, inc, tas[r], ta_min, dev)
             acc += cand.view(torch.int32)
             foreign += int(((cand.view(torch.int32) != 0).any(dim=-1) & (tas[r] != ta_min)).sum())           # this slab owns the vertex of a crossing another slab met
         rays = acc.view(torch.float32).contiguous()
