@@ -340,7 +340,7 @@ def launch_ranks(n, argv):
 
 def collective_selftest(args):
     """No GPU needed: the ranks form a gloo group and run SlabExchange -- the very sequence of collectives SlabPipeline issues per
-    frame (async MIN all-reduce of the 64-bit crossing words, overlap hook, normals by the vertex's owner, integer SUM all-reduce, unpack) -- on CPU tensors, with plain-torch
+    frame (MIN all-reduce of the 64-bit crossing words, normals by the vertex's owner, integer SUM all-reduce, unpack) -- on CPU tensors, with plain-torch
     restatements of the device launches (tests/slab_cpu_ops.py), and check the merged maps against the first-crossing rule.
     Used by tests/test_slab_distributed_cpu.py to cover the launcher path end to end at world_size 2."""
     import torch
@@ -528,8 +528,9 @@ def per_rank_leg(pipe, run, barrier, dist, world, rank, first, n_frames):
     rows = [{k: (int(v) if k in ("rank", "n_upd_per_frame", "bricks_queued_last_frame", "frames_lost", "z_begin", "z_end") else round(float(v), 2))
              for k, v in zip(keys, e.tolist())} for e in every]
     return dict(frames=n_frames, ranks=rows,
-                note="device time per frame and rank (HIP events; merge: torch events around MIN all-reduce + mask + integer SUM all-reduce + unpack, "
-                     "with the next frame's preprocess enqueued behind the first all-reduce)")
+                note="device time per frame and rank (HIP events; raycast: the marching launch incl. the speculative normals of the rank's own crossings; "
+                     "merge: torch events around MIN all-reduce + normals (a copy where the rank's crossing won) + integer SUM all-reduce + unpack, "
+                     "all enqueued on the pipeline's own stream)")
 
 
 def balanced_ranges(args, kcam, res, size, wl, world, device, first_frame_ptr):
