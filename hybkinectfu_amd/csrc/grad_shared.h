@@ -10,7 +10,7 @@
 // tap's own cell computation, not a premise: every tap's cell is computed the reference's way, and a wave in which some lane's tap lands
 // elsewhere (a rounding at a cell boundary; not met once in 8 M random points at four volume geometries, so tests force it) takes the generic path -- see gradient_for_point in raycast.hip.
 //
-// The separable brick addressing is sdf_rows.h's: idx(x, y, z) = ox(x) + oy(y) + oz(z).
+// The separable brick addressing follows sdf_rows.h (offset(x, y, z) = bx(x) + by(y) + bz(z)); sdf_rows.h is included for its 8-byte load type.
 #pragma once
 #include "kf_internal.h"
 #include "sdf_rows.h"
@@ -56,9 +56,9 @@ __device__ __forceinline__ RcGradCells rc_grad_cells(const KfVolume& v, float3 v
 // Addressing: BYTE offsets modulo 2^32, separable -- off(x, y, z) = bx(x) + by(y) + bz(z) -- relative to a brick layer of the stored volume (the view's first:
 // below), coordinates clamped into the stored volume.  Every component may wrap; the sum is right whenever the true offset is below 2^32, which the view test
 // guarantees for every voxel a lane loads.  Any volume size (2048^3: 256 MB per brick layer, a view of 16 layers).
-struct RcIdx32Addr {
+struct RcViewAddr {
   unsigned nb, nb2; int zlo, zhi, R, bz0;
-  __device__ __forceinline__ explicit RcIdx32Addr(const KfVolume& v) {
+  __device__ __forceinline__ explicit RcViewAddr(const KfVolume& v) {
     nb = (unsigned)v.nb; nb2 = nb * nb; zlo = v.bz0 * KF_BRICK; zhi = v.bz1 * KF_BRICK - 1; R = v.res; bz0 = v.bz0;
   }
   __device__ __forceinline__ unsigned bx(int x) const { x = min(max(x, 0), R - 1); return ((unsigned)(x >> 3) << 12) + ((unsigned)(x & 7) << 3); }
@@ -99,7 +99,7 @@ __device__ __forceinline__ float2 rc_view_load(const RcWaveView& w, unsigned byt
 template <int ROUNDS>
 __device__ __forceinline__ bool rc_grad_taps(const KfVolume& v, const RcGradCells& G, const RcWaveView& w, float f[6]) {
   static_assert(ROUNDS == 1 || ROUNDS == 2 || ROUNDS == 4, "");
-  const RcIdx32Addr E(v);
+  const RcViewAddr E(v);
   const int gx = G.c0[0].g, gy = G.c0[1].g, gz = G.c0[2].g;
   bool ok = gz - 1 >= E.zlo && gz + 2 <= E.zhi;                               // the four layers of the z line stored
 #pragma unroll
@@ -200,7 +200,7 @@ __device__ __forceinline__ int rc_gradient_shared(const KfVolume& v, float3 samp
   for (int ax = 0; ax < 3; ++ax) all_in = all_in && G.c0[ax].in && G.cp[ax].in && G.cm[ax].in;
   const bool wanted = in_g && all_in;                                 // otherwise the verdict is false whatever the voxels hold
   const bool fast = wanted && G.on_line;
-  const RcIdx32Addr E(v);
+  const RcViewAddr E(v);
   const int zb_lo = E.zbrick(G.c0[2].g - 1), zb_hi = E.zbrick(G.c0[2].g + 2);
   const unsigned long long fm = __ballot(fast);
   const int half = rc_view_half_layers(v, view_half);
