@@ -48,6 +48,7 @@ struct RaycastArgs {
   int neg_words;                 // words of vol.negbits to keep in LDS (0: the table does not fit -> brick flags are read from global memory)
   int meso_words;                // words of the meso table (16^3-voxel cells) to keep in LDS behind the macro / super tables (0: it does not fit)
   int shared_grad;               // 1: a crossing's six gradient taps come from one 32-voxel neighbourhood (grad_shared.h; KF_RAYCAST_SHARED_GRAD=0: six separate lookups; 2: shared, with every other wave forced down the fallback -- tests)
+  int bounds_meso;               // 1: where the volume has at most 8192 meso cells (up to 256^3), the tile bounds come from the meso table (KF_RAYCAST_BOUNDS_MESO=0: from the macro table)
   int tile_bounds;               // 1: every workgroup first bounds its tile's rays by the non-empty macro cells its frustum meets (rc_tile_bounds; KF_RAYCAST_BOUNDS=0: off)
   int exp_mode;                  // timing experiments only (KF_RAYCAST_EXP): 1 = stop at the crossing without evaluating it
   KfCounters* work;              // measurement passes only (kf_stage_timers bit 16): count the reference march's samples and the hits
@@ -267,7 +268,7 @@ __device__ __forceinline__ void rc_set_window(RcFrustum& f, const KfCam& cam, in
 // s_rb: [0] super-cell candidates, [1] / [2] the tile's bounds as bits, [3] spare, then the candidate list.
 // (A third level -- every wave testing the 64 bricks of each candidate macro cell against its own 8x8 patch's frustum -- was built and measured: the tests cost
 // more than the shorter march saves, 48.7 vs 46.2 us at 512^3 and 103 vs 85 us at 1024^3 where the bricks' bits do not fit into LDS; profiles/r05_raycast_bounds.txt)
-__device__ __forceinline__ void rc_tile_bounds(const RaycastArgs& a, const unsigned* s_macro, const unsigned* s_super, const unsigned* s_neg, bool neg_in_lds, const float* T,
+__device__ __forceinline__ void rc_tile_bounds(const RaycastArgs& a, const unsigned* s_macro, const unsigned* s_super, const unsigned* s_meso, const unsigned* s_neg, bool neg_in_lds, const float* T,
                                                int tile_x, int tile_y, unsigned* s_rb, float& t_lo, float& t_hi) {
   const KfVolume& v = a.vol;
   RcFrustum f;
@@ -282,22 +283,30 @@ __device__ __forceinline__ void rc_tile_bounds(const RaycastArgs& a, const unsig
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float lo = __builtin_huge_valf(), hi = 0.f;
   unsigned n = 0u;
-  if (nm * nm * nm <= RAYCAST_THREADS * 16) {
-    // few macro cells (up to 512^3: 4096): every thread tests its share of them directly -- one barrier instead of two, no list.  A thread takes whole BYTES of the
+  // small volumes (up to 256^3: 16^3 = 4096 meso cells of 16^3 voxels): the same scan over the MESO table -- cells half as wide, bounds twice as tight, where
+  // a 256^3 volume has only 8^3 macro cells (RaycastArgs::bounds_meso; the table is in LDS)
+  const int nq = v.nq;
+  const bool by_meso = a.bounds_meso && a.meso_words != 0 && nq * nq * nq <= RAYCAST_THREADS * 16;
+  if (by_meso || nm * nm * nm <= RAYCAST_THREADS * 16) {
+    // few cells (macro: up to 512^3 = 4096): every thread tests its share of them directly -- one barrier instead of two, no list.  A thread takes whole BYTES of the
     // table (one LDS read per eight cells, then only the set bits), cells numbered x-fastest
-    const int n_cells = nm * nm * nm;
-    const float inv_nm = 1.0f / (float)nm;
+    const unsigned* tbl = by_meso ? s_meso : s_macro;
+    const int nc = by_meso ? nq : nm;
+    const float edge = by_meso ? 16.f : (float)KF_MACRO;
+    const float r_cell = by_meso ? 0.8660254f * 1.01f * 16.f * cell + slack : r_macro;
+    const int n_cells = nc * nc * nc;
+    const float inv_nc = 1.0f / (float)nc;
     for (int byte = (int)threadIdx.x; byte * 8 < n_cells; byte += RAYCAST_THREADS) {
-      unsigned bits = (s_macro[byte >> 2] >> ((byte & 3) * 8)) & 0xFFu;
+      unsigned bits = (tbl[byte >> 2] >> ((byte & 3) * 8)) & 0xFFu;
       while (bits) {
         const int m = byte * 8 + (int)__builtin_ctz(bits);
         bits &= bits - 1u;
         if (m >= n_cells) break;
-        // m = (mz * nm + my) * nm + mx by two exact float quotients (m < 2^13, nm <= 20: the products are far from the rounding boundary after the +0.5)
-        const int q = (int)(((float)m + 0.5f) * inv_nm), mx = m - q * nm, mz = (int)(((float)q + 0.5f) * inv_nm), my = q - mz * nm;
+        // m = (mz * nc + my) * nc + mx by two exact float quotients (m < 2^13, nc <= 20: the products are far from the rounding boundary after the +0.5)
+        const int q = (int)(((float)m + 0.5f) * inv_nc), mx = m - q * nc, mz = (int)(((float)q + 0.5f) * inv_nc), my = q - mz * nc;
         float dist;
-        if (rc_sphere_in_frustum(f, ((float)(mx * KF_MACRO) + 0.5f * KF_MACRO) * cell, ((float)(my * KF_MACRO) + 0.5f * KF_MACRO) * cell, ((float)(mz * KF_MACRO) + 0.5f * KF_MACRO) * cell, r_macro, dist)) {
-          lo = fminf(lo, fmaxf(dist - r_macro, 0.f)); hi = fmaxf(hi, dist + r_macro);
+        if (rc_sphere_in_frustum(f, ((float)mx * edge + 0.5f * edge) * cell, ((float)my * edge + 0.5f * edge) * cell, ((float)mz * edge + 0.5f * edge) * cell, r_cell, dist)) {
+          lo = fminf(lo, fmaxf(dist - r_cell, 0.f)); hi = fmaxf(hi, dist + r_cell);
         }
       }
     }
@@ -369,7 +378,7 @@ __device__ __forceinline__ void raycast_tile(const RaycastArgs& a, int tile_x, i
   }
   const bool neg_in_lds = a.neg_words != 0;
   float tile_lo = 0.f, tile_hi = __builtin_huge_valf();
-  if (a.tile_bounds) rc_tile_bounds(a, s_macro, s_super, s_neg, neg_in_lds, a.pose ? a.pose : a.pose_val.m, tile_x, tile_y, s_rb, tile_lo, tile_hi);     // (uniform)
+  if (a.tile_bounds) rc_tile_bounds(a, s_macro, s_super, s_meso, s_neg, neg_in_lds, a.pose ? a.pose : a.pose_val.m, tile_x, tile_y, s_rb, tile_lo, tile_hi);     // (uniform)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // a workgroup is a 32x16 pixel tile, a wave an 8x8 patch of it
   const int x = tile_x * 32 + (wave & 3) * 8 + (lane & 7), y = tile_y * 16 + (wave >> 2) * 8 + (lane >> 3);
@@ -558,6 +567,7 @@ static int raycast_launch(kf_ctx* c, int has_color, const kf_mat44* transform, c
   a.inc = rp->ray_increment; a.near_plane = near_plane; a.far_plane = far_plane; a.has_color = has_color;
   { static int em = -1; if (em < 0) em = KF_EXP_ENV("KF_RAYCAST_EXP"); a.exp_mode = em; }
   { static int tb = -1; if (tb < 0) { const char* e = getenv("KF_RAYCAST_BOUNDS"); tb = e ? atoi(e) : 1; } a.tile_bounds = tb; }
+  { static int bm = -1; if (bm < 0) { const char* e = getenv("KF_RAYCAST_BOUNDS_MESO"); bm = e ? atoi(e) : 1; } a.bounds_meso = bm; }
   a.shared_grad = rc_shared_grad_for(c->vol);
   a.work = c->count_work ? c->counters : nullptr;
   size_t macro_bytes = (size_t)(c->vol.macro_words + c->vol.super_words) * 4;
